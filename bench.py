@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — SGD node-pair updates/s of the MI355X path-guided layout kernel (BASELINE.json metric).
+
+Workload (BASELINE.json configs[3], the one the HBM-roofline claim is quoted on; it fits one GPU):
+synthetic linearised pangenome, 1,000,000 nodes / 50 haplotype paths / ~4.6e7 path steps, seed 42,
+reference defaults (iter_max 30, 10*S terms per iteration, theta 0.99, cooling from iteration 15).
+A "step" is one SGD iteration (one learning-rate step): 10*S node-pair updates, sharded 1/G per
+GPU, followed by the coordinate-delta all-reduce when G > 1 (strong scaling: total terms fixed).
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Prints ONE JSON line on rank 0.  `roofline` is computed from HIP-event kernel durations measured
+inside the library on the launch stream; `cpu_baseline` times the CPU oracle (a restatement of the
+reference's Hogwild loop — the upstream binary cannot be built here) on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_TERM = 68.0      # SURVEY 8(d) / BASELINE.md 3: 52 B read + 16 B written per term
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--paths", type=int, default=50)
+    ap.add_argument("--streams", type=int, default=0, help="sampler streams per GPU (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--stress", action="store_true", help="also report sampled path stress of the final layout")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the layout kernels have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+
+    import odgi_amd as oa
+    from odgi_amd.distributed import DistributedLayout, HipEngine
+
+    t0 = time.time()
+    g = oa.Graph.synthetic(args.nodes, args.paths, seed=42)
+    iters = max(30, args.warmup + args.steps)
+    p = oa.LayoutParams.defaults(g, iter_max=iters, n_streams=args.streams, device=local_rank)
+    X0, Y0 = oa.initial_layout(g, "d", seed=42)
+    if rank == 0:
+        log(f"[bench] graph N={g.n_nodes} S={g.n_steps} P={g.n_paths} terms/iter={p.min_term_updates} "
+            f"built in {time.time() - t0:.1f}s")
+    eng = HipEngine(g, p, X0, Y0)
+    p.n_streams = eng.session.n_streams
+    p.stream_offset = rank * p.n_streams
+    if world > 1:  # disjoint sampler streams per rank: recreate the session with this rank's offset
+        eng.close()
+        eng = HipEngine(g, p, X0, Y0)
+    drv = DistributedLayout(p, eng)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        drv.step(it)
+    eng.session.kernel_time(reset=True)
+    fence()
+    t1 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        drv.step(it)
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = eng.session.kernel_time()
+
+    total_terms = float(p.min_term_updates) * args.steps
+    value = total_terms / elapsed
+    my_terms = drv.my_terms()
+    avg_kernel_s = (kernel_ms / 1e3) / max(launches, 1)
+    achieved = BYTES_PER_TERM * my_terms / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+
+    out = {
+        "metric": "SGD node-pair updates/sec",
+        "value": value,
+        "unit": "terms/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic linearised pangenome N={g.n_nodes} S={g.n_steps} P={g.n_paths} seed 42 "
+                               f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
+                               f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
+                   "streams_per_gpu": int(p.n_streams),
+                   "parallelism": f"term-sharded x{world}, graph replicated, delta all-reduce per eta step"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "pgsgd::sgd_iteration_kernel", "avg_kernel_ms": 1e3 * avg_kernel_s,
+                     "terms_per_launch": my_terms, "bytes_per_term": BYTES_PER_TERM},
+    }
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                pj = json.load(f)
+            out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = pj.get("source")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] could not read {prof}: {e}")
+
+    if args.stress and rank == 0:
+        X, Y = eng.result()
+        out["stress_sampled"] = oa.path_stress(g, X, Y, 2_000_000)
+        out["stress_initial"] = oa.path_stress(g, X0, Y0, 2_000_000)
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        # CPU baseline: the oracle's Hogwild restatement of path_sgd_layout.cpp:165-377 (fp64, 1 ms
+        # controller), reference Release flags minus -march=native, on a time-bounded sample of the
+        # same workload (same graph, same parameters, same initial layout).
+        from oracle import oracle as orc
+        og = orc.Graph.from_product(g)
+        cores = os.cpu_count() or 1
+        _, _, st = orc.layout_hogwild(og, orc.params_from(p), cores, X0, Y0, max_seconds=args.cpu_seconds, fast=True)
+        out["cpu_baseline"] = {
+            "value": st["terms"] / st["seconds"] if st["seconds"] > 0 else 0.0,
+            "unit": "terms/s", "cores": cores, "kind": "port",
+            "sample": f"{st['terms']} terms in {st['seconds']:.1f} s of the same workload "
+                      f"({cores} Hogwild threads, fp64, CPU restatement of the reference — upstream is unbuildable here)",
+        }
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+/*
+ * pgsgd.h — C ABI of the MI355X-native path-guided SGD 2D layout (the `odgi layout` hot path).
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, owns no global state and
+ * never calls exit(): errors come back as negative codes (pgsgd_strerror()).  This is the surface
+ * the reference's `--gpu` route would bind instead of `cuda::gpu_layout`
+ * (reference: src/cuda/layout.h:65-80, called from src/algorithms/path_sgd_layout.cpp:470-503).
+ *
+ * Terms:  N = nodes, S = path steps, P = paths.  A "term" is one sampled node-pair update
+ * (reference: src/algorithms/path_sgd_layout.cpp:178-375).
+ * Coordinates are per node END: X,Y have 2N entries, index 2*rank+0 = node start, 2*rank+1 = node
+ * end (reference: src/subcommand/layout_main.cpp:268-269,288; src/algorithms/layout.cpp:76-79).
+ */
+#ifndef PGSGD_H
+#define PGSGD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGSGD_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define PGSGD_OK              0
+#define PGSGD_E_INVALID      -1  /* bad argument / inconsistent view                              */
+#define PGSGD_E_NODEVICE     -2  /* no usable HIP device / HIP runtime error before launch        */
+#define PGSGD_E_HIP          -3  /* HIP runtime error (see pgsgd_last_error)                      */
+#define PGSGD_E_NOMEM        -4
+#define PGSGD_E_IO           -5  /* file could not be read / written                              */
+#define PGSGD_E_FORMAT       -6  /* malformed GFA / .lay                                          */
+#define PGSGD_E_NOTOPTIMIZED -7  /* node ids are not exactly 1..N (layout_main.cpp:148-151)       */
+#define PGSGD_E_UNSUPPORTED  -8
+
+const char* pgsgd_strerror(int code);
+/* thread-local detail text of the last failing call on this thread ("" if none). */
+const char* pgsgd_last_error(void);
+
+/* ---- the lowered graph: what graph_t + XP hand to the SGD loop ---------------------------- */
+/*
+ * Read-only, caller-owned HOST arrays, path-major (steps of path p are
+ * [path_first[p], path_first[p+1]) ).  Replaces, for this path:
+ *   node_len     <- graph.get_length(handle)                    (src/odgi.cpp:65-71)
+ *   path_first   <- XP::get_path_step_count per path, prefixed  (src/algorithms/xp.cpp:375-377)
+ *   step_path    <- XP npi_iv  (path id of a step; here 0-based) (xp.cpp:136-148, 434)
+ *   step_handle  <- XPPath::handles: 2*node_rank + is_reverse    (xp.cpp:585-595, 691-697)
+ *   step_pos     <- XPPath::positions: 0-based bp offset of the step start in its path
+ *                                                                (xp.cpp:607-617, 393-397)
+ * nr_iv (rank of a step in its path) is implicit: rank = k - path_first[step_path[k]].
+ */
+typedef struct pgsgd_graph_view {
+    uint64_t n_nodes;
+    uint64_t n_steps;
+    uint64_t n_paths;
+    const uint32_t* node_len;    /* [n_nodes]   */
+    const uint64_t* path_first;  /* [n_paths+1] */
+    const uint32_t* step_path;   /* [n_steps]   */
+    const uint32_t* step_handle; /* [n_steps]   */
+    const uint64_t* step_pos;    /* [n_steps]   */
+} pgsgd_graph_view;
+
+/* ---- parameters: the argument list of path_linear_sgd_layout_gpu -------------------------- */
+/* (reference: src/algorithms/path_sgd_layout.hpp:59-80; cuda::layout_config_t layout.h:65-77) */
+#define PGSGD_FLAG_COORD_LOAD_PLAIN   0x1u /* debug: read coordinates through L1/L2 (stale-prone)   */
+#define PGSGD_FLAG_NO_WAVE_MERGE      0x2u /* debug: skip the in-wavefront conflict merge            */
+
+typedef struct pgsgd_params {
+    uint64_t iter_max;                    /* -x, default 30                                        */
+    uint64_t iter_with_max_learning_rate; /* -F is parsed but the reference passes 0               */
+    uint64_t min_term_updates;            /* terms per iteration (-G/-U; default 10*S)             */
+    double   delta;                       /* -j, default 0                                         */
+    double   eps;                         /* -g, default 0.01                                      */
+    double   eta_max;                     /* -v, default (max steps per path)^2                    */
+    double   theta;                       /* -a, default 0.99                                      */
+    uint64_t space;                       /* -k, default max steps per path                        */
+    uint64_t space_max;                   /* -I, default 1000                                      */
+    uint64_t space_quantization_step;     /* -l, default 100                                       */
+    double   cooling_start;               /* -K, default 0.5                                       */
+    uint64_t seed;        /* sampler base seed; stream g seeds Xoshiro256+ with seed+g, exactly as  */
+                          /* reference worker tid does with 9399220+tid (path_sgd_layout.cpp:168)   */
+    uint32_t n_streams;   /* concurrent sampler streams (GPU lanes). 0 = choose from graph size     */
+    uint32_t stream_offset; /* first stream id of this device: rank r of a G-way run uses r*n_streams */
+    int32_t  device;      /* HIP device ordinal; -1 = current device                               */
+    int32_t  snapshot;    /* 1 = write <prefix><k> (.lay) after iteration k, k=1..iter_max-1        */
+    const char* snapshot_prefix;
+    int32_t  progress;    /* 1 = progress line on stderr                                           */
+    uint32_t flags;       /* PGSGD_FLAG_*                                                          */
+} pgsgd_params;
+
+#define PGSGD_DEFAULT_SEED 9399220ull
+
+typedef struct pgsgd_stats {
+    uint64_t iterations;      /* iterations actually run                                           */
+    uint64_t term_updates;    /* terms applied, all iterations                                     */
+    double   last_delta_max;  /* max |Delta| seen in the last iteration (early-stop quantity)       */
+    double   kernel_ms;       /* sum of update-kernel durations (HIP events on the launch stream)   */
+    double   wall_ms;         /* upload + iterations + download                                    */
+    uint32_t n_streams;       /* streams actually used                                             */
+    uint32_t early_stop;      /* 1 if Delta_max <= delta ended the run (path_sgd_layout.cpp:142)    */
+} pgsgd_stats;
+
+/* Fill every field of *p with the reference defaults derived from the path index
+ * (src/subcommand/layout_main.cpp:153-155,198-204,251-266). */
+int pgsgd_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p);
+
+/* Learning-rate schedule, iter_max+1 doubles (path_sgd_layout.cpp:433-468).  Returns count. */
+int64_t pgsgd_schedule(const pgsgd_params* p, double* etas, size_t capacity);
+
+/* Zipf zeta cache (path_sgd_layout.cpp:86-97).  size() then fill(). */
+size_t pgsgd_zeta_table_size(uint64_t space, uint64_t space_max, uint64_t space_quant);
+int pgsgd_zeta_table(double theta, uint64_t space, uint64_t space_max, uint64_t space_quant,
+                     double* zetas, size_t capacity);
+
+/* Initial layout (layout_main.cpp:268-330).  mode: 'd','r','u','g','h'.  seed==0 draws from
+ * std::random_device like the reference; any other value is reproducible.  X,Y: [2N] doubles. */
+int pgsgd_init_layout(const pgsgd_graph_view* g, char mode, uint64_t seed, double* X, double* Y);
+
+/* ---- one-shot run: the replacement for cuda::gpu_layout ------------------------------------ */
+/* X,Y: host fp32 [2N], pre-initialised, updated in place.  Blocking.  Fails with
+ * PGSGD_E_NODEVICE when no MI355X-class HIP device is usable: there is no CPU fallback. */
+int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p,
+                     float* X, float* Y, pgsgd_stats* stats);
+
+/* ---- session API: the same run, one iteration at a time ------------------------------------ */
+/* Used by the multi-GPU driver (one process per GPU; the coordinate all-reduce between eta
+ * steps happens outside, on the device buffer) and by the benchmark. */
+typedef struct pgsgd_session pgsgd_session;
+
+int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out);
+void pgsgd_session_destroy(pgsgd_session* s);
+/* host fp32 X,Y [2N]  <->  device float4-per-node {x0,y0,x1,y1} coordinate buffer */
+int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y);
+int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y);
+/* device pointer to the 4N-float coordinate buffer and to use an externally owned one instead */
+void* pgsgd_session_coords_ptr(pgsgd_session* s);
+int pgsgd_session_bind_coords(pgsgd_session* s, void* device_ptr_4N_floats);
+/* launch stream (hipStream_t as void*); set to make the session launch on a caller stream */
+void* pgsgd_session_stream(pgsgd_session* s);
+int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream);
+/* Asynchronously run `n_terms` terms with learning rate eta (cooling: 0/1) on the session stream. */
+int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms);
+/* Wait for the stream; returns max |Delta| of the last iteration in *delta_max (may be NULL). */
+int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
+/* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
+int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
+uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
+/* Parity hook: run the sampler only and write, for stream g and its j-th term (j < terms_per_stream),
+ * out[(j*n_streams+g)*4 + {0,1,2,3}] = {flat step a, flat step b, end offset a, end offset b}
+ * without touching coordinates or the persistent stream states. */
+int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t terms_per_stream, uint64_t* out);
+
+/* ---- graph input: GFA v1 -> lowered view (gfa_to_handle.cpp:27-217 + xp.cpp:49-175) -------- */
+typedef struct pgsgd_graph pgsgd_graph; /* owns its arrays */
+int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph** out);
+/* Seeded synthetic "linearised pangenome" (BASELINE.json configs 4/5). */
+int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_t seed, pgsgd_graph** out);
+void pgsgd_graph_free(pgsgd_graph* g);
+int pgsgd_graph_get_view(const pgsgd_graph* g, pgsgd_graph_view* view);
+uint64_t pgsgd_graph_edge_count(const pgsgd_graph* g);
+/* edges as handle pairs (2*rank+rev), [2*edge_count] */
+const uint64_t* pgsgd_graph_edges(const pgsgd_graph* g);
+const char* pgsgd_graph_path_name(const pgsgd_graph* g, uint64_t path);
+uint64_t pgsgd_graph_max_path_steps(const pgsgd_graph* g);
+
+/* ---- post-processing and output (layout_main.cpp:388-463; algorithms/layout.cpp) ----------- */
+/* Weakly connected components over the edges: comp_of_node[N] (component ids in discovery order,
+ * i.e. by lowest node rank: weakly_connected_components.cpp:8-68).  Returns component count. */
+int64_t pgsgd_weak_components(uint64_t n_nodes, const uint64_t* edges, uint64_t n_edges,
+                              uint32_t* comp_of_node);
+/* Stack components vertically with border 1000 (layout_main.cpp:407-435), in place. */
+int pgsgd_pack_components(uint64_t n_nodes, const uint32_t* comp_of_node, uint64_t n_comp,
+                          double* X, double* Y);
+int pgsgd_write_tsv(const char* path, uint64_t n_nodes, const uint32_t* comp_of_node,
+                    uint64_t n_comp, const double* X, const double* Y);
+/* .lay = f64 min_value + sdsl::enc_vector<> of the bit patterns (layout.cpp:43-61). */
+int pgsgd_write_lay(const char* path, uint64_t n_ends, const double* X, const double* Y);
+int pgsgd_lay_buffer(uint64_t n_ends, const double* X, const double* Y, uint8_t** buf, size_t* len);
+int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** X, double** Y);
+void pgsgd_free(void* p);
+
+/* ---- layout quality (no reference equivalent for 2D; odgi stats -s formula restated) -------- */
+/* Sampled path stress: mean over sampled same-path end pairs of ((|p_a-p_b| - d)/d)^2. */
+int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, const double* Y,
+                      uint64_t n_pairs, uint64_t seed, double* stress);
+/* stats_main.cpp:667-716 (2D branch): sum over paths of consecutive-step distances, per node and per bp */
+int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, const double* Y,
+                        double* per_node, double* per_bp);
+
+/* ---- the subcommand: argv as `odgi layout` takes it (layout_main.cpp:18-466) --------------- */
+int pgsgd_main_layout(int argc, char** argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGSGD_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of libpgsgd.so (the C ABI declared in include/pgsgd.h).
+
+The library is the product: HIP kernels for gfx950 plus the host code around them.  There is no
+Python or CPU implementation of the layout to fall back to: if the shared object is missing the
+import fails, and every compute entry point returns PGSGD_E_NODEVICE without a HIP device.
+"""
+import ctypes as C
+import os
+
+# torch ships its own HIP runtime with the same soname as /opt/rocm's; importing it first makes
+# libpgsgd bind to the runtime that owns torch's device memory and streams.
+import torch  # noqa: F401  (load order matters)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpgsgd.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C odgi_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback implementation.")
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+u32, u64, i32, i64, f64 = C.c_uint32, C.c_uint64, C.c_int32, C.c_int64, C.c_double
+P = C.POINTER
+
+
+class GraphView(C.Structure):
+    _fields_ = [("n_nodes", u64), ("n_steps", u64), ("n_paths", u64),
+                ("node_len", P(u32)), ("path_first", P(u64)), ("step_path", P(u32)),
+                ("step_handle", P(u32)), ("step_pos", P(u64))]
+
+
+class Params(C.Structure):
+    _fields_ = [("iter_max", u64), ("iter_with_max_learning_rate", u64), ("min_term_updates", u64),
+                ("delta", f64), ("eps", f64), ("eta_max", f64), ("theta", f64),
+                ("space", u64), ("space_max", u64), ("space_quantization_step", u64),
+                ("cooling_start", f64), ("seed", u64), ("n_streams", u32), ("stream_offset", u32),
+                ("device", i32), ("snapshot", i32), ("snapshot_prefix", C.c_char_p),
+                ("progress", i32), ("flags", u32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", u64), ("term_updates", u64), ("last_delta_max", f64),
+                ("kernel_ms", f64), ("wall_ms", f64), ("n_streams", u32), ("early_stop", u32)]
+
+
+FLAG_COORD_LOAD_PLAIN = 0x1
+FLAG_NO_WAVE_MERGE = 0x2
+DEFAULT_SEED = 9399220
+
+# every symbol include/pgsgd.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("pgsgd_strerror", C.c_char_p, [C.c_int]),
+    ("pgsgd_last_error", C.c_char_p, []),
+    ("pgsgd_params_defaults", C.c_int, [P(GraphView), P(Params)]),
+    ("pgsgd_schedule", i64, [P(Params), P(f64), C.c_size_t]),
+    ("pgsgd_zeta_table_size", C.c_size_t, [u64, u64, u64]),
+    ("pgsgd_zeta_table", C.c_int, [f64, u64, u64, u64, P(f64), C.c_size_t]),
+    ("pgsgd_init_layout", C.c_int, [P(GraphView), C.c_char, u64, P(f64), P(f64)]),
+    ("pgsgd_layout_run", C.c_int, [P(GraphView), P(Params), P(C.c_float), P(C.c_float), P(Stats)]),
+    ("pgsgd_session_create", C.c_int, [P(GraphView), P(Params), P(C.c_void_p)]),
+    ("pgsgd_session_destroy", None, [C.c_void_p]),
+    ("pgsgd_session_upload_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
+    ("pgsgd_session_download_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
+    ("pgsgd_session_coords_ptr", C.c_void_p, [C.c_void_p]),
+    ("pgsgd_session_bind_coords", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pgsgd_session_stream", C.c_void_p, [C.c_void_p]),
+    ("pgsgd_session_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pgsgd_session_iteration", C.c_int, [C.c_void_p, f64, C.c_int, u64]),
+    ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
+    ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
+    ("pgsgd_session_n_streams", u32, [C.c_void_p]),
+    ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
+    ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
+    ("pgsgd_graph_synthetic", C.c_int, [u64, u64, u64, P(C.c_void_p)]),
+    ("pgsgd_graph_free", None, [C.c_void_p]),
+    ("pgsgd_graph_get_view", C.c_int, [C.c_void_p, P(GraphView)]),
+    ("pgsgd_graph_edge_count", u64, [C.c_void_p]),
+    ("pgsgd_graph_edges", P(u64), [C.c_void_p]),
+    ("pgsgd_graph_path_name", C.c_char_p, [C.c_void_p, u64]),
+    ("pgsgd_graph_max_path_steps", u64, [C.c_void_p]),
+    ("pgsgd_weak_components", i64, [u64, P(u64), u64, P(u32)]),
+    ("pgsgd_pack_components", C.c_int, [u64, P(u32), u64, P(f64), P(f64)]),
+    ("pgsgd_write_tsv", C.c_int, [C.c_char_p, u64, P(u32), u64, P(f64), P(f64)]),
+    ("pgsgd_write_lay", C.c_int, [C.c_char_p, u64, P(f64), P(f64)]),
+    ("pgsgd_lay_buffer", C.c_int, [u64, P(f64), P(f64), P(P(C.c_uint8)), P(C.c_size_t)]),
+    ("pgsgd_read_lay", C.c_int, [C.c_char_p, P(u64), P(P(f64)), P(P(f64))]),
+    ("pgsgd_free", None, [C.c_void_p]),
+    ("pgsgd_path_stress", C.c_int, [P(GraphView), P(f64), P(f64), u64, u64, P(f64)]),
+    ("pgsgd_path_distance", C.c_int, [P(GraphView), P(f64), P(f64), P(f64), P(f64)]),
+    ("pgsgd_main_layout", C.c_int, [C.c_int, P(C.c_char_p)]),
+]
+for _name, _res, _args in SIGNATURES:
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class PgsgdError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        detail = lib.pgsgd_last_error().decode()
+        super().__init__(f"{where}: {lib.pgsgd_strerror(code).decode()}" + (f" ({detail})" if detail else ""))
+
+
+def check(code, where):
+    if code != 0:
+        raise PgsgdError(code, where)

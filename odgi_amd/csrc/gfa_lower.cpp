@@ -1,0 +1,366 @@
+// gfa_lower.cpp — GFA v1 -> the flat path-step index the SGD kernels read.
+//
+// Replaces, for `odgi layout`, the chain  gfa_to_handle (src/gfa_to_handle.cpp:27-217)
+//   -> graph_t -> XP::from_handle_graph (src/algorithms/xp.cpp:49-175, XPPath :543-649).
+// Only S, L and P lines are consumed (gfa_to_handle.cpp:45,72,108,193); segment names must be
+// non-negative integers (:75-79); duplicate ids (:89-93) and path steps on missing nodes (:162-170)
+// are errors; node rank = id-1 and the graph must be "optimized" = ids exactly 1..N
+// (src/odgi.cpp:752-758, enforced by layout_main.cpp:148-151); paths are numbered in P-line order
+// (odgi.cpp:1233-1234); the position of a step is the bp offset of its start in the path
+// (xp.cpp:607-617).  Instead of exit(1) every failure is an error code.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <thread>
+
+#include "pgsgd_internal.hpp"
+
+namespace {
+
+struct Line { const char* b; const char* e; };
+
+inline const char* next_tab(const char* p, const char* e) {
+    while (p < e && *p != '\t') ++p;
+    return p;
+}
+
+bool parse_uint(const char* b, const char* e, uint64_t* out) {
+    if (b >= e) return false;
+    uint64_t v = 0;
+    for (const char* p = b; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (uint64_t)(*p - '0');
+    }
+    *out = v;
+    return true;
+}
+
+struct ParsedPath {
+    std::vector<uint32_t> handles;
+    int err = 0;
+    std::string msg;
+};
+
+}  // namespace
+
+extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph** out) {
+    using pgsgd::set_error;
+    pgsgd::clear_error();
+    if (!path || !out) return PGSGD_E_INVALID;
+    *out = nullptr;
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) { set_error("cannot open '%s'", path); return PGSGD_E_IO; }
+    const std::streamoff size = in.tellg();
+    std::string buf;
+    try {
+        buf.resize((size_t)size);
+    } catch (...) { return PGSGD_E_NOMEM; }
+    in.seekg(0);
+    if (size > 0 && !in.read(&buf[0], size)) { set_error("cannot read '%s'", path); return PGSGD_E_IO; }
+    in.close();
+
+    std::vector<Line> s_lines, l_lines, p_lines;
+    {
+        const char* p = buf.data();
+        const char* end = p + buf.size();
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* le = nl ? nl : end;
+            const char* e = le;
+            if (e > p && e[-1] == '\r') --e;
+            if (e - p >= 2 && p[1] == '\t') {
+                if (p[0] == 'S') s_lines.push_back({p, e});
+                else if (p[0] == 'L') l_lines.push_back({p, e});
+                else if (p[0] == 'P') p_lines.push_back({p, e});
+            }
+            p = nl ? nl + 1 : end;
+        }
+    }
+    if (s_lines.empty()) { set_error("'%s' has no S lines", path); return PGSGD_E_FORMAT; }
+
+    auto g = new pgsgd_graph();
+    const uint64_t N = s_lines.size();
+    g->n_nodes = N;
+    g->node_len.assign(N, 0);
+    std::vector<uint8_t> seen(N, 0);
+    uint64_t min_id = UINT64_MAX, max_id = 0;
+    // nodes
+    for (const Line& ln : s_lines) {
+        const char* nb = ln.b + 2;
+        const char* ne = next_tab(nb, ln.e);
+        uint64_t id;
+        if (!parse_uint(nb, ne, &id)) {
+            set_error("segment name '%.*s' is not a non-negative integer node id", (int)(ne - nb), nb);
+            delete g;
+            return PGSGD_E_FORMAT;
+        }
+        min_id = std::min(min_id, id);
+        max_id = std::max(max_id, id);
+        const char* sb = ne < ln.e ? ne + 1 : ln.e;
+        const char* se = next_tab(sb, ln.e);
+        if (id >= 1 && id <= N) {
+            if (seen[id - 1]) { set_error("duplicate node id %llu", (unsigned long long)id); delete g; return PGSGD_E_FORMAT; }
+            seen[id - 1] = 1;
+            g->node_len[id - 1] = (uint32_t)(se - sb);
+        }
+    }
+    if (!(min_id == 1 && max_id == N)) {
+        set_error("the graph is not optimized: node ids span [%llu, %llu] for %llu nodes", (unsigned long long)min_id,
+                  (unsigned long long)max_id, (unsigned long long)N);
+        delete g;
+        return PGSGD_E_NOTOPTIMIZED;
+    }
+    // edges (only needed for the weakly-connected-component post step)
+    g->edges.reserve(l_lines.size() * 2);
+    for (const Line& ln : l_lines) {
+        const char* f[5];
+        const char* fe[5];
+        const char* p = ln.b + 2;
+        int nf = 0;
+        while (nf < 4 && p <= ln.e) {
+            const char* t = next_tab(p, ln.e);
+            f[nf] = p; fe[nf] = t; ++nf;
+            p = t + 1;
+        }
+        if (nf < 4 || fe[0] == f[0]) continue;  // gfa_to_handle.cpp:111 skips empty sources
+        uint64_t a, b;
+        if (!parse_uint(f[0], fe[0], &a) || !parse_uint(f[2], fe[2], &b) || a < 1 || a > N || b < 1 || b > N) {
+            set_error("edge '%.*s <--> %.*s' names a missing node", (int)(fe[0] - f[0]), f[0], (int)(fe[2] - f[2]), f[2]);
+            delete g;
+            return PGSGD_E_FORMAT;
+        }
+        const uint64_t ra = (fe[1] > f[1] && f[1][0] == '-') ? 1 : 0;
+        const uint64_t rb = (fe[3] > f[3] && f[3][0] == '-') ? 1 : 0;
+        g->edges.push_back(2 * (a - 1) + ra);
+        g->edges.push_back(2 * (b - 1) + rb);
+    }
+    // paths: parsed in parallel, numbered in file order
+    const uint64_t P = p_lines.size();
+    std::vector<ParsedPath> parsed(P);
+    g->path_names.resize(P);
+    std::atomic<uint64_t> next_path{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint64_t i = next_path.fetch_add(1);
+            if (i >= P) break;
+            const Line& ln = p_lines[i];
+            const char* nb = ln.b + 2;
+            const char* ne = next_tab(nb, ln.e);
+            g->path_names[i].assign(nb, ne);
+            const char* sb = ne < ln.e ? ne + 1 : ln.e;
+            const char* se = next_tab(sb, ln.e);
+            ParsedPath& pp = parsed[i];
+            // count commas for a single allocation
+            pp.handles.reserve((size_t)std::count(sb, se, ',') + 1);
+            const char* p = sb;
+            while (p < se) {
+                const char* c = (const char*)memchr(p, ',', (size_t)(se - p));
+                const char* te = c ? c : se;
+                if (te > p && !(te - p == 1 && *p == '*')) {
+                    const char orient = te[-1];
+                    uint64_t id;
+                    if ((orient != '+' && orient != '-') || !parse_uint(p, te - 1, &id)) {
+                        pp.err = PGSGD_E_FORMAT;
+                        pp.msg = "malformed path segment '" + std::string(p, te) + "' in path '" + g->path_names[i] + "'";
+                        break;
+                    }
+                    if (id < 1 || id > N) {
+                        pp.err = PGSGD_E_FORMAT;
+                        pp.msg = "path '" + g->path_names[i] + "' visits missing node '" + std::string(p, te - 1) + "'";
+                        break;
+                    }
+                    pp.handles.push_back((uint32_t)(2 * (id - 1) + (orient == '-' ? 1 : 0)));
+                }
+                p = c ? c + 1 : se;
+            }
+        }
+    };
+    {
+        const int nt = std::max(1, std::min(n_threads, 64));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    }
+    for (uint64_t i = 0; i < P; ++i)
+        if (parsed[i].err) {
+            set_error("%s", parsed[i].msg.c_str());
+            const int rc = parsed[i].err;
+            delete g;
+            return rc;
+        }
+    g->path_first.assign(P + 1, 0);
+    for (uint64_t i = 0; i < P; ++i) g->path_first[i + 1] = g->path_first[i] + parsed[i].handles.size();
+    const uint64_t S = g->path_first[P];
+    g->step_path.resize(S);
+    g->step_handle.resize(S);
+    g->step_pos.resize(S);
+    std::atomic<uint64_t> next_fill{0};
+    auto filler = [&]() {
+        for (;;) {
+            const uint64_t i = next_fill.fetch_add(1);
+            if (i >= P) break;
+            uint64_t k = g->path_first[i], pos = 0;
+            for (uint32_t h : parsed[i].handles) {
+                g->step_path[k] = (uint32_t)i;
+                g->step_handle[k] = h;
+                g->step_pos[k] = pos;
+                pos += g->node_len[h >> 1];
+                ++k;
+            }
+            std::vector<uint32_t>().swap(parsed[i].handles);
+        }
+    };
+    {
+        const int nt = std::max(1, std::min(n_threads, 64));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(filler);
+        filler();
+        for (auto& t : th) t.join();
+    }
+    *out = g;
+    return PGSGD_OK;
+}
+
+// Seeded synthetic "linearised pangenome" (BASELINE.json configs 4 and 5): a sorted
+// backbone of N nodes with geometric node lengths (mean 32 bp, clipped to [1,4096]); 5 % of the
+// nodes are the alternative allele of the node before them (a bubble: a haplotype takes one of the
+// two); each of the P haplotype paths walks the backbone, drops a node with p = 0.02 (deletion) and
+// traverses a node in reverse with p = 0.01.
+extern "C" int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_t seed, pgsgd_graph** out) {
+    pgsgd::clear_error();
+    if (!out || n_nodes < 2 || n_nodes > 0x7fffffffull || n_paths < 1) return PGSGD_E_INVALID;
+    auto g = new pgsgd_graph();
+    const uint64_t N = n_nodes;
+    g->n_nodes = N;
+    g->node_len.resize(N);
+    auto sm = [](uint64_t& x) {
+        uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&](uint64_t& x) { return (double)(sm(x) >> 11) * 0x1p-53; };
+    std::vector<uint8_t> is_alt(N, 0);
+    {
+        uint64_t x = seed ^ 0x6a09e667f3bcc909ull;
+        const double q = 1.0 / 32.0;  // geometric, mean 32
+        const double lq = std::log1p(-q);
+        for (uint64_t i = 0; i < N; ++i) {
+            const double u = unit(x);
+            double len = std::floor(std::log1p(-u) / lq) + 1.0;
+            if (len < 1) len = 1;
+            if (len > 4096) len = 4096;
+            g->node_len[i] = (uint32_t)len;
+            if (i >= 1 && !is_alt[i - 1] && unit(x) < 0.05) is_alt[i] = 1;
+        }
+        is_alt[N - 1] = 0;  // keep the last backbone node shared
+    }
+    // backbone edges: i -> i+1 for every consecutive choice (alt pairs get the four bubble edges)
+    for (uint64_t i = 0; i + 1 < N; ++i) {
+        if (is_alt[i + 1]) {  // bubble {i, i+1}: predecessor handled below, successor i+2
+            if (i + 2 < N) {
+                g->edges.push_back(2 * i); g->edges.push_back(2 * (i + 2));
+                g->edges.push_back(2 * (i + 1)); g->edges.push_back(2 * (i + 2));
+            }
+        } else if (!is_alt[i]) {
+            g->edges.push_back(2 * i); g->edges.push_back(2 * (i + 1));
+            if (i + 2 < N && is_alt[i + 2]) { g->edges.push_back(2 * i); g->edges.push_back(2 * (i + 2)); }
+        }
+    }
+    const uint64_t P = n_paths;
+    std::vector<std::vector<uint32_t>> walks(P);
+    const int nt = (int)std::min<uint64_t>(P, std::max(1u, std::thread::hardware_concurrency()));
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint64_t pi = next.fetch_add(1);
+            if (pi >= P) break;
+            uint64_t x = seed * 0x9e3779b97f4a7c15ull + 0x1234567ull + pi * 0xd1342543de82ef95ull;
+            auto& w = walks[pi];
+            w.reserve((size_t)((double)N * 0.95));
+            uint64_t i = 0;
+            while (i < N) {
+                uint64_t node = i;
+                if (i + 1 < N && is_alt[i + 1]) {
+                    if (sm(x) >> 63) node = i + 1;
+                    i += 2;
+                } else {
+                    i += 1;
+                }
+                if (unit(x) < 0.02) continue;  // deletion
+                const uint32_t rev = unit(x) < 0.01 ? 1u : 0u;
+                w.push_back((uint32_t)(2 * node + rev));
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    }
+    g->path_first.assign(P + 1, 0);
+    g->path_names.resize(P);
+    for (uint64_t pi = 0; pi < P; ++pi) {
+        g->path_first[pi + 1] = g->path_first[pi] + walks[pi].size();
+        g->path_names[pi] = "hap" + std::to_string(pi);
+    }
+    const uint64_t S = g->path_first[P];
+    g->step_path.resize(S);
+    g->step_handle.resize(S);
+    g->step_pos.resize(S);
+    next = 0;
+    auto filler = [&]() {
+        for (;;) {
+            const uint64_t pi = next.fetch_add(1);
+            if (pi >= P) break;
+            uint64_t k = g->path_first[pi], pos = 0;
+            for (uint32_t h : walks[pi]) {
+                g->step_path[k] = (uint32_t)pi;
+                g->step_handle[k] = h;
+                g->step_pos[k] = pos;
+                pos += g->node_len[h >> 1];
+                ++k;
+            }
+            std::vector<uint32_t>().swap(walks[pi]);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(filler);
+        filler();
+        for (auto& t : th) t.join();
+    }
+    *out = g;
+    return PGSGD_OK;
+}
+
+extern "C" void pgsgd_graph_free(pgsgd_graph* g) { delete g; }
+
+extern "C" int pgsgd_graph_get_view(const pgsgd_graph* g, pgsgd_graph_view* v) {
+    if (!g || !v) return PGSGD_E_INVALID;
+    v->n_nodes = g->n_nodes;
+    v->n_steps = g->n_steps();
+    v->n_paths = g->n_paths();
+    v->node_len = g->node_len.data();
+    v->path_first = g->path_first.data();
+    v->step_path = g->step_path.data();
+    v->step_handle = g->step_handle.data();
+    v->step_pos = g->step_pos.data();
+    return PGSGD_OK;
+}
+
+extern "C" uint64_t pgsgd_graph_edge_count(const pgsgd_graph* g) { return g ? g->edges.size() / 2 : 0; }
+extern "C" const uint64_t* pgsgd_graph_edges(const pgsgd_graph* g) { return g ? g->edges.data() : nullptr; }
+extern "C" const char* pgsgd_graph_path_name(const pgsgd_graph* g, uint64_t p) {
+    return (g && p < g->path_names.size()) ? g->path_names[p].c_str() : nullptr;
+}
+extern "C" uint64_t pgsgd_graph_max_path_steps(const pgsgd_graph* g) {
+    uint64_t m = 0;
+    if (g)
+        for (uint64_t p = 0; p + 1 < g->path_first.size(); ++p) m = std::max(m, g->path_first[p + 1] - g->path_first[p]);
+    return m;
+}

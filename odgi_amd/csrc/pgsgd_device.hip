@@ -1,0 +1,690 @@
+// pgsgd_device.hip — the HIP side of the path-guided SGD 2D layout for MI355X (gfx950, wave64).
+//
+// One launch = one learning-rate step ("iteration") of the reference's worker loop
+// (src/algorithms/path_sgd_layout.cpp:165-377): every GPU lane is one reference worker.  Lane g
+// owns a persistent Xoshiro256+ stream seeded with seed+g (the reference seeds worker tid with
+// 9399220+tid, :168-169) and draws, per term, exactly the reference's sequence of variates
+// (:182,205-206,215/228,235-237,253,262).  Terms i, i+L, i+2L, ... of an iteration belong to lane i.
+//
+// HBM layout (built once per session from the caller's SoA view, see build_step_records):
+//   recs   [S] x 16 B  {u32 handle = 2*rank+rev, u32 node length, u64 bp position of the step}
+//                      one 16-byte gather returns everything the term needs about a step, so the
+//                      node_len[] gather and the separate handle/position gathers disappear;
+//   coords [N] x 16 B  {x_start, y_start, x_end, y_end} fp32: one 8-byte gather per node end, both
+//                      fp32 atomics of an end land in the same 8 bytes;
+//   path_first [P+1] u64 — staged into LDS, (path, rank) of a flat step index by binary search,
+//                      which replaces the npi_iv/nr_iv gathers of the reference (xp.cpp:421-434);
+//   zetas  [~space_max + space/quant] f64 — read-only, L2 resident;
+//   rng    [4][L] u64 — SoA stream states, read and written once per launch, coalesced.
+// Coordinates are read with agent-scope loads (they bypass the per-CU L1, which is never refreshed
+// by other CUs' atomics) and updated with hardware fp32 atomic adds at agent scope.
+//
+// Built with -ffp-contract=off: the sampler is integer/fp64 work that the CPU oracle reproduces
+// bit for bit, and the fp32 update matches the oracle's fp32 mirror for a one-stream run.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pgsgd_internal.hpp"
+#include "pgsgd_math.hpp"
+
+namespace pgsgd {
+
+struct DevConst {
+    const uint4* recs;
+    const uint64_t* path_first;
+    const double* zetas;
+    float* coords;
+    uint64_t* rng;
+    unsigned int* delta_max_bits;
+    uint64_t n_steps;
+    uint32_t n_paths;
+    uint32_t n_streams;
+    uint64_t space, space_max, space_quant;
+    ZipfConst zc;
+};
+
+struct IterArgs {
+    uint64_t n_terms;
+    float eta;
+    uint32_t cooling;
+};
+
+constexpr int kBlock = 256;
+constexpr uint32_t kPathLdsCap = 4096;  // path_first entries staged in LDS (32 KiB)
+
+// largest p with pf[p] <= k  (pf[0] = 0 <= k < pf[n_paths])
+template <typename PF>
+__device__ __forceinline__ uint32_t find_path(const PF pf, uint32_t n_paths, uint64_t k) {
+    uint32_t lo = 0, hi = n_paths;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pf[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int COORD_LOAD>
+__device__ __forceinline__ float2 load_end(const float* coords, uint64_t end_idx) {
+    if (COORD_LOAD == 0) {
+        return *reinterpret_cast<const float2*>(coords + 2 * end_idx);
+    } else {
+        const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(coords + 2 * end_idx),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 r;
+        r.x = __uint_as_float((uint32_t)bits);
+        r.y = __uint_as_float((uint32_t)(bits >> 32));
+        return r;
+    }
+}
+
+struct Term {
+    uint64_t ka, kb;
+    uint64_t pos_a, pos_b;
+    uint32_t end_a, end_b;  // 2*rank + end offset
+};
+
+// The sampler: path_sgd_layout.cpp:182-270 on the lowered index.
+template <typename PF>
+__device__ __forceinline__ Term sample_term(const DevConst& c, const PF pf, uint32_t cooling, Xoshiro256Plus& rng) {
+    Term t;
+    uint64_t k, pstart, cnt;
+    do {  // :182-192 — a single-step path makes the reference draw again without counting a term
+        k = uniform_below(rng, c.n_steps);
+        const uint32_t p = find_path(pf, c.n_paths, k);
+        pstart = pf[p];
+        cnt = pf[p + 1] - pstart;
+    } while (cnt == 1);
+    const uint4 ra = c.recs[k];  // issued early; consumed after the partner is chosen
+    const uint64_t s_rank = k - pstart;
+    uint64_t b_rank;
+    if (cooling || coin(rng)) {                                          // :205
+        const bool back = (s_rank > 0 && coin(rng)) || s_rank == cnt - 1;  // :206
+        const uint64_t room = back ? s_rank : cnt - s_rank - 1;
+        const uint64_t jump = c.space < room ? c.space : room;
+        const double zeta_n = c.zetas[zeta_index(jump, c.space_max, c.space_quant)];
+        const uint64_t z = zipf(rng, c.zc, jump, zeta_n);
+        b_rank = back ? s_rank - z : s_rank + z;
+    } else {
+        b_rank = uniform_below(rng, cnt);                                // :235-237
+    }
+    t.ka = k;
+    t.kb = pstart + b_rank;
+    const uint4 rb = c.recs[t.kb];
+    // :242-269 — choose an end of each node; the path position moves to that end
+    const uint32_t flip_a = coin(rng), flip_b = coin(rng);
+    const uint32_t h_a = ra.x, h_b = rb.x;
+    uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32);
+    uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+    uint32_t off_a = h_a & 1u, off_b = h_b & 1u;
+    if (flip_a) { pos_a += ra.y; off_a ^= 1u; }
+    if (flip_b) { pos_b += rb.y; off_b ^= 1u; }
+    t.pos_a = pos_a;
+    t.pos_b = pos_b;
+    t.end_a = (h_a & ~1u) | off_a;
+    t.end_b = (h_b & ~1u) | off_b;
+    return t;
+}
+
+template <bool PF_LDS, int COORD_LOAD>
+__global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterArgs a) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    float dmax = 0.0f;
+    for (uint64_t ti = g; ti < a.n_terms; ti += L) {
+        const Term t = sample_term(c, pf, a.cooling, rng);
+        const float2 pa = load_end<COORD_LOAD>(c.coords, t.end_a);
+        const float2 pb = load_end<COORD_LOAD>(c.coords, t.end_b);
+        // :280-363 in fp32
+        const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
+        float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+        if (d == 0.0f) d = 1e-9f;
+        const float w = 1.0f / d;
+        float mu = a.eta * w;
+        if (mu > 1.0f) mu = 1.0f;
+        float dx = pa.x - pb.x;
+        const float dy = pa.y - pb.y;
+        if (dx == 0.0f) dx = 1e-9f;
+        const float dx2 = dx * dx;
+        const float dy2 = dy * dy;
+        const float mag = sqrtf(dx2 + dy2);
+        const float Delta = (mu * (mag - d)) / 2.0f;
+        dmax = fmaxf(dmax, fabsf(Delta));
+        const float r = Delta / mag;
+        const float r_x = r * dx, r_y = r * dy;
+        float* ca = c.coords + 2 * (uint64_t)t.end_a;
+        float* cb = c.coords + 2 * (uint64_t)t.end_b;
+        unsafeAtomicAdd(ca, -r_x);
+        unsafeAtomicAdd(ca + 1, -r_y);
+        unsafeAtomicAdd(cb, r_x);
+        unsafeAtomicAdd(cb + 1, r_y);
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+    // per-wavefront reduction of the early-stop quantity, one atomic per wave (:341-347)
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
+// sampler-only launch for parity checks: fresh streams, nothing is modified
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cooling, uint64_t seed_base,
+                                                       uint64_t terms_per_stream, uint64_t* out) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    rng.seed(seed_base + g);
+    for (uint64_t j = 0; j < terms_per_stream; ++j) {
+        const Term t = sample_term(c, pf, cooling, rng);
+        uint64_t* o = out + (j * (uint64_t)c.n_streams + g) * 4;
+        o[0] = t.ka;
+        o[1] = t.kb;
+        o[2] = t.end_a & 1u;
+        o[3] = t.end_b & 1u;
+    }
+}
+
+__global__ void seed_streams_kernel(uint64_t* rng, uint32_t n_streams, uint64_t seed_base) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_streams) return;
+    Xoshiro256Plus r;
+    r.seed(seed_base + g);
+    const size_t L = n_streams;
+    rng[g] = r.s0;
+    rng[L + g] = r.s1;
+    rng[2 * L + g] = r.s2;
+    rng[3 * L + g] = r.s3;
+}
+
+// SoA view -> 16-byte step records, on the device (the gather of node_len happens once, here)
+__global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len,
+                                   uint64_t n_steps, uint4* recs) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = step_handle[k];
+        const uint64_t pos = step_pos[k];
+        recs[k] = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
+    }
+}
+
+// host X[2N],Y[2N] (staged on the device) <-> interleaved coords[4N]
+__global__ void interleave_coords(const float* X, const float* Y, uint64_t n_ends, float* coords) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        coords[2 * i] = X[i];
+        coords[2 * i + 1] = Y[i];
+    }
+}
+__global__ void deinterleave_coords(const float* coords, uint64_t n_ends, float* X, float* Y) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        X[i] = coords[2 * i];
+        Y[i] = coords[2 * i + 1];
+    }
+}
+
+}  // namespace pgsgd
+
+// ---------------------------------------------------------------------------------------------
+// host side: the session
+using pgsgd::set_error;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PGSGD_E_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+struct pgsgd_session {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    pgsgd_params params{};
+    uint64_t n_nodes = 0, n_steps = 0, n_paths = 0;
+    uint32_t n_streams = 0;
+    bool pf_lds = false;
+    size_t lds_bytes = 0;
+    // device buffers
+    uint4* d_recs = nullptr;
+    uint64_t* d_path_first = nullptr;
+    double* d_zetas = nullptr;
+    float* d_coords = nullptr;
+    bool own_coords = true;
+    uint64_t* d_rng = nullptr;
+    unsigned int* d_delta_max = nullptr;
+    unsigned int* h_delta_max = nullptr;  // pinned
+    pgsgd::DevConst dc{};
+    // kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
+    double kernel_ms = 0;
+    uint64_t launches = 0;
+};
+
+static int pick_device(int requested, int* out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); the layout kernels run on MI355X only, there is no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return PGSGD_E_NODEVICE;
+    }
+    int dev = requested;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= count) { set_error("device %d requested but only %d present", dev, count); return PGSGD_E_NODEVICE; }
+    *out = dev;
+    return PGSGD_OK;
+}
+
+static int collect_events(pgsgd_session* s) {
+    for (auto& pr : s->pending_events) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        s->kernel_ms += ms;
+        s->launches++;
+        s->free_events.push_back(pr);
+    }
+    s->pending_events.clear();
+    return PGSGD_OK;
+}
+
+static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
+    // Full residency of the update kernel, but never more concurrent terms than the graph can take:
+    // atomic adds of concurrent terms on one node end accumulate (the reference's Hogwild stores
+    // overwrite instead), so the number of in-flight terms is kept below 1/8 of the node ends.
+    uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
+    uint64_t cap = (2 * s->n_nodes) / 8;
+    uint64_t n = std::min(full, std::max<uint64_t>(cap, 64));
+    n = std::max<uint64_t>(64, (n / 64) * 64);
+    if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
+    return (uint32_t)n;
+}
+
+extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
+    pgsgd::clear_error();
+    if (!out || !p) return PGSGD_E_INVALID;
+    *out = nullptr;
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (g->n_steps == 0 || g->n_paths == 0) { set_error("graph has no path steps"); return PGSGD_E_INVALID; }
+    if (p->space == 0 || p->space_quantization_step == 0 || !(p->theta < 1.0) || p->iter_max == 0) {
+        set_error("invalid SGD parameters (space, quantization step, theta < 1, iter_max)");
+        return PGSGD_E_INVALID;
+    }
+    int dev = 0;
+    rc = pick_device(p->device, &dev);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    auto s = new pgsgd_session();
+    s->device = dev;
+    s->params = *p;
+    s->n_nodes = g->n_nodes;
+    s->n_steps = g->n_steps;
+    s->n_paths = g->n_paths;
+    auto fail = [&](int code) {
+        pgsgd_session_destroy(s);
+        return code;
+    };
+#define S_TRY(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP);               \
+        }                                                                                       \
+    } while (0)
+    S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = true;
+    hipDeviceProp_t prop;
+    S_TRY(hipGetDeviceProperties(&prop, dev));
+
+    s->pf_lds = (g->n_paths + 1) <= pgsgd::kPathLdsCap;
+    s->lds_bytes = s->pf_lds ? (size_t)(g->n_paths + 1) * sizeof(uint64_t) : 0;
+
+    // stream count
+    if (p->n_streams) {
+        s->n_streams = p->n_streams;
+    } else {
+        int bpc = 0;
+        if (s->pf_lds)
+            S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_iteration_kernel<true, 1>, pgsgd::kBlock, s->lds_bytes));
+        else
+            S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_iteration_kernel<false, 1>, pgsgd::kBlock, 0));
+        if (bpc < 1) bpc = 1;
+        s->n_streams = auto_streams(s, prop.multiProcessorCount, bpc);
+    }
+
+    // step records: upload the SoA arrays, pack on the device, drop the staging copies
+    {
+        uint32_t *d_handle = nullptr, *d_len = nullptr;
+        uint64_t* d_pos = nullptr;
+        S_TRY(hipMalloc(&s->d_recs, g->n_steps * sizeof(uint4)));
+        S_TRY(hipMalloc(&d_handle, g->n_steps * sizeof(uint32_t)));
+        S_TRY(hipMalloc(&d_pos, g->n_steps * sizeof(uint64_t)));
+        S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
+        S_TRY(hipMemcpyAsync(d_handle, g->step_handle, g->n_steps * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+        S_TRY(hipMemcpyAsync(d_len, g->node_len, g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        const int grid = (int)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(pgsgd::build_step_records, dim3(grid), dim3(256), 0, s->stream, d_handle, d_pos, d_len, g->n_steps, s->d_recs);
+        S_TRY(hipGetLastError());
+        S_TRY(hipStreamSynchronize(s->stream));
+        (void)hipFree(d_handle);
+        (void)hipFree(d_pos);
+        (void)hipFree(d_len);
+    }
+    S_TRY(hipMalloc(&s->d_path_first, (g->n_paths + 1) * sizeof(uint64_t)));
+    S_TRY(hipMemcpy(s->d_path_first, g->path_first, (g->n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    {
+        const size_t nz = pgsgd_zeta_table_size(p->space, p->space_max, p->space_quantization_step);
+        std::vector<double> z(nz);
+        rc = pgsgd_zeta_table(p->theta, p->space, p->space_max, p->space_quantization_step, z.data(), nz);
+        if (rc) return fail(rc);
+        S_TRY(hipMalloc(&s->d_zetas, nz * sizeof(double)));
+        S_TRY(hipMemcpy(s->d_zetas, z.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    S_TRY(hipMalloc(&s->d_coords, g->n_nodes * 4 * sizeof(float)));
+    S_TRY(hipMemset(s->d_coords, 0, g->n_nodes * 4 * sizeof(float)));
+    S_TRY(hipMalloc(&s->d_rng, (size_t)s->n_streams * 4 * sizeof(uint64_t)));
+    S_TRY(hipMalloc(&s->d_delta_max, sizeof(unsigned int)));
+    S_TRY(hipMemset(s->d_delta_max, 0, sizeof(unsigned int)));
+    S_TRY(hipHostMalloc(&s->h_delta_max, sizeof(unsigned int)));
+    *s->h_delta_max = 0;
+    {
+        const int grid = (int)((s->n_streams + 255) / 256);
+        hipLaunchKernelGGL(pgsgd::seed_streams_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rng, s->n_streams,
+                           p->seed + (uint64_t)p->stream_offset);
+        S_TRY(hipGetLastError());
+        S_TRY(hipStreamSynchronize(s->stream));
+    }
+    pgsgd::DevConst& c = s->dc;
+    c.recs = s->d_recs;
+    c.path_first = s->d_path_first;
+    c.zetas = s->d_zetas;
+    c.coords = s->d_coords;
+    c.rng = s->d_rng;
+    c.delta_max_bits = s->d_delta_max;
+    c.n_steps = g->n_steps;
+    c.n_paths = (uint32_t)g->n_paths;
+    c.n_streams = s->n_streams;
+    c.space = p->space;
+    c.space_max = p->space_max;
+    c.space_quant = p->space_quantization_step;
+    c.zc.init(p->theta);
+    *out = s;
+    return PGSGD_OK;
+#undef S_TRY
+}
+
+extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto& pr : s->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : s->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (s->d_recs) (void)hipFree(s->d_recs);
+    if (s->d_path_first) (void)hipFree(s->d_path_first);
+    if (s->d_zetas) (void)hipFree(s->d_zetas);
+    if (s->d_coords && s->own_coords) (void)hipFree(s->d_coords);
+    if (s->d_rng) (void)hipFree(s->d_rng);
+    if (s->d_delta_max) (void)hipFree(s->d_delta_max);
+    if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
+    if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y) {
+    pgsgd::clear_error();
+    if (!s || !X || !Y) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n_ends = 2 * s->n_nodes;
+    float *dX = nullptr, *dY = nullptr;
+    HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
+    HIP_TRY(hipMalloc(&dY, n_ends * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(dX, X, n_ends * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(dY, Y, n_ends * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::interleave_coords, dim3(grid), dim3(256), 0, s->stream, dX, dY, n_ends, s->d_coords);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    (void)hipFree(dX);
+    (void)hipFree(dY);
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y) {
+    pgsgd::clear_error();
+    if (!s || !X || !Y) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n_ends = 2 * s->n_nodes;
+    float *dX = nullptr, *dY = nullptr;
+    HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
+    HIP_TRY(hipMalloc(&dY, n_ends * sizeof(float)));
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::deinterleave_coords, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends, dX, dY);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(X, dX, n_ends * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(Y, dY, n_ends * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    (void)hipFree(dX);
+    (void)hipFree(dY);
+    return PGSGD_OK;
+}
+
+extern "C" void* pgsgd_session_coords_ptr(pgsgd_session* s) { return s ? (void*)s->d_coords : nullptr; }
+
+extern "C" int pgsgd_session_bind_coords(pgsgd_session* s, void* dptr) {
+    pgsgd::clear_error();
+    if (!s || !dptr) return PGSGD_E_INVALID;
+    if (((uintptr_t)dptr & 15u) != 0) { set_error("coordinate buffer must be 16-byte aligned"); return PGSGD_E_INVALID; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_coords && s->own_coords) (void)hipFree(s->d_coords);
+    s->d_coords = (float*)dptr;
+    s->own_coords = false;
+    s->dc.coords = s->d_coords;
+    return PGSGD_OK;
+}
+
+extern "C" void* pgsgd_session_stream(pgsgd_session* s) { return s ? (void*)s->stream : nullptr; }
+
+extern "C" int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    int rc = collect_events(s);
+    if (rc) return rc;
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return PGSGD_OK;
+}
+
+extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return s ? s->n_streams : 0; }
+
+extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->pending_events.size() >= 64) {  // bound the event pool
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        int rc = collect_events(s);
+        if (rc) return rc;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!s->free_events.empty()) {
+        ev = s->free_events.back();
+        s->free_events.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&ev.first));
+        HIP_TRY(hipEventCreate(&ev.second));
+    }
+    HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
+    pgsgd::IterArgs a;
+    a.n_terms = n_terms;
+    a.eta = (float)eta;
+    a.cooling = cooling ? 1u : 0u;
+    const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
+    const uint32_t grid = (s->n_streams + block - 1) / block;
+    const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
+    HIP_TRY(hipEventRecord(ev.first, s->stream));
+    if (s->pf_lds) {
+        if (plain) hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<true, 0>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
+        else hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<true, 1>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
+    } else {
+        if (plain) hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<false, 0>), dim3(grid), dim3(block), 0, s->stream, s->dc, a);
+        else hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<false, 1>), dim3(grid), dim3(block), 0, s->stream, s->dc, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, s->stream));
+    s->pending_events.push_back(ev);
+    HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_sync(pgsgd_session* s, double* delta_max) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    int rc = collect_events(s);
+    if (rc) return rc;
+    if (delta_max) {
+        float f;
+        memcpy(&f, s->h_delta_max, sizeof f);
+        *delta_max = (double)f;
+    }
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset) {
+    if (!s) return PGSGD_E_INVALID;
+    if (total_ms) *total_ms = s->kernel_ms;
+    if (launches) *launches = s->launches;
+    if (reset) { s->kernel_ms = 0; s->launches = 0; }
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t terms_per_stream, uint64_t* out) {
+    pgsgd::clear_error();
+    if (!s || !out) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = (size_t)terms_per_stream * s->n_streams * 4;
+    uint64_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, n * sizeof(uint64_t)));
+    const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
+    const uint32_t grid = (s->n_streams + block - 1) / block;
+    const uint64_t seed_base = s->params.seed + (uint64_t)s->params.stream_offset;
+    if (s->pf_lds) hipLaunchKernelGGL((pgsgd::trace_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, cooling ? 1u : 0u, seed_base, terms_per_stream, d_out);
+    else hipLaunchKernelGGL((pgsgd::trace_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, cooling ? 1u : 0u, seed_base, terms_per_stream, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error("trace launch failed: %s", hipGetErrorString(e)); return PGSGD_E_HIP; }
+    return PGSGD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the one-shot run: iteration control of path_sgd_layout.cpp:120-163 with exact iteration lengths
+int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);
+
+extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, pgsgd_stats* stats) {
+    pgsgd::clear_error();
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!g || !p || !X || !Y) return PGSGD_E_INVALID;
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    // path_sgd_layout.cpp:64-74: nothing to do unless some path has more than one step
+    bool multi = false;
+    for (uint64_t i = 0; i < g->n_paths && !multi; ++i) multi = g->path_first[i + 1] - g->path_first[i] > 1;
+    if (!multi) {
+        int dev;  // still refuse to "succeed" without a device: the product never runs on the CPU
+        return pick_device(p->device, &dev);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    pgsgd_session* s = nullptr;
+    rc = pgsgd_session_create(g, p, &s);
+    if (rc) return rc;
+    std::vector<double> etas(p->iter_max + 1);
+    if (pgsgd_schedule(p, etas.data(), etas.size()) < 0) { pgsgd_session_destroy(s); return PGSGD_E_INVALID; }
+    rc = pgsgd_session_upload_coords(s, X, Y);
+    const uint64_t first_cooling = (uint64_t)std::floor(p->cooling_start * (double)p->iter_max);  // :39
+    uint64_t iters = 0, terms = 0;
+    double dmax = 0;
+    uint32_t early = 0;
+    std::vector<float> sx, sy;
+    for (uint64_t it = 0; rc == PGSGD_OK && it < p->iter_max; ++it) {
+        rc = pgsgd_session_iteration(s, etas[it], it >= first_cooling, p->min_term_updates);
+        if (rc) break;
+        rc = pgsgd_session_sync(s, &dmax);
+        if (rc) break;
+        ++iters;
+        terms += p->min_term_updates;
+        if (p->progress)
+            fprintf(stderr, "\r[odgi::path_linear_sgd_layout] 2D path-guided SGD: iteration %llu/%llu  eta %.4g  delta_max %.4g   ",
+                    (unsigned long long)(it + 1), (unsigned long long)p->iter_max, etas[it], dmax);
+        if (it + 1 >= p->iter_max) break;
+        if (dmax <= p->delta) {  // :142 (also stops at 0, as upstream notes)
+            if (p->progress)
+                fprintf(stderr, "\n[odgi::path_linear_sgd_layout] delta_max: %g <= delta: %g. Threshold reached, therefore ending iterations.\n", dmax, p->delta);
+            early = 1;
+            break;
+        }
+        if (p->snapshot && p->snapshot_prefix) {  // :379-408: snapshot k after iteration k, k = 1..iter_max-1
+            sx.resize(2 * g->n_nodes);
+            sy.resize(2 * g->n_nodes);
+            rc = pgsgd_session_download_coords(s, sx.data(), sy.data());
+            if (rc) break;
+            const std::string name = std::string(p->snapshot_prefix) + std::to_string(it + 1);
+            fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");
+            rc = pgsgd_write_lay_f32(name.c_str(), 2 * g->n_nodes, sx.data(), sy.data());
+        }
+    }
+    if (p->progress) fprintf(stderr, "\n");
+    if (rc == PGSGD_OK) rc = pgsgd_session_download_coords(s, X, Y);
+    if (stats) {
+        stats->iterations = iters;
+        stats->term_updates = terms;
+        stats->last_delta_max = dmax;
+        stats->n_streams = s->n_streams;
+        stats->early_stop = early;
+        pgsgd_session_kernel_time(s, &stats->kernel_ms, nullptr, 0);
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    pgsgd_session_destroy(s);
+    return rc;
+}
+
+int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y) {
+    std::vector<double> dx(n_ends), dy(n_ends);
+    for (uint64_t i = 0; i < n_ends; ++i) { dx[i] = X[i]; dy[i] = Y[i]; }
+    return pgsgd_write_lay(path, n_ends, dx.data(), dy.data());
+}

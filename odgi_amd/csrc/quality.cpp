@@ -1,0 +1,91 @@
+// quality.cpp — layout quality figures reported by the CLI and the benchmark.
+// The reference has no 2D stress metric; `odgi stats -s` with a layout
+// (src/subcommand/stats_main.cpp:667-716, 2D branch) is restated as pgsgd_path_distance, and the
+// sampled path stress is the SGD objective evaluated on pairs drawn by the SGD sampler itself.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pgsgd_internal.hpp"
+#include "pgsgd_math.hpp"
+
+extern "C" int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, const double* Y, uint64_t n_pairs,
+                                 uint64_t seed, double* stress) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X || !Y || !stress) return PGSGD_E_INVALID;
+    *stress = 0.0;
+    uint64_t max_steps = 0;
+    for (uint64_t p = 0; p < g->n_paths; ++p) max_steps = std::max(max_steps, g->path_first[p + 1] - g->path_first[p]);
+    if (max_steps < 2) return PGSGD_OK;
+    const uint64_t space = max_steps, space_max = 1000, quant = 100;
+    std::vector<double> zetas(pgsgd_zeta_table_size(space, space_max, quant));
+    rc = pgsgd_zeta_table(0.99, space, space_max, quant, zetas.data(), zetas.size());
+    if (rc) return rc;
+    pgsgd::ZipfConst zc;
+    zc.init(0.99);
+    pgsgd::Xoshiro256Plus rng;
+    rng.seed(seed);
+    double acc = 0.0;
+    uint64_t cnt = 0;
+    for (uint64_t n = 0; n < n_pairs; ++n) {
+        // the SGD sampler in its non-cooling mode: half Zipf partners, half uniform partners
+        const uint64_t k = pgsgd::uniform_below(rng, g->n_steps);
+        const uint64_t p = g->step_path[k];
+        const uint64_t pstart = g->path_first[p], c = g->path_first[p + 1] - pstart;
+        if (c == 1) continue;
+        const uint64_t s_rank = k - pstart;
+        uint64_t b_rank;
+        if (pgsgd::coin(rng)) {
+            const bool back = (s_rank > 0 && pgsgd::coin(rng)) || s_rank == c - 1;
+            const uint64_t room = back ? s_rank : c - s_rank - 1;
+            const uint64_t jump = std::min(space, room);
+            const uint64_t z = pgsgd::zipf(rng, zc, jump, zetas[pgsgd::zeta_index(jump, space_max, quant)]);
+            b_rank = back ? s_rank - z : s_rank + z;
+        } else {
+            b_rank = pgsgd::uniform_below(rng, c);
+        }
+        const uint64_t kb = pstart + b_rank;
+        const uint32_t ha = g->step_handle[k], hb = g->step_handle[kb];
+        uint64_t pa = g->step_pos[k], pb = g->step_pos[kb];
+        uint32_t oa = ha & 1u, ob = hb & 1u;
+        if (pgsgd::coin(rng)) { pa += g->node_len[ha >> 1]; oa ^= 1u; }
+        if (pgsgd::coin(rng)) { pb += g->node_len[hb >> 1]; ob ^= 1u; }
+        const double d = std::fabs((double)pa - (double)pb);
+        if (d == 0) continue;
+        const uint64_t i = (uint64_t)(ha & ~1u) | oa, j = (uint64_t)(hb & ~1u) | ob;
+        const double dx = X[i] - X[j], dy = Y[i] - Y[j];
+        const double e = (std::sqrt(dx * dx + dy * dy) - d) / d;
+        acc += e * e;
+        ++cnt;
+    }
+    *stress = cnt ? acc / (double)cnt : 0.0;
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, const double* Y, double* per_node, double* per_bp) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X || !Y) return PGSGD_E_INVALID;
+    double sum2d = 0.0;
+    uint64_t nodes = 0, bp = 0;
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        const uint64_t b = g->path_first[p], e = g->path_first[p + 1];
+        for (uint64_t k = b; k < e; ++k) {
+            const uint32_t h = g->step_handle[k];
+            if (k + 1 < e) {
+                const uint32_t i = g->step_handle[k + 1];
+                const double dx = X[h] - X[i], dy = Y[h] - Y[i];
+                sum2d += std::sqrt(dx * dx + dy * dy);
+            }
+            ++nodes;
+            bp += g->node_len[h >> 1];
+        }
+    }
+    if (per_node) *per_node = nodes ? sum2d / (double)nodes : 0.0;
+    if (per_bp) *per_bp = bp ? sum2d / (double)bp : 0.0;
+    return PGSGD_OK;
+}

@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference's layout interface over the C ABI (include/pgsgd.h).
+
+Names and argument meaning follow src/algorithms/path_sgd_layout.hpp:32-80 and
+src/algorithms/layout.hpp:24-40; the work happens in libpgsgd.so on the GPU.
+"""
+import ctypes as C
+import dataclasses
+import math
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+from .graph import Graph
+
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+
+
+def _f64(a):
+    return a.ctypes.data_as(_F64P)
+
+
+@dataclasses.dataclass
+class LayoutParams:
+    """Argument list of path_linear_sgd_layout[_gpu] (path_sgd_layout.hpp:59-80) plus GPU knobs."""
+    iter_max: int = 30
+    iter_with_max_learning_rate: int = 0
+    min_term_updates: int = 0
+    delta: float = 0.0
+    eps: float = 0.01
+    eta_max: float = 0.0
+    theta: float = 0.99
+    space: int = 0
+    space_max: int = 1000
+    space_quantization_step: int = 100
+    cooling_start: float = 0.5
+    seed: int = _lib.DEFAULT_SEED
+    n_streams: int = 0
+    stream_offset: int = 0
+    device: int = -1
+    snapshot_prefix: str = ""
+    progress: bool = False
+    flags: int = 0
+
+    @classmethod
+    def defaults(cls, graph: Graph, **overrides):
+        """layout_main.cpp:198-204,251-266 for a graph whose paths are all used."""
+        p = _lib.Params()
+        check(lib.pgsgd_params_defaults(C.byref(graph.view), C.byref(p)), "params_defaults")
+        out = cls(iter_max=p.iter_max, iter_with_max_learning_rate=p.iter_with_max_learning_rate,
+                  min_term_updates=p.min_term_updates, delta=p.delta, eps=p.eps, eta_max=p.eta_max,
+                  theta=p.theta, space=p.space, space_max=p.space_max,
+                  space_quantization_step=p.space_quantization_step, cooling_start=p.cooling_start,
+                  seed=p.seed)
+        return dataclasses.replace(out, **overrides)
+
+    def first_cooling_iteration(self):
+        return int(math.floor(self.cooling_start * float(self.iter_max)))  # path_sgd_layout.cpp:39
+
+    def to_c(self):
+        p = _lib.Params()
+        for f in ("iter_max", "iter_with_max_learning_rate", "min_term_updates", "delta", "eps", "eta_max",
+                  "theta", "space", "space_max", "space_quantization_step", "cooling_start", "seed",
+                  "n_streams", "stream_offset", "device", "flags"):
+            setattr(p, f, getattr(self, f))
+        p.snapshot = 1 if self.snapshot_prefix else 0
+        self._prefix_bytes = self.snapshot_prefix.encode() if self.snapshot_prefix else None
+        p.snapshot_prefix = self._prefix_bytes
+        p.progress = 1 if self.progress else 0
+        return p
+
+
+def path_linear_sgd_layout_schedule(params: LayoutParams):
+    """etas[0..iter_max] (path_sgd_layout.cpp:433-468)."""
+    etas = np.zeros(params.iter_max + 1, dtype=np.float64)
+    p = params.to_c()
+    n = lib.pgsgd_schedule(C.byref(p), _f64(etas), len(etas))
+    if n < 0:
+        check(int(n), "schedule")
+    return etas
+
+
+def zeta_table(theta, space, space_max, space_quantization_step):
+    """Zipf zeta cache (path_sgd_layout.cpp:86-97)."""
+    n = lib.pgsgd_zeta_table_size(space, space_max, space_quantization_step)
+    z = np.zeros(n, dtype=np.float64)
+    check(lib.pgsgd_zeta_table(theta, space, space_max, space_quantization_step, _f64(z), n), "zeta_table")
+    return z
+
+
+def initial_layout(graph: Graph, mode="d", seed=0):
+    """Initial X,Y [2N] float64 (layout_main.cpp:268-330); seed 0 = std::random_device as upstream."""
+    X = np.zeros(2 * graph.n_nodes, dtype=np.float64)
+    Y = np.zeros(2 * graph.n_nodes, dtype=np.float64)
+    check(lib.pgsgd_init_layout(C.byref(graph.view), mode.encode()[:1], int(seed), _f64(X), _f64(Y)), "init_layout")
+    return X, Y
+
+
+def path_linear_sgd_layout_gpu(graph: Graph, params: LayoutParams, X, Y):
+    """The `--gpu` entry (path_sgd_layout.hpp:59-80): X,Y [2N] pre-initialised, updated IN PLACE.
+
+    Accepts float64 arrays like the reference's vector<atomic<double>> (converted to the kernel's
+    fp32 and back) or float32 arrays (used as is).  Returns the run statistics.
+    """
+    if X.shape != (2 * graph.n_nodes,) or Y.shape != X.shape:
+        raise ValueError("X and Y must have 2*node_count entries")
+    Xf = np.ascontiguousarray(X, dtype=np.float32)
+    Yf = np.ascontiguousarray(Y, dtype=np.float32)
+    st = _lib.Stats()
+    p = params.to_c()
+    check(lib.pgsgd_layout_run(C.byref(graph.view), C.byref(p), Xf.ctypes.data_as(_F32P), Yf.ctypes.data_as(_F32P),
+                               C.byref(st)), "layout_run")
+    X[...] = Xf
+    Y[...] = Yf
+    return {f: getattr(st, f) for f, _ in _lib.Stats._fields_}
+
+
+class LayoutSession:
+    """One GPU's resident graph + coordinates; runs the SGD one learning-rate step at a time."""
+
+    def __init__(self, graph: Graph, params: LayoutParams):
+        self.graph = graph
+        self.params = params
+        self._h = C.c_void_p()
+        self._cparams = params.to_c()
+        check(lib.pgsgd_session_create(C.byref(graph.view), C.byref(self._cparams), C.byref(self._h)), "session_create")
+        self._bound = None
+
+    def close(self):
+        if self._h:
+            lib.pgsgd_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def n_streams(self):
+        return int(lib.pgsgd_session_n_streams(self._h))
+
+    def upload(self, X, Y):
+        Xf = np.ascontiguousarray(X, dtype=np.float32)
+        Yf = np.ascontiguousarray(Y, dtype=np.float32)
+        check(lib.pgsgd_session_upload_coords(self._h, Xf.ctypes.data_as(_F32P), Yf.ctypes.data_as(_F32P)), "upload")
+
+    def download(self):
+        n = 2 * self.graph.n_nodes
+        X = np.zeros(n, dtype=np.float32)
+        Y = np.zeros(n, dtype=np.float32)
+        check(lib.pgsgd_session_download_coords(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
+        return X, Y
+
+    def coords_tensor(self):
+        """The device coordinate buffer as a torch float32 tensor [N, 4] = {x0, y0, x1, y1}.
+
+        The tensor is allocated by torch (so RCCL collectives and torch streams see it) and bound
+        into the session; the previous contents are carried over."""
+        import torch
+        if self._bound is None:
+            X, Y = self.download()
+            dev = torch.device("cuda", torch.cuda.current_device() if self.params.device < 0 else self.params.device)
+            t = torch.empty((self.graph.n_nodes, 4), dtype=torch.float32, device=dev)
+            t[:, 0] = torch.from_numpy(X[0::2]).to(dev)
+            t[:, 1] = torch.from_numpy(Y[0::2]).to(dev)
+            t[:, 2] = torch.from_numpy(X[1::2]).to(dev)
+            t[:, 3] = torch.from_numpy(Y[1::2]).to(dev)
+            torch.cuda.synchronize(dev)
+            check(lib.pgsgd_session_bind_coords(self._h, C.c_void_p(t.data_ptr())), "bind_coords")
+            self._bound = t
+        return self._bound
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream so torch ops and collectives order with the kernels."""
+        import torch
+        check(lib.pgsgd_session_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "set_stream")
+
+    def iteration(self, eta, cooling, n_terms):
+        check(lib.pgsgd_session_iteration(self._h, float(eta), 1 if cooling else 0, int(n_terms)), "iteration")
+
+    def sync(self):
+        d = C.c_double()
+        check(lib.pgsgd_session_sync(self._h, C.byref(d)), "sync")
+        return d.value
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib.pgsgd_session_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "kernel_time")
+        return ms.value, n.value
+
+    def trace_terms(self, cooling, terms_per_stream):
+        """Sampler-only parity hook: uint64 [terms_per_stream, n_streams, 4] = (ka, kb, off_a, off_b)."""
+        out = np.zeros((terms_per_stream, self.n_streams, 4), dtype=np.uint64)
+        check(lib.pgsgd_session_trace_terms(self._h, 1 if cooling else 0, terms_per_stream,
+                                            out.ctypes.data_as(C.POINTER(C.c_uint64))), "trace_terms")
+        return out
+
+
+class Layout:
+    """algorithms::layout::Layout (layout.hpp:24-40): X,Y per node end, `.lay` and TSV forms."""
+
+    def __init__(self, X=None, Y=None):
+        self.X = np.zeros(0) if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        self.Y = np.zeros(0) if Y is None else np.ascontiguousarray(Y, dtype=np.float64)
+
+    def size(self):
+        return len(self.X)
+
+    def serialize(self, path):
+        check(lib.pgsgd_write_lay(str(path).encode(), len(self.X), _f64(self.X), _f64(self.Y)), "write_lay")
+
+    def to_bytes(self):
+        buf, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        check(lib.pgsgd_lay_buffer(len(self.X), _f64(self.X), _f64(self.Y), C.byref(buf), C.byref(n)), "lay_buffer")
+        try:
+            return C.string_at(buf, n.value)
+        finally:
+            lib.pgsgd_free(buf)
+
+    @classmethod
+    def load(cls, path):
+        n, px, py = C.c_uint64(), _F64P(), _F64P()
+        check(lib.pgsgd_read_lay(str(path).encode(), C.byref(n), C.byref(px), C.byref(py)), "read_lay")
+        try:
+            X = np.ctypeslib.as_array(px, shape=(n.value,)).copy() if n.value else np.zeros(0)
+            Y = np.ctypeslib.as_array(py, shape=(n.value,)).copy() if n.value else np.zeros(0)
+        finally:
+            lib.pgsgd_free(px)
+            lib.pgsgd_free(py)
+        return cls(X, Y)
+
+    def get_X(self):
+        return self.X
+
+    def get_Y(self):
+        return self.Y
+
+
+def weak_components(graph: Graph):
+    comp = np.zeros(graph.n_nodes, dtype=np.uint32)
+    e = np.ascontiguousarray(graph.edges, dtype=np.uint64)
+    n = lib.pgsgd_weak_components(graph.n_nodes, e.ctypes.data_as(C.POINTER(C.c_uint64)), len(e),
+                                  comp.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if n < 0:
+        check(int(n), "weak_components")
+    return comp, int(n)
+
+
+def pack_components(graph: Graph, X, Y):
+    """layout_main.cpp:401-435, in place on float64 X,Y; returns (comp_of_node, n_components)."""
+    comp, n = weak_components(graph)
+    check(lib.pgsgd_pack_components(graph.n_nodes, comp.ctypes.data_as(C.POINTER(C.c_uint32)), n, _f64(X), _f64(Y)), "pack")
+    return comp, n
+
+
+def write_tsv(path, graph: Graph, comp, n_comp, X, Y):
+    check(lib.pgsgd_write_tsv(str(path).encode(), graph.n_nodes, comp.ctypes.data_as(C.POINTER(C.c_uint32)), n_comp,
+                              _f64(X), _f64(Y)), "write_tsv")
+
+
+def path_stress(graph: Graph, X, Y, n_pairs=1_000_000, seed=0x5eed):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    s = C.c_double()
+    check(lib.pgsgd_path_stress(C.byref(graph.view), _f64(X), _f64(Y), n_pairs, seed, C.byref(s)), "path_stress")
+    return s.value
+
+
+def path_distance(graph: Graph, X, Y):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    check(lib.pgsgd_path_distance(C.byref(graph.view), _f64(X), _f64(Y), C.byref(a), C.byref(b)), "path_distance")
+    return a.value, b.value
+
+
+def main_layout(argv=None):
+    """`odgi layout` with the reference's flags (layout_main.cpp:18-466). argv without the program name."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    full = [b"odgi", b"layout"] + [a.encode() for a in argv]
+    arr = (C.c_char_p * len(full))(*full)
+    return int(lib.pgsgd_main_layout(len(full), arr))

@@ -1,0 +1,206 @@
+"""ctypes wrapper of the CPU oracle (oracle/pgsgd_oracle.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by odgi_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+
+def build(force=False):
+    need = [os.path.join(_BUILD, f) for f in ("liboracle.so", "liboracle_fast.so", "check_libstdcxx")]
+    if force or not all(os.path.exists(f) for f in need):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return need
+
+
+class OrcGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_steps", C.c_uint64), ("n_paths", C.c_uint64),
+                ("node_len", C.POINTER(C.c_uint32)), ("path_first", C.POINTER(C.c_uint64)),
+                ("step_path", C.POINTER(C.c_uint32)), ("step_handle", C.POINTER(C.c_uint32)),
+                ("step_pos", C.POINTER(C.c_uint64))]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("iter_max", C.c_uint64), ("iter_with_max_learning_rate", C.c_uint64),
+                ("min_term_updates", C.c_uint64), ("delta", C.c_double), ("eps", C.c_double),
+                ("eta_max", C.c_double), ("theta", C.c_double), ("space", C.c_uint64),
+                ("space_max", C.c_uint64), ("space_quantization_step", C.c_uint64),
+                ("cooling_start", C.c_double)]
+
+
+class HogStats(C.Structure):
+    _fields_ = [("terms", C.c_uint64), ("iterations", C.c_uint64), ("seconds", C.c_double)]
+
+
+_F64P = C.POINTER(C.c_double)
+_F32P = C.POINTER(C.c_float)
+_U64P = C.POINTER(C.c_uint64)
+
+
+def _load(name):
+    build()
+    lib = C.CDLL(os.path.join(_BUILD, name))
+    lib.orc_rng_seed.argtypes = [C.c_uint64, _U64P]
+    lib.orc_rng_next.argtypes = [_U64P]
+    lib.orc_rng_next.restype = C.c_uint64
+    lib.orc_uniform_u64.argtypes = [_U64P, C.c_uint64]
+    lib.orc_uniform_u64.restype = C.c_uint64
+    lib.orc_canonical.argtypes = [_U64P]
+    lib.orc_canonical.restype = C.c_double
+    lib.orc_fast_precise_pow.argtypes = [C.c_double, C.c_double]
+    lib.orc_fast_precise_pow.restype = C.c_double
+    lib.orc_zipf.argtypes = [_U64P, C.c_uint64, C.c_double, C.c_double]
+    lib.orc_zipf.restype = C.c_uint64
+    lib.orc_schedule.argtypes = [C.POINTER(OrcParams), _F64P]
+    lib.orc_zeta_size.argtypes = [C.c_uint64] * 3
+    lib.orc_zeta_size.restype = C.c_size_t
+    lib.orc_zetas.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _F64P]
+    lib.orc_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32,
+                                    C.c_int, C.c_uint64, _U64P]
+    lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
+                                           C.c_uint32, _F32P, _F32P, _F64P]
+    lib.orc_layout_streams_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
+                                           C.c_uint32, _F64P, _F64P]
+    lib.orc_layout_batched_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
+                                           C.c_uint32, _F64P, _F64P]
+    lib.orc_layout_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, _F64P,
+                                       C.POINTER(HogStats)]
+    lib.orc_path_stress_sampled.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P, C.c_uint64, C.c_uint64]
+    lib.orc_path_stress_sampled.restype = C.c_double
+    lib.orc_path_stress_exhaustive.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P]
+    lib.orc_path_stress_exhaustive.restype = C.c_double
+    lib.orc_path_distance.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P, _F64P, _F64P]
+    return lib
+
+
+_libs = {}
+
+
+def lib(fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _libs:
+        _libs[name] = _load(name)
+    return _libs[name]
+
+
+class Graph:
+    """Holds numpy arrays and the C view over them (same layout as pgsgd_graph_view)."""
+
+    def __init__(self, node_len, path_first, step_path, step_handle, step_pos):
+        self.node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
+        self.path_first = np.ascontiguousarray(path_first, dtype=np.uint64)
+        self.step_path = np.ascontiguousarray(step_path, dtype=np.uint32)
+        self.step_handle = np.ascontiguousarray(step_handle, dtype=np.uint32)
+        self.step_pos = np.ascontiguousarray(step_pos, dtype=np.uint64)
+        v = OrcGraph()
+        v.n_nodes, v.n_steps, v.n_paths = len(self.node_len), len(self.step_handle), len(self.path_first) - 1
+        v.node_len = self.node_len.ctypes.data_as(C.POINTER(C.c_uint32))
+        v.path_first = self.path_first.ctypes.data_as(_U64P)
+        v.step_path = self.step_path.ctypes.data_as(C.POINTER(C.c_uint32))
+        v.step_handle = self.step_handle.ctypes.data_as(C.POINTER(C.c_uint32))
+        v.step_pos = self.step_pos.ctypes.data_as(_U64P)
+        self.view = v
+
+    @classmethod
+    def from_product(cls, g):
+        """Copy the arrays of an odgi_amd.Graph (tests build the graph once, with the product loader)."""
+        return cls(g.node_len.copy(), g.path_first.copy(), g.step_path.copy(), g.step_handle.copy(), g.step_pos.copy())
+
+    n_nodes = property(lambda s: len(s.node_len))
+    n_steps = property(lambda s: len(s.step_handle))
+    n_paths = property(lambda s: len(s.path_first) - 1)
+
+
+def params(**kw):
+    p = OrcParams()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def params_from(lp):
+    """From an odgi_amd.LayoutParams-like object."""
+    return params(iter_max=lp.iter_max, iter_with_max_learning_rate=lp.iter_with_max_learning_rate,
+                  min_term_updates=lp.min_term_updates, delta=lp.delta, eps=lp.eps, eta_max=lp.eta_max,
+                  theta=lp.theta, space=lp.space, space_max=lp.space_max,
+                  space_quantization_step=lp.space_quantization_step, cooling_start=lp.cooling_start)
+
+
+def schedule(p):
+    etas = np.zeros(p.iter_max + 1)
+    lib().orc_schedule(C.byref(p), etas.ctypes.data_as(_F64P))
+    return etas
+
+
+def zetas(theta, space, space_max, quant):
+    n = lib().orc_zeta_size(space, space_max, quant)
+    z = np.zeros(n)
+    lib().orc_zetas(theta, space, space_max, quant, z.ctypes.data_as(_F64P))
+    return z
+
+
+def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream):
+    out = np.zeros((terms_per_stream, n_streams, 4), dtype=np.uint64)
+    lib().orc_trace_terms(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if cooling else 0,
+                          terms_per_stream, out.ctypes.data_as(_U64P))
+    return out
+
+
+def layout_streams_f32(g, p, seed, n_streams, X, Y, stream_offset=0):
+    X = np.ascontiguousarray(X, dtype=np.float32).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
+    d = C.c_double()
+    lib().orc_layout_streams_f32(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset,
+                                 X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P), C.byref(d))
+    return X, Y, d.value
+
+
+def layout_streams_f64(g, p, seed, n_streams, X, Y, stream_offset=0):
+    X = np.ascontiguousarray(X, dtype=np.float64).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float64).copy()
+    lib().orc_layout_streams_f64(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset,
+                                 X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P))
+    return X, Y
+
+
+def layout_batched_f64(g, p, seed, n_streams, X, Y, stream_offset=0):
+    """Model of the device's concurrency: n_streams terms read one snapshot, their deltas are summed."""
+    X = np.ascontiguousarray(X, dtype=np.float64).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float64).copy()
+    lib().orc_layout_batched_f64(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset,
+                                 X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P))
+    return X, Y
+
+
+def layout_hogwild(g, p, nthreads, X, Y, max_seconds=0.0, fast=False):
+    X = np.ascontiguousarray(X, dtype=np.float64).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float64).copy()
+    st = HogStats()
+    lib(fast).orc_layout_hogwild(C.byref(g.view), C.byref(p), nthreads, max_seconds,
+                                 X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), C.byref(st))
+    return X, Y, {"terms": st.terms, "iterations": st.iterations, "seconds": st.seconds}
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def path_stress_sampled(g, X, Y, n_pairs=1_000_000, seed=0x5eed):
+    X, Y = _d(X), _d(Y)
+    return lib().orc_path_stress_sampled(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), n_pairs, seed)
+
+
+def path_stress_exhaustive(g, X, Y):
+    X, Y = _d(X), _d(Y)
+    return lib().orc_path_stress_exhaustive(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P))
+
+
+def path_distance(g, X, Y):
+    X, Y = _d(X), _d(Y)
+    a, b = C.c_double(), C.c_double()
+    lib().orc_path_distance(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), C.byref(a), C.byref(b))
+    return a.value, b.value

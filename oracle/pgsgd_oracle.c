@@ -1,0 +1,604 @@
+/*
+ * pgsgd_oracle.c — CPU restatement of the reference path-guided SGD 2D layout.
+ * TEST INFRASTRUCTURE ONLY (see pgsgd_oracle.h).  Plain C11 + pthreads.
+ *
+ * Each function cites the reference lines it follows (paths relative to the odgi tree).
+ * The reference samples a flat step index in NODE-major order (XP nr_iv/npi_iv); the lowered view is
+ * PATH-major.  The draw is uniform over all S steps in both, so (path, rank) has the same
+ * distribution; rank = k - path_first[path] replaces nr_iv[k]-1.
+ */
+#define _GNU_SOURCE
+#include "pgsgd_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------- */
+/* Xoshiro-cpp (Reputeless/Xoshiro-cpp): Xoshiro256Plus(seed) seeds its four words from SplitMix64 */
+/* call site: src/algorithms/path_sgd_layout.cpp:168-169                                          */
+void orc_rng_seed(uint64_t seed, uint64_t s[4]) {
+    uint64_t x = seed;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        s[i] = z ^ (z >> 31);
+    }
+}
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+uint64_t orc_rng_next(uint64_t s[4]) {
+    const uint64_t result = s[0] + s[3];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+/* libstdc++ (GCC >= 11) std::uniform_int_distribution<uint64_t>(0, range-1) on a generator whose
+ * range is exactly [0, 2^64): Lemire's multiply-shift with rejection (bits/uniform_int_dist.h,
+ * _S_nd<unsigned __int128>).  Call sites: path_sgd_layout.cpp:175-176,182,205-206,235-237,253,262.
+ * range == 0 means the full 2^64 range (the generator output is returned as is). */
+uint64_t orc_uniform_u64(uint64_t s[4], uint64_t range) {
+    if (range == 0) return orc_rng_next(s);
+    unsigned __int128 product = (unsigned __int128)orc_rng_next(s) * (unsigned __int128)range;
+    uint64_t low = (uint64_t)product;
+    if (low < range) {
+        const uint64_t threshold = (0 - range) % range;
+        while (low < threshold) {
+            product = (unsigned __int128)orc_rng_next(s) * (unsigned __int128)range;
+            low = (uint64_t)product;
+        }
+    }
+    return (uint64_t)(product >> 64);
+}
+
+static inline uint64_t orc_flip(uint64_t s[4]) { return orc_uniform_u64(s, 2); }
+
+/* std::generate_canonical<double, 53> on a 64-bit generator: one draw / 2^64, result >= 1 is
+ * replaced by nextafter(1, 0) (bits/random.tcc). */
+double orc_canonical(uint64_t s[4]) {
+    double r = (double)orc_rng_next(s) * 0x1p-64;
+    if (r >= 1.0) r = 0x1.fffffffffffffp-1;
+    return r;
+}
+
+/* dirtyzipf::fast_precise_pow (Ankerl's approximation): exact a^int(b) by squaring times a
+ * bit-twiddled approximation of a^frac(b).  Call sites: path_sgd_layout.cpp:90 and inside the
+ * distribution (:213-215,226-228); same formula as the in-tree src/cuda/layout.cu:89-113. */
+double orc_fast_precise_pow(double a, double b) {
+    int e = (int)b;
+    union { double d; int32_t x[2]; } u;
+    u.d = a;
+    u.x[1] = (int32_t)((b - e) * (u.x[1] - 1072632447) + 1072632447);
+    u.x[0] = 0;
+    double r = 1.0;
+    while (e) {
+        if (e & 1) r *= a;
+        a *= a;
+        e >>= 1;
+    }
+    return r * u.d;
+}
+
+/* dirtyzipf::dirty_zipfian_int_distribution<uint64_t>(1, n, theta, zeta_n)(gen)
+ * (Gray et al. 1994 as in YCSB; cross-checked with src/cuda/layout.cu:89-113).
+ * The final clamp to [1,n] never fires for in-range arithmetic; it only keeps memory safe. */
+uint64_t orc_zipf(uint64_t s[4], uint64_t n, double theta, double zeta_n) {
+    const double alpha = 1.0 / (1.0 - theta);
+    const double zeta2 = orc_fast_precise_pow(1.0, theta) + orc_fast_precise_pow(0.5, theta);
+    const double eta = (1.0 - orc_fast_precise_pow(2.0 / (double)n, 1.0 - theta)) / (1.0 - zeta2 / zeta_n);
+    const double u = orc_canonical(s);
+    const double uz = u * zeta_n;
+    if (uz < 1.0) return 1;
+    if (uz < 1.0 + orc_fast_precise_pow(0.5, theta)) return 2;
+    const double v = 1.0 + (double)n * orc_fast_precise_pow(eta * u - eta + 1.0, alpha);
+    uint64_t r = (v >= 1.0 && v < 1.8446744073709552e19) ? (uint64_t)v : 1; /* NaN/neg -> 1 */
+    if (r < 1) r = 1;
+    if (r > n) r = n;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* path_linear_sgd_layout_schedule, path_sgd_layout.cpp:433-468 (w_min = 1/eta_max, w_max = 1)   */
+void orc_schedule(const orc_params* p, double* etas) {
+    const double w_min = 1.0 / p->eta_max;
+    const double w_max = 1.0;
+    const double eta_max = 1.0 / w_min;
+    const double eta_min = p->eps / w_max;
+    const double lambda = log(eta_max / eta_min) / ((double)p->iter_max - 1);
+    for (int64_t t = 0; t <= (int64_t)p->iter_max; t++) {
+        int64_t a = t - (int64_t)p->iter_with_max_learning_rate;
+        if (a < 0) a = -a;
+        etas[t] = eta_max * exp(-lambda * (double)a);
+    }
+}
+
+/* zeta cache, path_sgd_layout.cpp:86-97.  One extra slot is allocated so the reference's
+ * out-of-bounds write for space == space_max lands inside the table (it is never read). */
+size_t orc_zeta_size(uint64_t space, uint64_t space_max, uint64_t quant) {
+    return (size_t)((space <= space_max ? space : space_max + (space - space_max) / quant + 1) + 1) + 1;
+}
+
+void orc_zetas(double theta, uint64_t space, uint64_t space_max, uint64_t quant, double* zetas) {
+    const size_t n = orc_zeta_size(space, space_max, quant);
+    for (size_t i = 0; i < n; ++i) zetas[i] = 0.0;
+    double zeta_tmp = 0.0;
+    for (uint64_t i = 1; i < space + 1; i++) {
+        zeta_tmp += orc_fast_precise_pow(1.0 / (double)i, theta);
+        if (i <= space_max) zetas[i] = zeta_tmp;
+        if (i >= space_max && (i - space_max) % quant == 0)
+            zetas[space_max + 1 + (i - space_max) / quant] = zeta_tmp;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* sampler: path_sgd_layout.cpp:182-270.  RNG draw order is the reference's. */
+int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
+                    uint64_t s[4], orc_term* t) {
+    const uint64_t step_index = orc_uniform_u64(s, g->n_steps);        /* :182 */
+    const uint64_t path_i = g->step_path[step_index];                  /* :186 npi_iv */
+    const uint64_t pstart = g->path_first[path_i];
+    const uint64_t path_step_count = g->path_first[path_i + 1] - pstart; /* :189 */
+    if (path_step_count == 1) return 0;                                /* :190-192 */
+    const uint64_t s_rank = step_index - pstart;                       /* :200 nr_iv - 1 */
+    uint64_t b_rank;
+    if (cooling || orc_flip(s)) {                                      /* :205 */
+        if ((s_rank > 0 && orc_flip(s)) || s_rank == path_step_count - 1) { /* :206 backward */
+            const uint64_t jump_space = p->space < s_rank ? p->space : s_rank;
+            uint64_t space = jump_space;
+            if (jump_space > p->space_max)
+                space = p->space_max + (jump_space - p->space_max) / p->space_quantization_step + 1;
+            const uint64_t z_i = orc_zipf(s, jump_space, p->theta, zetas[space]);
+            b_rank = s_rank - z_i;
+        } else {                                                       /* :219 forward */
+            const uint64_t rest = path_step_count - s_rank - 1;
+            const uint64_t jump_space = p->space < rest ? p->space : rest;
+            uint64_t space = jump_space;
+            if (jump_space > p->space_max)
+                space = p->space_max + (jump_space - p->space_max) / p->space_quantization_step + 1;
+            const uint64_t z_i = orc_zipf(s, jump_space, p->theta, zetas[space]);
+            b_rank = s_rank + z_i;
+        }
+    } else {
+        b_rank = orc_uniform_u64(s, path_step_count);                  /* :235-237 */
+    }
+    t->ka = step_index;
+    t->kb = pstart + b_rank;
+    const uint32_t h_a = g->step_handle[t->ka], h_b = g->step_handle[t->kb]; /* :242-243 */
+    uint64_t pos_a = g->step_pos[t->ka], pos_b = g->step_pos[t->kb];   /* :248-249 */
+    const uint32_t rev_a = h_a & 1u, rev_b = h_b & 1u;                  /* :252,261 */
+    if (orc_flip(s)) {                                                 /* :253 */
+        pos_a += g->node_len[h_a >> 1];
+        t->off_a = !rev_a;
+    } else {
+        t->off_a = rev_a;
+    }
+    if (orc_flip(s)) {                                                 /* :262 */
+        pos_b += g->node_len[h_b >> 1];
+        t->off_b = !rev_b;
+    } else {
+        t->off_b = rev_b;
+    }
+    t->pos_a = pos_a;
+    t->pos_b = pos_b;
+    return 1;
+}
+
+/* the device streams redraw on a single-step path so that every stream term is a real term */
+static inline void sample_valid(const orc_graph* g, const orc_params* p, const double* zetas,
+                                int cooling, uint64_t s[4], orc_term* t) {
+    while (!orc_sample_term(g, p, zetas, cooling, s, t)) { }
+}
+
+/* update in fp64, exactly path_sgd_layout.cpp:283-363 (single-threaded view of the same loads/stores) */
+static inline double update_f64(const orc_graph* g, const orc_term* t, double eta, double* X, double* Y) {
+    double term_dist = fabs((double)t->pos_a - (double)t->pos_b);       /* :280-281 */
+    if (term_dist == 0) term_dist = 1e-9;                              /* :283-285 */
+    const double w_ij = 1.0 / term_dist;                               /* :295-297 */
+    double mu = eta * w_ij;                                            /* :301 */
+    if (mu > 1) mu = 1;
+    const double d_ij = term_dist;
+    const uint64_t i = 2 * (uint64_t)(g->step_handle[t->ka] >> 1) + t->off_a; /* :308-324 */
+    const uint64_t j = 2 * (uint64_t)(g->step_handle[t->kb] >> 1) + t->off_b;
+    double dx = X[i] - X[j];                                           /* :325 */
+    const double dy = Y[i] - Y[j];
+    if (dx == 0) dx = 1e-9;                                            /* :327-329 */
+    const double mag = sqrt(dx * dx + dy * dy);                        /* :335 */
+    const double Delta = mu * (mag - d_ij) / 2;                        /* :340 */
+    const double r = Delta / mag;                                      /* :350 */
+    const double r_x = r * dx, r_y = r * dy;
+    X[i] = X[i] - r_x;                                                 /* :360-363 */
+    Y[i] = Y[i] - r_y;
+    X[j] = X[j] + r_x;
+    Y[j] = Y[j] + r_y;
+    return fabs(Delta);
+}
+
+/* fp32 mirror of the HIP kernel's arithmetic (odgi_amd/csrc/pgsgd_kernels.hip, term_update).
+ * Compiled with -ffp-contract=off on both sides, so a 1-stream GPU run matches bit for bit. */
+static inline float update_f32(const orc_graph* g, const orc_term* t, float eta, float* X, float* Y) {
+    const int64_t diff = (int64_t)t->pos_a - (int64_t)t->pos_b;
+    const uint64_t ad = (uint64_t)(diff < 0 ? -diff : diff);
+    float d = (float)ad;
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > 1.0f) mu = 1.0f;
+    const uint64_t i = 2 * (uint64_t)(g->step_handle[t->ka] >> 1) + t->off_a;
+    const uint64_t j = 2 * (uint64_t)(g->step_handle[t->kb] >> 1) + t->off_b;
+    float dx = X[i] - X[j];
+    const float dy = Y[i] - Y[j];
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    const float r = Delta / mag;
+    const float r_x = r * dx, r_y = r * dy;
+    /* the device issues four atomic adds: a.x, a.y, b.x, b.y (same order) */
+    X[i] = X[i] + (-r_x);
+    Y[i] = Y[i] + (-r_y);
+    X[j] = X[j] + r_x;
+    Y[j] = Y[j] + r_y;
+    return fabsf(Delta);
+}
+
+void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams,
+                     uint32_t stream_offset, int cooling, uint64_t terms_per_stream, uint64_t* out) {
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    for (uint32_t gi = 0; gi < n_streams; ++gi) {
+        uint64_t s[4];
+        orc_rng_seed(seed + stream_offset + gi, s);
+        for (uint64_t j = 0; j < terms_per_stream; ++j) {
+            orc_term t;
+            sample_valid(g, p, zetas, cooling, s, &t);
+            uint64_t* o = out + (j * (uint64_t)n_streams + gi) * 4;
+            o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
+        }
+    }
+    free(zetas);
+}
+
+/* iteration control shared by the serialised stream runs: path_sgd_layout.cpp:120-163 with exact
+ * iteration lengths (min_term_updates terms each) instead of the 1 ms polling. */
+typedef struct stream_run {
+    const orc_graph* g; const orc_params* p; double* zetas; double* etas;
+    uint64_t* states; uint32_t n_streams;
+} stream_run;
+
+static void stream_run_init(stream_run* r, const orc_graph* g, const orc_params* p, uint64_t seed,
+                            uint32_t n_streams, uint32_t stream_offset) {
+    r->g = g; r->p = p; r->n_streams = n_streams;
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    r->zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, r->zetas);
+    r->etas = (double*)malloc((p->iter_max + 1) * sizeof(double));
+    orc_schedule(p, r->etas);
+    r->states = (uint64_t*)malloc((size_t)n_streams * 4 * sizeof(uint64_t));
+    for (uint32_t i = 0; i < n_streams; ++i) orc_rng_seed(seed + stream_offset + i, r->states + 4 * (size_t)i);
+}
+
+static void stream_run_free(stream_run* r) { free(r->zetas); free(r->etas); free(r->states); }
+
+static int has_multistep_path(const orc_graph* g) {
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi)
+        if (g->path_first[pi + 1] - g->path_first[pi] > 1) return 1;
+    return 0;
+}
+
+void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
+                            uint32_t n_streams, uint32_t stream_offset, float* X, float* Y,
+                            double* last_delta_max) {
+    if (last_delta_max) *last_delta_max = 0.0;
+    if (!has_multistep_path(g)) return;                                /* :64-74 */
+    stream_run r;
+    stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+    const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max); /* :39 */
+    for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
+        const float eta = (float)r.etas[iter];
+        const int cooling = iter >= first_cooling;
+        float dmax = 0.0f;
+        for (uint64_t t = 0; t < p->min_term_updates; ++t) {
+            uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
+            orc_term term;
+            sample_valid(g, p, r.zetas, cooling, s, &term);
+            const float da = update_f32(g, &term, eta, X, Y);
+            if (da > dmax) dmax = da;
+        }
+        if (last_delta_max) *last_delta_max = dmax;
+        if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;  /* :142 */
+    }
+    stream_run_free(&r);
+}
+
+void orc_layout_streams_f64(const orc_graph* g, const orc_params* p, uint64_t seed,
+                            uint32_t n_streams, uint32_t stream_offset, double* X, double* Y) {
+    if (!has_multistep_path(g)) return;
+    stream_run r;
+    stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+    const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
+        const double eta = r.etas[iter];
+        const int cooling = iter >= first_cooling;
+        double dmax = 0.0;
+        for (uint64_t t = 0; t < p->min_term_updates; ++t) {
+            uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
+            orc_term term;
+            sample_valid(g, p, r.zetas, cooling, s, &term);
+            const double da = update_f64(g, &term, eta, X, Y);
+            if (da > dmax) dmax = da;
+        }
+        if (iter + 1 < p->iter_max && dmax <= p->delta) break;
+    }
+    stream_run_free(&r);
+}
+
+/* Concurrency model of the device (not part of the reference): the n_streams terms of one round all
+ * read the coordinates as they were before the round, and their displacements are summed — what
+ * fp32 atomic adds do when n_streams lanes are in flight together.  Pessimistic: on the GPU lanes
+ * drift apart and atomics land continuously.  Used on the CPU to bound n_streams per graph size. */
+void orc_layout_batched_f64(const orc_graph* g, const orc_params* p, uint64_t seed,
+                            uint32_t n_streams, uint32_t stream_offset, double* X, double* Y) {
+    if (!has_multistep_path(g)) return;
+    stream_run r;
+    stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+    const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    const uint64_t n_ends = 2 * g->n_nodes;
+    double* DX = (double*)calloc(n_ends, sizeof(double));
+    double* DY = (double*)calloc(n_ends, sizeof(double));
+    uint64_t* touched = (uint64_t*)malloc((size_t)n_streams * 2 * sizeof(uint64_t));
+    for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
+        const double eta = r.etas[iter];
+        const int cooling = iter >= first_cooling;
+        for (uint64_t t0 = 0; t0 < p->min_term_updates; t0 += n_streams) {
+            const uint64_t nb = (p->min_term_updates - t0 < n_streams) ? p->min_term_updates - t0 : n_streams;
+            for (uint64_t b = 0; b < nb; ++b) {
+                uint64_t* s = r.states + 4 * (size_t)b;
+                orc_term t;
+                sample_valid(g, p, r.zetas, cooling, s, &t);
+                double term_dist = fabs((double)t.pos_a - (double)t.pos_b);
+                if (term_dist == 0) term_dist = 1e-9;
+                double mu = eta * (1.0 / term_dist);
+                if (mu > 1) mu = 1;
+                const uint64_t i = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
+                const uint64_t j = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+                double dx = X[i] - X[j];
+                const double dy = Y[i] - Y[j];
+                if (dx == 0) dx = 1e-9;
+                const double mag = sqrt(dx * dx + dy * dy);
+                const double rr = (mu * (mag - term_dist) / 2) / mag;
+                DX[i] -= rr * dx; DY[i] -= rr * dy;
+                DX[j] += rr * dx; DY[j] += rr * dy;
+                touched[2 * b] = i; touched[2 * b + 1] = j;
+            }
+            for (uint64_t b = 0; b < 2 * nb; ++b) {
+                const uint64_t e = touched[b];
+                X[e] += DX[e]; Y[e] += DY[e];
+                DX[e] = 0; DY[e] = 0;
+            }
+        }
+    }
+    free(DX); free(DY); free(touched);
+    stream_run_free(&r);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* The reference as it is: Hogwild workers, 1 ms polling controller (path_sgd_layout.cpp:99-425). */
+typedef struct hog_shared {
+    const orc_graph* g; const orc_params* p;
+    const double* zetas; const double* etas;
+    double* X; double* Y;
+    uint64_t first_cooling_iteration;
+    uint64_t term_updates;   /* atomic */
+    double eta;              /* atomic */
+    int cooling;             /* atomic */
+    double Delta_max;        /* atomic */
+    int work_todo;           /* atomic */
+    uint64_t iteration;
+    uint64_t total_terms;    /* atomic: sum of all worker counts */
+    double max_seconds;
+    struct timespec t0;
+} hog_shared;
+
+typedef struct hog_worker { hog_shared* sh; uint64_t tid; } hog_worker;
+
+static inline double ld_f64(const double* p) { double v; __atomic_load(p, &v, __ATOMIC_SEQ_CST); return v; }
+static inline void st_f64(double* p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+
+static double seconds_since(const struct timespec* t0) {
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0->tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0->tv_nsec);
+}
+
+static void* hog_checker(void* arg) {                                   /* :120-163 */
+    hog_shared* sh = (hog_shared*)arg;
+    const struct timespec ms = {0, 1000000};
+    while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&sh->term_updates, __ATOMIC_SEQ_CST) > sh->p->min_term_updates) {
+            sh->iteration++;
+            if (sh->iteration >= sh->p->iter_max) {
+                __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+            } else if (ld_f64(&sh->Delta_max) <= sh->p->delta) {
+                __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+            } else {
+                st_f64(&sh->eta, sh->etas[sh->iteration]);
+                st_f64(&sh->Delta_max, sh->p->delta);
+                if (sh->iteration >= sh->first_cooling_iteration)
+                    __atomic_store_n(&sh->cooling, 1, __ATOMIC_SEQ_CST);
+            }
+            __atomic_store_n(&sh->term_updates, (uint64_t)0, __ATOMIC_SEQ_CST);
+        }
+        if (sh->max_seconds > 0 && seconds_since(&sh->t0) > sh->max_seconds)
+            __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+        nanosleep(&ms, NULL);
+    }
+    return NULL;
+}
+
+static void* hog_work(void* arg) {                                      /* :165-377 */
+    hog_worker* w = (hog_worker*)arg;
+    hog_shared* sh = w->sh;
+    const orc_graph* g = sh->g;
+    uint64_t s[4];
+    orc_rng_seed(9399220ull + w->tid, s);                               /* :168-169 */
+    uint64_t term_updates_local = 0, total_local = 0;
+    double* X = sh->X; double* Y = sh->Y;
+    while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
+        orc_term t;
+        const int cooling = __atomic_load_n(&sh->cooling, __ATOMIC_SEQ_CST);
+        if (!orc_sample_term(g, sh->p, sh->zetas, cooling, s, &t)) continue;
+        double term_dist = fabs((double)t.pos_a - (double)t.pos_b);
+        if (term_dist == 0) term_dist = 1e-9;
+        const double w_ij = 1.0 / term_dist;
+        double mu = ld_f64(&sh->eta) * w_ij;
+        if (mu > 1) mu = 1;
+        const double d_ij = term_dist;
+        const uint64_t i = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
+        const uint64_t j = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+        double dx = ld_f64(&X[i]) - ld_f64(&X[j]);
+        const double dy = ld_f64(&Y[i]) - ld_f64(&Y[j]);
+        if (dx == 0) dx = 1e-9;
+        const double mag = sqrt(dx * dx + dy * dy);
+        const double Delta = mu * (mag - d_ij) / 2;
+        const double Delta_abs = fabs(Delta);
+        while (Delta_abs > ld_f64(&sh->Delta_max)) st_f64(&sh->Delta_max, Delta_abs); /* :345-347 */
+        const double r = Delta / mag;
+        const double r_x = r * dx, r_y = r * dy;
+        st_f64(&X[i], ld_f64(&X[i]) - r_x);                            /* :360-363 load-then-store */
+        st_f64(&Y[i], ld_f64(&Y[i]) - r_y);
+        st_f64(&X[j], ld_f64(&X[j]) + r_x);
+        st_f64(&Y[j], ld_f64(&Y[j]) + r_y);
+        term_updates_local++;
+        if (term_updates_local >= 1000) {                              /* :367-374 */
+            __atomic_fetch_add(&sh->term_updates, term_updates_local, __ATOMIC_SEQ_CST);
+            total_local += term_updates_local;
+            term_updates_local = 0;
+        }
+    }
+    total_local += term_updates_local;
+    __atomic_fetch_add(&sh->total_terms, total_local, __ATOMIC_SEQ_CST);
+    return NULL;
+}
+
+void orc_layout_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds,
+                        double* X, double* Y, orc_hogwild_stats* st) {
+    if (st) { st->terms = 0; st->iterations = 0; st->seconds = 0; }
+    if (!has_multistep_path(g) || nthreads == 0) return;
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    double* etas = (double*)malloc((p->iter_max + 1) * sizeof(double));
+    orc_schedule(p, etas);
+    hog_shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.g = g; sh.p = p; sh.zetas = zetas; sh.etas = etas; sh.X = X; sh.Y = Y;
+    sh.first_cooling_iteration = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    sh.eta = etas[0];
+    sh.cooling = 0; sh.Delta_max = 0; sh.work_todo = 1; sh.iteration = 0;
+    sh.max_seconds = max_seconds;
+    clock_gettime(CLOCK_MONOTONIC, &sh.t0);
+    pthread_t checker;
+    pthread_t* th = (pthread_t*)malloc(nthreads * sizeof(pthread_t));
+    hog_worker* ws = (hog_worker*)malloc(nthreads * sizeof(hog_worker));
+    pthread_create(&checker, NULL, hog_checker, &sh);
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        ws[t].sh = &sh; ws[t].tid = t;
+        pthread_create(&th[t], NULL, hog_work, &ws[t]);
+    }
+    for (uint32_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    const double secs = seconds_since(&sh.t0);
+    pthread_join(checker, NULL);
+    if (st) { st->terms = sh.total_terms; st->iterations = sh.iteration; st->seconds = secs; }
+    free(th); free(ws); free(zetas); free(etas);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* quality metrics */
+double orc_path_stress_sampled(const orc_graph* g, const double* X, const double* Y,
+                               uint64_t n_pairs, uint64_t seed) {
+    if (!has_multistep_path(g)) return 0.0;
+    /* evaluation sampler: the SGD sampler itself in its non-cooling mode (half Zipf, half uniform),
+     * with default-like Zipf parameters derived from the graph, on an independent stream */
+    uint64_t max_steps = 0;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) {
+        const uint64_t c = g->path_first[pi + 1] - g->path_first[pi];
+        if (c > max_steps) max_steps = c;
+    }
+    orc_params p;
+    memset(&p, 0, sizeof p);
+    p.theta = 0.99; p.space = max_steps; p.space_max = 1000; p.space_quantization_step = 100;
+    const size_t nz = orc_zeta_size(p.space, p.space_max, p.space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p.theta, p.space, p.space_max, p.space_quantization_step, zetas);
+    uint64_t s[4];
+    orc_rng_seed(seed, s);
+    double acc = 0.0;
+    uint64_t cnt = 0;
+    for (uint64_t n = 0; n < n_pairs; ++n) {
+        orc_term t;
+        if (!orc_sample_term(g, &p, zetas, 0, s, &t)) continue;
+        const double d = fabs((double)t.pos_a - (double)t.pos_b);
+        if (d == 0) continue;
+        const uint64_t i = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
+        const uint64_t j = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+        const double dx = X[i] - X[j], dy = Y[i] - Y[j];
+        const double e = (sqrt(dx * dx + dy * dy) - d) / d;
+        acc += e * e;
+        cnt++;
+    }
+    free(zetas);
+    return cnt ? acc / (double)cnt : 0.0;
+}
+
+double orc_path_stress_exhaustive(const orc_graph* g, const double* X, const double* Y) {
+    double acc = 0.0;
+    uint64_t cnt = 0;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) {
+        const uint64_t b = g->path_first[pi], e = g->path_first[pi + 1];
+        for (uint64_t a = b; a < e; ++a) {
+            const uint64_t ia = g->step_handle[a]; /* 2*rank + is_rev = step-start end */
+            for (uint64_t c = a + 1; c < e; ++c) {
+                const double d = (double)g->step_pos[c] - (double)g->step_pos[a];
+                if (d == 0) continue;
+                const uint64_t ic = g->step_handle[c];
+                const double dx = X[ia] - X[ic], dy = Y[ia] - Y[ic];
+                const double r = (sqrt(dx * dx + dy * dy) - d) / d;
+                acc += r * r;
+                cnt++;
+            }
+        }
+    }
+    return cnt ? acc / (double)cnt : 0.0;
+}
+
+void orc_path_distance(const orc_graph* g, const double* X, const double* Y, double* per_node, double* per_bp) {
+    double sum2d = 0.0;
+    uint64_t nodes = 0, bp = 0;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) {
+        const uint64_t b = g->path_first[pi], e = g->path_first[pi + 1];
+        for (uint64_t k = b; k < e; ++k) {
+            const uint32_t h = g->step_handle[k];
+            if (k + 1 < e) {
+                const uint32_t i = g->step_handle[k + 1];
+                const double dx = X[h] - X[i], dy = Y[h] - Y[i]; /* 2*rank+bit == handle */
+                sum2d += sqrt(dx * dx + dy * dy);
+            }
+            nodes++;
+            bp += g->node_len[h >> 1];
+        }
+    }
+    if (per_node) *per_node = nodes ? sum2d / (double)nodes : 0.0;
+    if (per_bp) *per_bp = bp ? sum2d / (double)bp : 0.0;
+}

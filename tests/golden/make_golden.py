@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/golden_vectors.npz from the CPU oracle (oracle/pgsgd_oracle.c).
+
+The upstream reference cannot run here (its deps/ are empty) and has no golden vectors for the
+layout path, so these vectors are the oracle's own output, committed so that (a) any later change
+to the oracle is caught and (b) the GPU sampler can be checked on a box without re-deriving them.
+Contents: learning-rate schedules and zeta tables for the three fixture graphs'
+default parameters, and the first 1000 sampled terms (ka, kb, off_a, off_b) of stream seed 9399220
+on DRB1-3123 in non-cooling and cooling mode.
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import parse_gfa_py  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+GOLDEN = os.path.dirname(os.path.abspath(__file__))
+out = {}
+for name in ("DRB1-3123", "LPA", "chr6.C4"):
+    d = parse_gfa_py(os.path.join(GOLDEN, name + ".gfa"))
+    counts = np.diff(d["path_first"].astype(np.int64))
+    max_steps = int(counts.max())
+    p = orc.params(iter_max=30, iter_with_max_learning_rate=0, min_term_updates=10 * len(d["step_handle"]),
+                   delta=0.0, eps=0.01, eta_max=float(max_steps) ** 2, theta=0.99, space=max_steps,
+                   space_max=1000, space_quantization_step=100, cooling_start=0.5)
+    out[f"etas/{name}"] = orc.schedule(p)
+    out[f"zetas/{name}"] = orc.zetas(0.99, max_steps, 1000, 100)
+    if name == "DRB1-3123":
+        g = orc.Graph(d["node_len"], d["path_first"], d["step_path"], d["step_handle"], d["step_pos"])
+        out["terms/DRB1-3123/warm"] = orc.trace_terms(g, p, 9399220, 1, 0, False, 1000)[:, 0, :]
+        out["terms/DRB1-3123/cooling"] = orc.trace_terms(g, p, 9399220, 1, 0, True, 1000)[:, 0, :]
+out["zetas/theta0.5_space2932"] = orc.zetas(0.5, 2932, 1000, 100)
+np.savez_compressed(os.path.join(GOLDEN, "golden_vectors.npz"), **out)
+print("wrote", len(out), "arrays")

@@ -1,0 +1,219 @@
+"""Host logic of the product on the CPU: GFA lowering, defaults, schedule/zeta tables vs the
+oracle, initial layouts, .lay/TSV, component packing, CLI argument handling, C-ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, ROOT, parse_gfa_py
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_gfa_lowering_matches_independent_parser(oa, graphs, name):
+    g = graphs(name)
+    N, S, P, max_steps = FIXTURES[name]
+    assert (g.n_nodes, g.n_steps, g.n_paths, g.max_path_steps()) == (N, S, P, max_steps)
+    d = parse_gfa_py(os.path.join(GOLDEN, name + ".gfa"))
+    for k in ("node_len", "path_first", "step_path", "step_handle", "step_pos"):
+        assert np.array_equal(getattr(g, k), d[k]), k
+    assert np.array_equal(g.edges, d["edges"])
+    assert g.path_names == d["names"]
+
+
+def test_fixture_facts_from_survey(graphs):
+    g = graphs("DRB1-3123")
+    assert int((g.step_handle & 1).sum()) == 3096 and int(g.node_len.sum()) == 21997
+    g = graphs("chr6.C4")
+    assert int((g.step_handle & 1).sum()) == 104031
+
+
+def test_gfa_errors_are_codes_not_exits(oa, tmp_path):
+    from odgi_amd._lib import PgsgdError
+    with pytest.raises(PgsgdError) as e:
+        oa.Graph.from_gfa(tmp_path / "missing.gfa")
+    assert e.value.code == -5
+    bad = tmp_path / "gap.gfa"
+    bad.write_text("S\t1\tA\nS\t3\tC\nP\tx\t1+,3+\t*\n")
+    with pytest.raises(PgsgdError) as e:
+        oa.Graph.from_gfa(bad)
+    assert e.value.code == -7  # not optimized: ids are not 1..N (layout_main.cpp:148-151)
+    bad.write_text("S\ts1\tA\n")
+    with pytest.raises(PgsgdError) as e:
+        oa.Graph.from_gfa(bad)
+    assert e.value.code == -6
+    bad.write_text("S\t1\tA\nS\t2\tC\nP\tx\t1+,7+\t*\n")
+    with pytest.raises(PgsgdError) as e:
+        oa.Graph.from_gfa(bad)
+    assert e.value.code == -6 and "missing node" in str(e.value)
+    bad.write_text("S\t1\tA\nS\t1\tC\n")
+    with pytest.raises(PgsgdError):
+        oa.Graph.from_gfa(bad)
+    # ragged but legal: empty path, single-step path, CRLF, unknown line types, W lines ignored
+    ok = tmp_path / "ok.gfa"
+    ok.write_text("H\tVN:Z:1.0\r\nS\t1\tACGT\r\nS\t2\tG\r\nW\tx\t0\tc\t0\t5\t>1>2\r\nP\tempty\t*\t*\r\nP\tone\t2-\t*\r\nP\ttwo\t1+,2-\t*\r\n")
+    g = oa.Graph.from_gfa(ok)
+    assert (g.n_nodes, g.n_paths, g.n_steps) == (2, 3, 3)
+    assert list(g.path_first) == [0, 0, 1, 3] and list(g.step_handle) == [3, 0, 3] and list(g.step_pos) == [0, 0, 4]
+
+
+def test_defaults_match_reference_rules(oa, graphs):
+    # C1 DRB1-3123 -> min_term_updates 350 590, eta_max 9.61e6, space 3100
+    p = oa.LayoutParams.defaults(graphs("DRB1-3123"))
+    assert (p.iter_max, p.min_term_updates, p.eta_max, p.space, p.space_max, p.space_quantization_step) == \
+        (30, 350590, 3100.0 ** 2, 3100, 1000, 100)
+    assert (p.theta, p.eps, p.delta, p.cooling_start, p.seed) == (0.99, 0.01, 0.0, 0.5, 9399220)
+    assert p.first_cooling_iteration() == 15
+    p = oa.LayoutParams.defaults(graphs("LPA"))
+    assert p.min_term_updates == 2028060 and p.eta_max == 21901.0 ** 2
+    p = oa.LayoutParams.defaults(graphs("chr6.C4"))
+    assert p.min_term_updates == 1712080 and p.space == 2932
+
+
+def test_schedule_and_zetas_bitwise_equal_to_oracle(oa, orc, graphs):
+    for name in ("DRB1-3123", "LPA", "chr6.C4"):
+        p = oa.LayoutParams.defaults(graphs(name))
+        assert np.array_equal(oa.path_linear_sgd_layout_schedule(p), orc.schedule(orc.params_from(p)))
+        assert np.array_equal(oa.zeta_table(p.theta, p.space, p.space_max, p.space_quantization_step),
+                              orc.zetas(p.theta, p.space, p.space_max, p.space_quantization_step))
+    for theta, space, smax, q in [(0.5, 2932, 1000, 100), (0.999, 1000, 1000, 100), (0.9, 7, 1000, 2), (0.99, 50000, 10, 7)]:
+        assert np.array_equal(oa.zeta_table(theta, space, smax, q), orc.zetas(theta, space, smax, q))
+
+
+def test_product_sampler_equals_oracle_sampler_on_host(oa, orc, graphs, ographs):
+    """pgsgd_path_stress draws its pairs with the product's own host build of the device sampler
+    (pgsgd_math.hpp); the oracle's evaluator draws them with the C restatement.  Bit-equal results
+    mean the two samplers produced the same 200k terms."""
+    for name in ("DRB1-3123", "chr6.C4"):
+        g, og = graphs(name), ographs(name)
+        X, Y = oa.initial_layout(g, "h")
+        a = oa.path_stress(g, X, Y, 200000, seed=123)
+        b = orc.path_stress_sampled(og, X, Y, 200000, seed=123)
+        assert a == b and a > 0
+        assert oa.path_distance(g, X, Y) == orc.path_distance(og, X, Y)
+
+
+def test_initial_layouts(oa, graphs):
+    g = graphs("DRB1-3123")
+    N = g.n_nodes
+    X, Y = oa.initial_layout(g, "d", seed=3)
+    cs = np.r_[0, np.cumsum(g.node_len.astype(np.int64))]
+    assert np.array_equal(X[0::2], cs[:-1]) and np.array_equal(X[1::2], cs[1:])   # layout_main.cpp:321-326
+    assert abs(Y.std() - np.sqrt(2 * N)) < 0.1 * np.sqrt(2 * N)
+    X2, Y2 = oa.initial_layout(g, "d", seed=3)
+    assert np.array_equal(Y, Y2)                                                   # seeded -> reproducible
+    _, Y3 = oa.initial_layout(g, "d", seed=0)
+    assert not np.array_equal(Y, Y3)                                               # seed 0 = random_device
+    X, Y = oa.initial_layout(g, "u", seed=3)
+    assert Y.min() >= 0 and Y.max() <= np.sqrt(2 * N)
+    X, Y = oa.initial_layout(g, "r", seed=3)
+    assert X.max() <= g.node_len.sum() and X.min() >= 0
+    X, Y = oa.initial_layout(g, "g", seed=3)
+    assert abs(X.mean()) < 5 and abs(X.std() - np.sqrt(2 * N)) < 0.1 * np.sqrt(2 * N)
+    # Hilbert: deterministic; d2xy(n, d) for the first indices (hilbert.hpp:30-41)
+    X, Y = oa.initial_layout(g, "h")
+    assert [(X[i], Y[i]) for i in range(4)] == [(0, 0), (1, 0), (1, 1), (0, 1)]
+    assert len({(x, y) for x, y in zip(X, Y)}) == 2 * N                            # a curve: no repeats
+
+
+def test_lay_roundtrip_and_reference_bytes(oa, tmp_path):
+    raw = open(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"), "rb").read()
+    lay = oa.Layout.load(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"))
+    assert lay.to_bytes() == raw              # our writer reproduces sdsl::enc_vector's bytes exactly
+    rs = np.random.RandomState(0)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 1000):
+        X = rs.normal(0, 1e4, n)
+        Y = rs.normal(0, 1e4, n)
+        X[n // 2] = Y[n // 2]                 # equal neighbours: a zero delta (coded as 2^64)
+        if n > 3:
+            X[1] = X[0]
+            Y[0] = X[0]
+        f = tmp_path / f"r{n}.lay"
+        oa.Layout(X, Y).serialize(f)
+        back = oa.Layout.load(f)
+        m = min(X.min(), Y.min())
+        # values are stored relative to the minimum and restored by adding it back (layout.cpp:86-96)
+        assert np.array_equal(back.X, (X - m) + m) and np.array_equal(back.Y, (Y - m) + m)
+    from odgi_amd._lib import PgsgdError
+    (tmp_path / "short.lay").write_bytes(raw[:1000])
+    with pytest.raises(PgsgdError):
+        oa.Layout.load(tmp_path / "short.lay")
+
+
+def test_components_pack_and_tsv(oa, tmp_path):
+    from odgi_amd import layout as L
+    # two components: {1,2,4} and {3,5}; discovery order = lowest rank first
+    gfa = tmp_path / "c.gfa"
+    gfa.write_text("S\t1\tAA\nS\t2\tC\nS\t3\tGGG\nS\t4\tT\nS\t5\tA\nL\t1\t+\t2\t-\t0M\nL\t4\t+\t2\t+\t0M\nL\t5\t-\t3\t+\t0M\n"
+                   "P\ta\t1+,2-,4+\t*\nP\tb\t3+,5-\t*\n")
+    g = oa.Graph.from_gfa(gfa)
+    comp, n = L.weak_components(g)
+    assert n == 2 and list(comp) == [0, 0, 1, 0, 1]
+    X = np.array([5, 6, 7, 8, -3, -2, 9, 10, -1, 0], dtype=np.float64)
+    Y = np.array([1, 2, 3, 4, -9, -8, 5, 6, -7, -6], dtype=np.float64)
+    Xp, Yp = X.copy(), Y.copy()
+    comp, n = L.pack_components(g, Xp, Yp)
+    # layout_main.cpp:407-435: x -= min_x - 1000 ; y += curr_y_offset - min_y ; offset += height + 1000
+    c0 = [0, 1, 2, 3, 6, 7]
+    c1 = [4, 5, 8, 9]
+    assert np.allclose(Xp[c0], X[c0] - (5 - 1000)) and np.allclose(Yp[c0], Y[c0] + (1000 - 1))
+    h0 = 6 - 1
+    # component 1 lies entirely at negative y: max_y keeps its start value DBL_MIN (draw.hpp:37-39)
+    assert np.allclose(Xp[c1], X[c1] - (-3 - 1000)) and np.allclose(Yp[c1], Y[c1] + (1000 + h0 + 1000 - (-9)))
+    tsv = tmp_path / "o.tsv"
+    L.write_tsv(tsv, g, comp, n, Xp, Yp)
+    rows = tsv.read_text().splitlines()
+    assert rows[0] == "idx\tX\tY\tcomponent"
+    assert [r.split("\t")[0] for r in rows[1:]] == ["0", "1", "2", "3", "6", "7", "4", "5", "8", "9"]
+    assert [r.split("\t")[3] for r in rows[1:]] == ["0"] * 6 + ["1"] * 4
+    assert float(rows[1].split("\t")[1]) == Xp[0]
+
+
+def test_c_abi_exports_every_declared_symbol(oa):
+    from odgi_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pgsgd.h")).read()
+    declared = set(re.findall(r"\b(pgsgd_[a-z0-9_]+)\s*\(", hdr))
+    bound = {n for n, _, _ in _lib.SIGNATURES}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 48 and C.sizeof(_lib.Params) == 128
+
+
+def test_no_cpu_fallback_without_a_device(oa, graphs):
+    """On a machine without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from odgi_amd._lib import PgsgdError
+    g = graphs("DRB1-3123")
+    p = oa.LayoutParams.defaults(g)
+    X, Y = oa.initial_layout(g, "h")
+    X0 = X.copy()
+    with pytest.raises(PgsgdError) as e:
+        oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    assert e.value.code == -2 and np.array_equal(X, X0)
+    with pytest.raises(PgsgdError):
+        oa.LayoutSession(g, p)
+
+
+def test_cli_argument_handling(oa, tmp_path, capfd):
+    assert oa.main_layout(["-h"]) == 0
+    assert "odgi layout" in capfd.readouterr().out
+    assert oa.main_layout([]) == 1
+    assert oa.main_layout(["-o", str(tmp_path / "x.lay")]) == 1
+    assert "Please specify an input file" in capfd.readouterr().err
+    assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa")]) == 1
+    assert "Please specify an output file" in capfd.readouterr().err
+    assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", "x", "-G", "1", "-U", "1"]) == 1
+    assert oa.main_layout(["--bogus"]) == 1
+    bad = tmp_path / "gap.gfa"
+    bad.write_text("S\t1\tA\nS\t3\tC\n")
+    assert oa.main_layout(["-i", str(bad), "-o", str(tmp_path / "x.lay")]) == 1
+    assert "not optimized" in capfd.readouterr().err
+    assert oa.main_layout(["-i", "graph.og", "-o", "x"]) == 1
+    import torch
+    if not torch.cuda.is_available():  # a valid command line still ends in a loud device error
+        assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "t.lay")]) == 1
+        assert "no usable HIP device" in capfd.readouterr().err

@@ -1,0 +1,193 @@
+"""Pins the CPU oracle before it is trusted as the checker (CPU only).
+
+Pins, strongest first: the real libstdc++ (distributions), the reference's committed layout
+test/DRB1-3123_unsorted.og.lay (quality bar), reference src/unittest/pathindex.cpp known answers,
+closed forms of the schedule, a third pure-Python restatement, and the committed golden vectors.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyref
+from conftest import GOLDEN, ROOT
+
+
+def test_libstdcxx_distributions_match_real_libstdcxx(orc):
+    exe = os.path.join(ROOT, "oracle", "_build", "check_libstdcxx")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_splitmix64_known_answers(orc):
+    import ctypes as C
+    # published SplitMix64 vectors for seed 1234567 (Vigna's reference / Rosetta Code)
+    want = [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431]
+    s = (C.c_uint64 * 4)()
+    orc.lib().orc_rng_seed(1234567, s)
+    assert list(s) == want
+
+
+def test_rng_and_distributions_match_python_restatement(orc):
+    import ctypes as C
+    for seed in (9399220, 9399221, 42):
+        s = (C.c_uint64 * 4)()
+        orc.lib().orc_rng_seed(seed, s)
+        g = pyref.Xoshiro256Plus(seed)
+        assert list(s) == g.s
+        for _ in range(200):
+            assert orc.lib().orc_rng_next(s) == g.next()
+        for rng in (2, 3, 12, 35059, 202806):
+            for _ in range(100):
+                assert orc.lib().orc_uniform_u64(s, rng) == pyref.uniform_below(g, rng)
+        for _ in range(100):
+            assert orc.lib().orc_canonical(s) == pyref.canonical(g)
+
+
+def test_fast_precise_pow_and_zipf_match_python_restatement(orc):
+    import ctypes as C
+    lib = orc.lib()
+    rs = np.random.RandomState(1)
+    for a, b in [(1.0, 0.99), (0.5, 0.99), (2.0 / 3100, 0.01), (0.3, 100.0), (1.0 / 7, 0.99), (0.99, 100.00000000000009)]:
+        assert lib.orc_fast_precise_pow(a, b) == pyref.fast_precise_pow(a, b)
+    for a, b in zip(rs.uniform(1e-6, 1.0, 200), rs.uniform(0.0, 3.0, 200)):
+        assert lib.orc_fast_precise_pow(a, b) == pyref.fast_precise_pow(a, b)
+    # the "dirty" bias: the fractional-part estimate of a^0 is ~0.97, not 1
+    assert 0.9 < lib.orc_fast_precise_pow(0.5, 2.0) / 0.25 < 1.0
+    z = orc.zetas(0.99, 3100, 1000, 100)
+    for n, zi in [(1, 1), (2, 2), (3, 3), (17, 17), (1000, 1000), (1500, 1006), (3100, 1022)]:
+        s = (C.c_uint64 * 4)()
+        lib.orc_rng_seed(77 + n, s)
+        g = pyref.Xoshiro256Plus(77 + n)
+        for _ in range(300):
+            got = lib.orc_zipf(s, n, 0.99, z[zi])
+            assert got == pyref.zipf(g, n, 0.99, float(z[zi]))
+            assert 1 <= got <= n
+
+
+def test_schedule_closed_forms(orc):
+    # path_sgd_layout.cpp:444-459 with iter_with_max_lr = 0: etas[0] = eta_max, etas[iter_max-1] = eps
+    for eta_max, eps, iters in [(9.61e6, 0.01, 30), (4.797e8, 0.01, 30), (100.0, 0.5, 2), (8.6e6, 0.001, 100)]:
+        p = orc.params(iter_max=iters, iter_with_max_learning_rate=0, eps=eps, eta_max=eta_max)
+        e = orc.schedule(p)
+        assert len(e) == iters + 1
+        assert e[0] == pytest.approx(eta_max, rel=1e-12)
+        assert e[iters - 1] == pytest.approx(eps, rel=1e-9)
+        assert np.all(np.diff(e) < 0)
+    p = orc.params(iter_max=10, iter_with_max_learning_rate=3, eps=0.01, eta_max=1000.0)
+    e = orc.schedule(p)
+    assert np.argmax(e) == 3 and e[2] == pytest.approx(e[4])
+
+
+def test_zeta_table_rule(orc):
+    theta, space, smax, q = 0.99, 3100, 1000, 100
+    z = orc.zetas(theta, space, smax, q)
+    assert len(z) == smax + (space - smax) // q + 1 + 1 + 1  # reference size + the guard slot
+    pw = [orc.lib().orc_fast_precise_pow(1.0 / i, theta) for i in range(1, space + 1)]
+    cs = np.cumsum(pw)  # same left-to-right accumulation
+    run = 0.0
+    exact = []
+    for v in pw:
+        run += v
+        exact.append(run)
+    assert z[0] == 0.0
+    assert np.array_equal(z[1:smax + 1], np.array(exact[:smax]))
+    for k in range(0, (space - smax) // q + 1):  # quantised part: zeta at the LOWER edge of each bucket
+        assert z[smax + 1 + k] == exact[smax + k * q - 1]
+    assert np.all(np.diff(z[1:smax + 1]) > 0)
+    del cs
+    # space == space_max: the reference writes one slot past its table; ours has room for it
+    z2 = orc.zetas(theta, 1000, 1000, 100)
+    assert len(z2) == 1000 + 1 + 1 and z2[1001] == z2[1000]
+    # space < space_max
+    z3 = orc.zetas(theta, 12, 1000, 100)
+    assert len(z3) == 14 and np.array_equal(z3[1:13], z[1:13])
+
+
+def test_golden_vectors_regression(orc, ographs):
+    gv = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
+    for name, max_steps in (("DRB1-3123", 3100), ("LPA", 21901), ("chr6.C4", 2932)):
+        p = orc.params(iter_max=30, iter_with_max_learning_rate=0, eps=0.01, eta_max=float(max_steps) ** 2)
+        assert np.array_equal(orc.schedule(p), gv[f"etas/{name}"])
+        assert np.array_equal(orc.zetas(0.99, max_steps, 1000, 100), gv[f"zetas/{name}"])
+    assert np.array_equal(orc.zetas(0.5, 2932, 1000, 100), gv["zetas/theta0.5_space2932"])
+    g = ographs("DRB1-3123")
+    p = orc.params(iter_max=30, min_term_updates=10 * g.n_steps, eps=0.01, eta_max=3100.0 ** 2, theta=0.99,
+                   space=3100, space_max=1000, space_quantization_step=100, cooling_start=0.5)
+    warm = orc.trace_terms(g, p, 9399220, 1, 0, False, 1000)[:, 0, :]
+    cool = orc.trace_terms(g, p, 9399220, 1, 0, True, 1000)[:, 0, :]
+    assert np.array_equal(warm, gv["terms/DRB1-3123/warm"])
+    assert np.array_equal(cool, gv["terms/DRB1-3123/cooling"])
+
+
+def test_sampler_terms_are_valid_and_follow_the_reference_rules(orc, ographs):
+    g = ographs("chr6.C4")  # 104 031 reverse steps, 90 paths
+    p = orc.params(iter_max=30, min_term_updates=1, eps=0.01, eta_max=1.0, theta=0.99, space=2932, space_max=1000,
+                   space_quantization_step=100, cooling_start=0.5)
+    for cooling in (False, True):
+        t = orc.trace_terms(g, p, 5, 64, 0, cooling, 400).reshape(-1, 4)
+        ka, kb = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+        assert ka.max() < g.n_steps and kb.max() < g.n_steps
+        assert np.array_equal(g.step_path[ka], g.step_path[kb])       # partner on the same path
+        assert set(np.unique(t[:, 2])) <= {0, 1} and set(np.unique(t[:, 3])) <= {0, 1}
+        if cooling:
+            assert np.all(ka != kb)                                   # a Zipf jump is >= 1
+            jump = np.abs(ka - kb)
+            assert np.mean(jump <= 10) > 0.25                         # Zipf: mass near the origin
+        # a is uniform over all steps: mean flat index near S/2
+        assert abs(ka.mean() / g.n_steps - 0.5) < 0.02
+
+
+def test_pathindex_known_answers(oa, orc, tmp_path):
+    """reference src/unittest/pathindex.cpp:22-130 — 4 nodes AGGA/A/TC/TCTCAGG, three paths."""
+    gfa = tmp_path / "pi.gfa"
+    gfa.write_text("H\tVN:Z:1.0\nS\t1\tAGGA\nS\t2\tA\nS\t3\tTC\nS\t4\tTCTCAGG\n"
+                   "L\t1\t+\t2\t+\t0M\nL\t2\t+\t3\t+\t0M\nL\t2\t+\t4\t+\t0M\nL\t3\t+\t4\t+\t0M\nL\t1\t+\t4\t+\t0M\n"
+                   "L\t4\t+\t3\t-\t0M\nL\t4\t+\t3\t+\t0M\n"
+                   "P\t5\t1+,3+,4+\t*\nP\t5-\t1+,4+,3+\t*\nP\t5-m\t1+,4+,3-\t*\n")
+    g = oa.Graph.from_gfa(gfa)
+    assert (g.n_nodes, g.n_paths, g.n_steps) == (4, 3, 9)
+    assert list(g.node_len) == [4, 1, 2, 7]
+    assert g.path_names == ["5", "5-", "5-m"]
+    # get_position_of_step: path "5" steps start at 0, 4, 6 (pathindex.cpp:127-130)
+    assert list(g.step_pos[0:3]) == [0, 4, 6]
+    assert list(g.step_pos[3:6]) == [0, 4, 11]
+    assert list(g.step_handle[6:9]) == [0, 6, 5]      # n3_m = 2*2+1
+    assert list(g.step_path) == [0, 0, 0, 1, 1, 1, 2, 2, 2]
+    # node-major grouping of steps (np_bv: 1 at each node's first step, :83-97) is derivable
+    order = np.argsort(g.step_handle >> 1, kind="stable")
+    ranks = (g.step_handle >> 1)[order]
+    np_bv = np.r_[1, (np.diff(ranks) != 0).astype(int)]
+    assert np_bv.sum() == 3 and len(np_bv) == 9       # node 2 is on no path
+    # from_arrays derives the same positions
+    g2 = oa.Graph.from_arrays(g.node_len, g.path_first, g.step_handle)
+    assert np.array_equal(g2.step_pos, g.step_pos) and np.array_equal(g2.step_path, g.step_path)
+
+
+def test_reference_layout_fixture_quality_bar(oa, orc, graphs, ographs):
+    """The one reference-made output: test/DRB1-3123_unsorted.og.lay (BASELINE 1b)."""
+    lay = oa.Layout.load(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"))
+    g = ographs("DRB1-3123_unsorted")
+    assert lay.size() == 2 * 3214
+    assert min(lay.X.min(), lay.Y.min()) == 1000.0
+    assert orc.path_stress_exhaustive(g, lay.X, lay.Y) == pytest.approx(0.08709, abs(1e-4))
+    per_node, per_bp = orc.path_distance(g, lay.X, lay.Y)
+    assert per_node == pytest.approx(9.59988, abs=1e-4) and per_bp == pytest.approx(1.28546, abs=1e-4)
+
+
+def test_oracle_hogwild_reaches_reference_quality(oa, orc, graphs, ographs):
+    """The oracle's restatement of the reference loop lays DRB1-3123_unsorted out as well as the
+    reference did (0.0871): this pins the whole restated chain end to end, statistically."""
+    g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
+    p = oa.LayoutParams.defaults(g)
+    X0, Y0 = oa.initial_layout(g, "d", seed=7)
+    assert orc.path_stress_exhaustive(og, X0, Y0) > 1000
+    X, Y, st = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
+    assert st["iterations"] == 30 and st["terms"] >= 30 * p.min_term_updates
+    assert orc.path_stress_exhaustive(og, X, Y) < 0.0871 * 1.25
+    # the serialised stream schedule (what the GPU runs) gives the same quality
+    X, Y = orc.layout_streams_f64(og, orc.params_from(p), 9399220, 64, X0, Y0)
+    assert orc.path_stress_exhaustive(og, X, Y) < 0.0871 * 1.25
+    Xf, Yf, dmax = orc.layout_streams_f32(og, orc.params_from(p), 9399220, 64, X0, Y0)
+    assert orc.path_stress_exhaustive(og, Xf, Yf) < 0.0871 * 1.25 and dmax > 0
