@@ -101,7 +101,8 @@ def main():
 
     total_terms = float(p.min_term_updates) * args.steps
     value = total_terms / elapsed
-    my_terms = drv.my_terms()
+    # one launch per exchange block: terms per launch = this rank's terms in the timed region / launches
+    my_terms = drv.my_terms() * args.steps / max(launches, 1)
     avg_kernel_s = (kernel_ms / 1e3) / max(launches, 1)
     achieved = BYTES_PER_TERM * my_terms / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
@@ -122,7 +123,7 @@ def main():
                                f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
                                f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
                    "streams_per_gpu": int(p.n_streams),
-                   "parallelism": f"term-sharded x{world}, graph replicated, delta all-reduce per eta step"},
+                   "parallelism": f"term-sharded x{world}, graph replicated, {drv.blocks} delta all-reduce(s) per eta step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "pgsgd::sgd_iteration_kernel", "avg_kernel_ms": 1e3 * avg_kernel_s,

@@ -64,7 +64,6 @@ typedef struct pgsgd_graph_view {
 /* ---- parameters: the argument list of path_linear_sgd_layout_gpu -------------------------- */
 /* (reference: src/algorithms/path_sgd_layout.hpp:59-80; cuda::layout_config_t layout.h:65-77) */
 #define PGSGD_FLAG_COORD_LOAD_PLAIN   0x1u /* debug: read coordinates through L1/L2 (stale-prone)   */
-#define PGSGD_FLAG_NO_WAVE_MERGE      0x2u /* debug: skip the in-wavefront conflict merge            */
 
 typedef struct pgsgd_params {
     uint64_t iter_max;                    /* -x, default 30                                        */
@@ -146,6 +145,14 @@ int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
+/* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.
+ *   mark : remember the current coordinates as the exchange base (call once, after upload);
+ *   begin: buf[0..4N) = coords - base, buf[4N..6N) = squared length of each node end's delta;
+ *          the caller then all-reduces (SUM) the 6N-float device buffer over the G ranks;
+ *   end  : coords = base + S * clamp(Q/|S|^2, 1/G, 1) per node end, base = coords. */
+int pgsgd_session_exchange_mark(pgsgd_session* s);
+int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats);
+int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size);
 /* Parity hook: run the sampler only and write, for stream g and its j-th term (j < terms_per_stream),
  * out[(j*n_streams+g)*4 + {0,1,2,3}] = {flat step a, flat step b, end offset a, end offset b}
  * without touching coordinates or the persistent stream states. */

@@ -44,7 +44,6 @@ class Stats(C.Structure):
 
 
 FLAG_COORD_LOAD_PLAIN = 0x1
-FLAG_NO_WAVE_MERGE = 0x2
 DEFAULT_SEED = 9399220
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)
@@ -69,6 +68,9 @@ SIGNATURES = [
     ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
+    ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),
+    ("pgsgd_session_exchange_begin", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pgsgd_session_exchange_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_synthetic", C.c_int, [u64, u64, u64, P(C.c_void_p)]),

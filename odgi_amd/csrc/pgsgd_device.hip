@@ -245,6 +245,38 @@ __global__ void deinterleave_coords(const float* coords, uint64_t n_ends, float*
     }
 }
 
+// Multi-GPU exchange, step 1: buf[0..4N) = coords - start (what this rank changed since the last
+// exchange), buf[4N + e] = |delta of node end e|^2.  One fused buffer -> one all-reduce.
+__global__ void exchange_prepare_kernel(const float4* coords, const float4* start, uint64_t n_nodes, float* buf) {
+    float4* S = reinterpret_cast<float4*>(buf);
+    float2* Q = reinterpret_cast<float2*>(buf + 4 * n_nodes);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 c = coords[i], s = start[i];
+        const float4 d = make_float4(c.x - s.x, c.y - s.y, c.z - s.z, c.w - s.w);
+        S[i] = d;
+        Q[i] = make_float2(d.x * d.x + d.y * d.y, d.z * d.z + d.w * d.w);
+    }
+}
+
+// step 2, after the all-reduce (SUM) over G ranks: S = sum of the ranks' deltas, Q = sum of their
+// squared lengths.  Each node end moves by S * f with f = clamp(Q / |S|^2, 1/G, 1): ranks that
+// pulled the end the same way (coherent deltas, |S|^2 = G*Q: every rank already made the full
+// correction) are averaged, f = 1/G; uncorrelated small steps (|S|^2 ~ Q) add up, f = 1.
+__global__ void exchange_apply_kernel(float4* coords, float4* start, uint64_t n_nodes, const float* buf, float inv_world) {
+    const float4* S = reinterpret_cast<const float4*>(buf);
+    const float2* Q = reinterpret_cast<const float2*>(buf + 4 * n_nodes);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 d = S[i], s = start[i];
+        const float2 q = Q[i];
+        const float s0 = d.x * d.x + d.y * d.y, s1 = d.z * d.z + d.w * d.w;
+        const float f0 = s0 > 0.0f ? fminf(fmaxf(q.x / s0, inv_world), 1.0f) : 1.0f;
+        const float f1 = s1 > 0.0f ? fminf(fmaxf(q.y / s1, inv_world), 1.0f) : 1.0f;
+        const float4 c = make_float4(s.x + d.x * f0, s.y + d.y * f0, s.z + d.z * f1, s.w + d.w * f1);
+        coords[i] = c;
+        start[i] = c;
+    }
+}
+
 }  // namespace pgsgd
 
 // ---------------------------------------------------------------------------------------------
@@ -278,6 +310,7 @@ struct pgsgd_session {
     uint64_t* d_rng = nullptr;
     unsigned int* d_delta_max = nullptr;
     unsigned int* h_delta_max = nullptr;  // pinned
+    float* d_start = nullptr;             // coordinates at the last exchange (multi-GPU only)
     pgsgd::DevConst dc{};
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
@@ -454,6 +487,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_coords && s->own_coords) (void)hipFree(s->d_coords);
     if (s->d_rng) (void)hipFree(s->d_rng);
     if (s->d_delta_max) (void)hipFree(s->d_delta_max);
+    if (s->d_start) (void)hipFree(s->d_start);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -589,6 +623,42 @@ extern "C" int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uin
     if (total_ms) *total_ms = s->kernel_ms;
     if (launches) *launches = s->launches;
     if (reset) { s->kernel_ms = 0; s->launches = 0; }
+    return PGSGD_OK;
+}
+
+// ---- multi-GPU exchange (see odgi_amd/distributed.py) ------------------------------------------
+extern "C" int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats) {
+    pgsgd::clear_error();
+    if (!s || !device_buf_6N_floats) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const int grid = (int)std::min<uint64_t>((s->n_nodes + 255) / 256, 2048);
+    if (!s->d_start) {  // first exchange: nothing was changed yet relative to "now"
+        HIP_TRY(hipMalloc(&s->d_start, s->n_nodes * 4 * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(s->d_start, s->d_coords, s->n_nodes * 4 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    }
+    hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel, dim3(grid), dim3(256), 0, s->stream, (const float4*)s->d_coords,
+                       (const float4*)s->d_start, s->n_nodes, (float*)device_buf_6N_floats);
+    HIP_TRY(hipGetLastError());
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_exchange_mark(pgsgd_session* s) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->d_start) HIP_TRY(hipMalloc(&s->d_start, s->n_nodes * 4 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(s->d_start, s->d_coords, s->n_nodes * 4 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size) {
+    pgsgd::clear_error();
+    if (!s || !device_buf_6N_floats || world_size < 1 || !s->d_start) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const int grid = (int)std::min<uint64_t>((s->n_nodes + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::exchange_apply_kernel, dim3(grid), dim3(256), 0, s->stream, (float4*)s->d_coords, (float4*)s->d_start,
+                       s->n_nodes, (const float*)device_buf_6N_floats, 1.0f / (float)world_size);
+    HIP_TRY(hipGetLastError());
     return PGSGD_OK;
 }
 

@@ -1,31 +1,43 @@
-"""Multi-GPU path-guided SGD: replicated graph, term-sharded iterations, one all-reduce per eta step.
+"""Multi-GPU path-guided SGD: replicated graph, term-sharded iterations, RCCL all-reduce exchanges.
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  Every rank holds the
 whole lowered graph and a full copy of the coordinates.  In each iteration (learning-rate step)
-rank r applies its 1/G share of the iteration's terms with its own sampler streams
-(stream ids r*L .. r*L+L-1, disjoint across ranks), then the ranks exchange what they changed:
+rank r applies its 1/G share of the iteration's terms with its own sampler streams (stream ids
+r*L .. r*L+L-1, disjoint across ranks), in `exchanges_per_iteration` blocks; after each block the
+ranks exchange what they changed since the previous exchange:
 
-    delta_r = coords_r - coords_start          (fp32, 4N values)
-    all-reduce(sum) over ranks                 (one fused buffer: 16 MB at N = 1e6)
-    coords  = coords_start + sum_r delta_r
+    begin : buf[0..4N) = coords - base ; buf[4N..6N) = |delta of each node end|^2      (HIP kernel)
+    all-reduce(SUM) of the one fused 6N-float buffer over the G ranks                    (RCCL)
+    end   : coords = base + S * clamp(Q/|S|^2, 1/G, 1) per node end ; base = coords      (HIP kernel)
 
-which is what one GPU running all G shares with atomic adds would have produced, up to the
-staleness of not seeing the other ranks' updates inside the iteration.  The early-stop quantity
-max|Delta| is all-reduced with MAX.  The reference has no multi-device path (src/cuda/layout.cu is
-single-GPU, its NCCLCHECK macro is unused), so this exchange is new; SURVEY 8(e).
+The merge is not a plain sum: with the early learning rates every term is a full projection
+(mu = 1), each rank alone already moves a node end all the way, and summing G such deltas
+overshoots G-fold (measured: divergence at G = 2 on DRB1-3123).  The factor f = Q/|S|^2 is 1/G when
+the ranks' deltas agree (-> their mean) and 1 when they are uncorrelated small steps (-> their sum);
+validated by stress at G = 1,2,4,8.  max|Delta| is all-reduced with MAX for the
+reference's stop rule.  The reference has no multi-device path (src/cuda/layout.cu is single-GPU,
+its NCCLCHECK macro is unused), so this exchange is new; SURVEY 8(e).
 """
+import ctypes as C
 import math
 
 import torch
 import torch.distributed as dist
 
+from ._lib import lib, check
 from .layout import LayoutParams, LayoutSession, path_linear_sgd_layout_schedule
 
 
 def shard_terms(n_terms, world_size, rank):
-    """Terms of one iteration owned by `rank`: the first n_terms % G ranks take one extra."""
+    """Terms of one block owned by `rank`: the first n_terms % G ranks take one extra."""
     base, rem = divmod(int(n_terms), int(world_size))
     return base + (1 if rank < rem else 0)
+
+
+def split_blocks(n_terms, blocks):
+    """Terms of one iteration split into `blocks` exchange blocks (sizes differ by at most 1)."""
+    base, rem = divmod(int(n_terms), int(blocks))
+    return [base + (1 if b < rem else 0) for b in range(blocks)]
 
 
 class HipEngine:
@@ -36,12 +48,25 @@ class HipEngine:
         self.session.upload(X, Y)
         self.coords = self.session.coords_tensor()
         self.session.use_torch_stream()
+        self.n_nodes = graph.n_nodes
+
+    def new_exchange_buffer(self):
+        return torch.empty(6 * self.n_nodes, dtype=torch.float32, device=self.coords.device)
 
     def iteration(self, eta, cooling, n_terms):
         self.session.iteration(eta, cooling, n_terms)
 
     def sync(self):
         return self.session.sync()
+
+    def exchange_mark(self):
+        check(lib.pgsgd_session_exchange_mark(self.session._h), "exchange_mark")
+
+    def exchange_begin(self, buf):
+        check(lib.pgsgd_session_exchange_begin(self.session._h, C.c_void_p(buf.data_ptr())), "exchange_begin")
+
+    def exchange_end(self, buf, world):
+        check(lib.pgsgd_session_exchange_end(self.session._h, C.c_void_p(buf.data_ptr()), int(world)), "exchange_end")
 
     def result(self):
         c = self.coords.detach().cpu().numpy()
@@ -54,39 +79,44 @@ class HipEngine:
 
 
 class DistributedLayout:
-    """Drives one engine per rank through the schedule with the delta all-reduce between eta steps."""
+    """Drives one engine per rank through the schedule with the exchange between blocks."""
 
-    def __init__(self, params: LayoutParams, engine, group=None):
+    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None):
         self.params = params
         self.engine = engine
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
+        if exchanges_per_iteration is None:
+            exchanges_per_iteration = 1 if self.world == 1 else 4
+        self.blocks = max(1, int(exchanges_per_iteration)) if self.world > 1 else 1
         self.etas = path_linear_sgd_layout_schedule(params)
         self.first_cooling = int(math.floor(params.cooling_start * float(params.iter_max)))
-        self._start = torch.empty_like(engine.coords)
         self.iterations_done = 0
         self.stopped_early = False
+        self._buf = None
+        if self.world > 1:
+            self._buf = engine.new_exchange_buffer()
+            engine.exchange_mark()
 
     def my_terms(self):
-        return shard_terms(self.params.min_term_updates, self.world, self.rank)
+        """Terms this rank applies per iteration."""
+        return sum(shard_terms(b, self.world, self.rank) for b in split_blocks(self.params.min_term_updates, self.blocks))
 
     def step(self, it):
-        """Iteration `it` (0-based) on every rank, then the exchange.  Returns global max|Delta|."""
+        """Iteration `it` (0-based) on every rank with its exchanges.  Returns global max|Delta|."""
         eng = self.engine
-        coords = eng.coords
+        dmax = 0.0
+        for block_terms in split_blocks(self.params.min_term_updates, self.blocks):
+            eng.iteration(self.etas[it], it >= self.first_cooling, shard_terms(block_terms, self.world, self.rank))
+            if self.world > 1:
+                eng.exchange_begin(self._buf)
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+                eng.exchange_end(self._buf, self.world)
+            dmax = max(dmax, eng.sync())
         if self.world > 1:
-            self._start.copy_(coords)
-        eng.iteration(self.etas[it], it >= self.first_cooling, self.my_terms())
-        if self.world > 1:
-            # delta in place: coords <- coords - start; all-reduce; coords <- start + sum
-            coords.sub_(self._start)
-            dist.all_reduce(coords, op=dist.ReduceOp.SUM, group=self.group)
-            coords.add_(self._start)
-        dmax = eng.sync()
-        if self.world > 1:
-            t = torch.tensor([dmax], dtype=torch.float64, device=coords.device)
+            t = torch.tensor([dmax], dtype=torch.float64, device=self._buf.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             dmax = float(t.item())
         self.iterations_done = it + 1

@@ -1,0 +1,217 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (run with -m gpu on MI355X).
+
+Bit-exact where the work is integer / byte: the sampler streams, .lay bytes.  For the fp32
+coordinate update: bit-exact against the oracle's fp32 mirror for a one-stream run, and — because
+the concurrent run is Hogwild by construction, like the reference — statistical for full runs:
+stress tolerance stated in each test.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(oa, g, **kw):
+    return oa.LayoutParams.defaults(g, device=0, **kw)
+
+
+@pytest.mark.parametrize("name,n_streams,offset", [("DRB1-3123", 64, 0), ("DRB1-3123", 1024, 4096),
+                                                   ("chr6.C4", 256, 0), ("LPA", 4096, 7)])
+@pytest.mark.parametrize("cooling", [False, True])
+def test_sampler_streams_bit_exact(oa, orc, graphs, ographs, name, n_streams, offset, cooling):
+    g, og = graphs(name), ographs(name)
+    p = _params(oa, g, n_streams=n_streams, stream_offset=offset)
+    with oa.LayoutSession(g, p) as s:
+        assert s.n_streams == n_streams
+        got = s.trace_terms(cooling, 16)
+    want = orc.trace_terms(og, orc.params_from(p), p.seed, n_streams, offset, cooling, 16)
+    assert np.array_equal(got, want)
+
+
+def test_sampler_matches_committed_golden_vectors(oa, graphs):
+    gv = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
+    g = graphs("DRB1-3123")
+    p = _params(oa, g, n_streams=64)
+    with oa.LayoutSession(g, p) as s:
+        warm = s.trace_terms(False, 1000)[:, 0, :]
+        cool = s.trace_terms(True, 1000)[:, 0, :]
+    assert np.array_equal(warm, gv["terms/DRB1-3123/warm"])
+    assert np.array_equal(cool, gv["terms/DRB1-3123/cooling"])
+
+
+def test_sampler_other_theta_and_quantisation(oa, orc, graphs, ographs):
+    g, og = graphs("chr6.C4"), ographs("chr6.C4")
+    for theta, space, smax, q in [(0.5, 2932, 1000, 100), (0.999, 500, 100, 7), (0.9, 2932, 2932, 100)]:
+        p = _params(oa, g, n_streams=128, theta=theta, space=space, space_max=smax, space_quantization_step=q)
+        with oa.LayoutSession(g, p) as s:
+            got = s.trace_terms(True, 32)
+        want = orc.trace_terms(og, orc.params_from(p), p.seed, 128, 0, True, 32)
+        assert np.array_equal(got, want)
+
+
+def test_single_step_and_ragged_paths(oa, orc, tmp_path):
+    """Edge cases of the sampler: single-step paths are skipped (path_sgd_layout.cpp:189-192),
+    two-step paths force the jump direction, an empty path owns no steps."""
+    gfa = tmp_path / "ragged.gfa"
+    gfa.write_text("S\t1\tACGT\nS\t2\tG\nS\t3\tTTTTTTTT\nS\t4\tAC\n"
+                   "P\tempty\t*\t*\nP\tone\t2-\t*\nP\ttwo\t1+,2-\t*\nP\tlong\t1+,2+,3-,4+,3+,1-\t*\n")
+    g = oa.Graph.from_gfa(gfa)
+    og = orc.Graph.from_product(g)
+    p = _params(oa, g, n_streams=64)
+    for cooling in (False, True):
+        with oa.LayoutSession(g, p) as s:
+            got = s.trace_terms(cooling, 64)
+        want = orc.trace_terms(og, orc.params_from(p), p.seed, 64, 0, cooling, 64)
+        assert np.array_equal(got, want)
+        assert not np.any(got[..., 0] == 0)  # flat step 0 is the single-step path: never sampled
+
+
+def test_one_stream_run_is_bit_exact_with_fp32_oracle(oa, orc, graphs, ographs):
+    """A single stream is a sequential program: the GPU must reproduce the oracle's fp32 mirror of
+    the update arithmetic exactly (both built without FMA contraction)."""
+    g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000)
+    X0, Y0 = oa.initial_layout(g, "d", seed=5)
+    Xg, Yg = X0.astype(np.float32), Y0.astype(np.float32)
+    st = oa.path_linear_sgd_layout_gpu(g, p, Xg, Yg)
+    Xo, Yo, dmax = orc.layout_streams_f32(og, orc.params_from(p), p.seed, 1, X0, Y0)
+    assert st["iterations"] == 6 and st["term_updates"] == 18000 and st["n_streams"] == 1
+    assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
+    assert st["last_delta_max"] == pytest.approx(dmax, rel=0, abs=0)
+
+
+@pytest.mark.parametrize("name", ["DRB1-3123", "LPA", "chr6.C4"])
+def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name):
+    """BASELINE configs 1-3 with reference defaults.  The reference itself is Hogwild and not
+    reproducible run to run; parity is on layout quality: sampled path stress of the GPU layout
+    within 25 % (+0.02 absolute) of the CPU oracle's Hogwild layout from the same initial layout."""
+    g, og = graphs(name), ographs(name)
+    p = _params(oa, g)
+    X0, Y0 = oa.initial_layout(g, "d", seed=11)
+    X, Y = X0.copy(), Y0.copy()
+    st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    assert st["iterations"] == 30 and st["term_updates"] == 30 * p.min_term_updates
+    assert np.isfinite(X).all() and np.isfinite(Y).all()
+    Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
+    s_gpu = orc.path_stress_sampled(og, X, Y, 1_000_000)
+    s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
+    s_init = orc.path_stress_sampled(og, X0, Y0, 1_000_000)
+    print(f"{name}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
+    assert s_gpu <= 1.25 * s_cpu + 0.02
+    d_gpu, d_cpu = orc.path_distance(og, X, Y)[0], orc.path_distance(og, Xo, Yo)[0]
+    assert d_gpu <= 1.25 * d_cpu + 0.5          # `odgi stats -s` 2D figure, same tolerance
+
+
+def test_reference_layout_quality_bar(oa, orc, graphs, ographs):
+    """The GPU layout of DRB1-3123_unsorted is at least as good as the layout the reference
+    committed for it (exhaustive path stress 0.0871), within 25 %."""
+    g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
+    p = _params(oa, g)
+    X, Y = oa.initial_layout(g, "d", seed=3)
+    oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    s = orc.path_stress_exhaustive(og, X, Y)
+    print("DRB1-3123_unsorted exhaustive stress", s)
+    assert s <= 0.0871 * 1.25
+
+
+def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs):
+    """BASELINE config 3 in small: deterministic -N h initial layout, theta and -K sweep."""
+    g, og = graphs("chr6.C4"), ographs("chr6.C4")
+    X0, Y0 = oa.initial_layout(g, "h")
+    for theta, K in [(0.5, 0.5), (0.9, 0.25), (0.999, 0.75)]:
+        p = _params(oa, g, theta=theta, cooling_start=K)
+        X, Y = X0.copy(), Y0.copy()
+        oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+        Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
+        s_gpu, s_cpu = orc.path_stress_sampled(og, X, Y, 500_000), orc.path_stress_sampled(og, Xo, Yo, 500_000)
+        print(f"theta {theta} K {K}: gpu {s_gpu:.4f} cpu {s_cpu:.4f}")
+        assert s_gpu <= 1.3 * s_cpu + 0.03
+
+
+def test_delta_early_stop_and_counts(oa, graphs):
+    g = graphs("DRB1-3123")
+    X, Y = oa.initial_layout(g, "d", seed=2)
+    p = _params(oa, g, delta=1e12)             # any displacement is below the threshold
+    st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    assert st["iterations"] == 1 and st["early_stop"] == 1 and st["term_updates"] == p.min_term_updates
+    assert st["last_delta_max"] > 0
+
+
+def test_session_torch_binding_and_snapshots(oa, orc, graphs, ographs, tmp_path):
+    import torch
+    g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
+    p = _params(oa, g, n_streams=512)
+    X0, Y0 = oa.initial_layout(g, "d", seed=9)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        s.upload(X0, Y0)
+        t = s.coords_tensor()
+        assert t.shape == (g.n_nodes, 4) and t.is_cuda
+        assert np.array_equal(t[:, 0].cpu().numpy(), X0[0::2].astype(np.float32))
+        s.use_torch_stream()
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            dmax = s.sync()
+            assert dmax > 0
+        ms, n = s.kernel_time()
+        assert n == p.iter_max and ms > 0
+        X, Y = s.download()
+        assert np.array_equal(t[:, 2].cpu().numpy(), X[1::2])
+    s_gpu = orc.path_stress_sampled(og, X, Y, 500_000)
+    assert s_gpu < 2.0
+    # snapshots: <prefix>1 .. <prefix>(iter_max-1), readable .lay files (path_sgd_layout.cpp:379-408)
+    p2 = _params(oa, g, iter_max=4, snapshot_prefix=str(tmp_path / "snap_"))
+    X, Y = X0.copy(), Y0.copy()
+    oa.path_linear_sgd_layout_gpu(g, p2, X, Y)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["snap_1", "snap_2", "snap_3"]
+    lay = oa.Layout.load(tmp_path / "snap_3")
+    assert lay.size() == 2 * g.n_nodes and np.isfinite(lay.X).all()
+
+
+def test_cli_end_to_end(oa, orc, graphs, ographs, tmp_path):
+    og = ographs("DRB1-3123")
+    lay, tsv = tmp_path / "o.lay", tmp_path / "o.tsv"
+    rc = oa.main_layout(["-i", os.path.join(GOLDEN, "DRB1-3123.gfa"), "-o", str(lay), "-T", str(tsv), "-t", "2",
+                         "--gpu", "--seed", "5", "-P", "--stress"])
+    assert rc == 0
+    L = oa.Layout.load(lay)
+    assert L.size() == 2 * 4955
+    rows = tsv.read_text().splitlines()
+    assert rows[0] == "idx\tX\tY\tcomponent" and len(rows) == 1 + 2 * 4955
+    x1 = float(rows[1].split("\t")[1])
+    assert x1 == L.X[0]
+    assert min(L.X.min(), L.Y.min()) == pytest.approx(1000.0)   # component packing border
+    assert orc.path_stress_sampled(og, L.X, L.Y, 500_000) < 2.0
+    # the standalone binary gives the same interface
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "odgi_amd", "lib", "odgi")
+    r = subprocess.run([exe, "layout", "-i", os.path.join(GOLDEN, "t.gfa"), "-T", "-", "-N", "h"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("idx\tX\tY\tcomponent") and len(r.stdout.splitlines()) == 31
+
+
+def test_synthetic_million_node_properties(oa, orc):
+    """BASELINE config 4 at full size: size-independent properties (the oracle is too slow here):
+    exact term accounting, finite coordinates, stress collapsing from the initial layout, and the
+    sampler still bit-exact on a sample of streams."""
+    g = oa.Graph.synthetic(1_000_000, 50, seed=42)
+    assert g.n_nodes == 1_000_000 and 4.4e7 < g.n_steps < 5.2e7
+    p = _params(oa, g, iter_max=10)
+    X0, Y0 = oa.initial_layout(g, "d", seed=42)
+    X, Y = X0.copy(), Y0.copy()
+    st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    assert st["term_updates"] == 10 * p.min_term_updates
+    assert np.isfinite(X).all() and np.isfinite(Y).all()
+    s_init = oa.path_stress(g, X0, Y0, 1_000_000)
+    s_end = oa.path_stress(g, X, Y, 1_000_000)
+    print(f"synthetic 1M: stress {s_init:.3f} -> {s_end:.4f}; {1e3 * st['term_updates'] / st['kernel_ms']:.3g} terms/s")
+    assert s_end < 0.5 * s_init
+    og = orc.Graph.from_product(g)
+    p2 = _params(oa, g, n_streams=256)
+    with oa.LayoutSession(g, p2) as s:
+        got = s.trace_terms(True, 4)
+    assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p2), p2.seed, 256, 0, True, 4))
