@@ -64,6 +64,13 @@ typedef struct pgsgd_graph_view {
 /* ---- parameters: the argument list of path_linear_sgd_layout_gpu -------------------------- */
 /* (reference: src/algorithms/path_sgd_layout.hpp:59-80; cuda::layout_config_t layout.h:65-77) */
 #define PGSGD_FLAG_COORD_LOAD_PLAIN   0x1u /* debug: read coordinates through L1/L2 (stale-prone)   */
+#define PGSGD_FLAG_FP32_ATOMICS       0x2u /* keep {f32 x, f32 y} words and use four fp32 atomic adds */
+                                           /* per term instead of the default 32.32 packed fixed      */
+                                           /* point with one 64-bit integer atomic add per node end  */
+#define PGSGD_FLAG_HOGWILD_STORES     0x4u /* update by load -> store like the reference CPU loop    */
+                                           /* (path_sgd_layout.cpp:360-363) instead of atomic adds   */
+#define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
+                                                  /* 3 no coordinate loads, 4 neither (results invalid) */
 
 typedef struct pgsgd_params {
     uint64_t iter_max;                    /* -x, default 30                                        */
@@ -129,12 +136,15 @@ typedef struct pgsgd_session pgsgd_session;
 
 int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out);
 void pgsgd_session_destroy(pgsgd_session* s);
-/* host fp32 X,Y [2N]  <->  device float4-per-node {x0,y0,x1,y1} coordinate buffer */
+/* host fp32 X,Y [2N]  <->  device coordinate words (one 8-byte word per node end) */
 int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y);
 int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y);
-/* device pointer to the 4N-float coordinate buffer and to use an externally owned one instead */
+/* device pointer to the 2N coordinate words, and their format: fixed_point 1 = {u32 Xq, u32 Yq}
+ * with x = x_off + Xq / quanta_per_bp (frame chosen at upload), 0 = {f32 x, f32 y} */
 void* pgsgd_session_coords_ptr(pgsgd_session* s);
-int pgsgd_session_bind_coords(pgsgd_session* s, void* device_ptr_4N_floats);
+int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words /* [2N] raw coordinate words */);
+int pgsgd_session_coord_format(const pgsgd_session* s, int* fixed_point, double* x_off, double* y_off,
+                               double* quanta_per_bp);
 /* launch stream (hipStream_t as void*); set to make the session launch on a caller stream */
 void* pgsgd_session_stream(pgsgd_session* s);
 int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream);
@@ -147,7 +157,7 @@ int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* laun
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
 /* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.
  *   mark : remember the current coordinates as the exchange base (call once, after upload);
- *   begin: buf[0..4N) = coords - base, buf[4N..6N) = squared length of each node end's delta;
+ *   begin: buf[2e..2e+1] = (dx, dy) node end e moved since the base, in bp; buf[4N+e] = dx^2+dy^2;
  *          the caller then all-reduces (SUM) the 6N-float device buffer over the G ranks;
  *   end  : coords = base + S * clamp(Q/|S|^2, 1/G, 1) per node end, base = coords. */
 int pgsgd_session_exchange_mark(pgsgd_session* s);

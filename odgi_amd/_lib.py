@@ -44,6 +44,8 @@ class Stats(C.Structure):
 
 
 FLAG_COORD_LOAD_PLAIN = 0x1
+FLAG_FP32_ATOMICS = 0x2
+FLAG_HOGWILD_STORES = 0x4
 DEFAULT_SEED = 9399220
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)
@@ -61,7 +63,8 @@ SIGNATURES = [
     ("pgsgd_session_upload_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
     ("pgsgd_session_download_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
     ("pgsgd_session_coords_ptr", C.c_void_p, [C.c_void_p]),
-    ("pgsgd_session_bind_coords", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pgsgd_session_download_words", C.c_int, [C.c_void_p, P(u64)]),
+    ("pgsgd_session_coord_format", C.c_int, [C.c_void_p, P(C.c_int), P(f64), P(f64), P(f64)]),
     ("pgsgd_session_stream", C.c_void_p, [C.c_void_p]),
     ("pgsgd_session_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_iteration", C.c_int, [C.c_void_p, f64, C.c_int, u64]),

@@ -35,11 +35,25 @@
 
 namespace pgsgd {
 
+// Coordinate formats.  Both keep one 8-byte word per node END (the two ends of a node share 16 B):
+//   kFmtQ32 (default): {u32 Xq, u32 Yq} fixed point, x = x_off + Xq / scale.  One 64-bit integer
+//            atomic add moves x and y together: for signed steps (qx, qy) the word changes by
+//            qx + qy*2^32 (mod 2^64), exact as long as each field stays inside [0, 2^32).  The
+//            atomic units of MI355X retire ~21-24 G scattered atomics/s whatever their width
+//            (tools/microbench.hip), so this halves the cost of the update, the kernel's limiter.
+//   kFmtF32: {f32 x, f32 y}, four fp32 atomic adds per term (the literal north-star form).
+enum : int { kFmtQ32 = 0, kFmtF32 = 1 };
+
+struct Xform {  // kFmtQ32 only
+    double x_off, y_off;
+    float scale, inv_scale;  // scale = 2^k quanta per bp
+};
+
 struct DevConst {
     const uint4* recs;
     const uint64_t* path_first;
     const double* zetas;
-    float* coords;
+    uint64_t* coords;  // [2N] words
     uint64_t* rng;
     unsigned int* delta_max_bits;
     uint64_t n_steps;
@@ -47,6 +61,7 @@ struct DevConst {
     uint32_t n_streams;
     uint64_t space, space_max, space_quant;
     ZipfConst zc;
+    Xform xf;
 };
 
 struct IterArgs {
@@ -69,24 +84,19 @@ __device__ __forceinline__ uint32_t find_path(const PF pf, uint32_t n_paths, uin
     return lo;
 }
 
+// Coordinates are read at agent scope (sc1): the load bypasses the per-CU L1, which other CUs'
+// atomics never refresh.  COORD_LOAD 0 is the plain (L1-cached) load, kept for A/B profiling.
 template <int COORD_LOAD>
-__device__ __forceinline__ float2 load_end(const float* coords, uint64_t end_idx) {
-    if (COORD_LOAD == 0) {
-        return *reinterpret_cast<const float2*>(coords + 2 * end_idx);
-    } else {
-        const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(coords + 2 * end_idx),
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float2 r;
-        r.x = __uint_as_float((uint32_t)bits);
-        r.y = __uint_as_float((uint32_t)(bits >> 32));
-        return r;
-    }
+__device__ __forceinline__ uint64_t load_word(const uint64_t* coords, uint32_t end_idx) {
+    if (COORD_LOAD == 0) return coords[end_idx];
+    return __hip_atomic_load(coords + end_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct Term {
     uint64_t ka, kb;
     uint64_t pos_a, pos_b;
     uint32_t end_a, end_b;  // 2*rank + end offset
+    uint32_t dither;        // low 32 bits of the draw whose top bit chose end a (otherwise unused)
 };
 
 // The sampler: path_sgd_layout.cpp:182-270 on the lowered index.
@@ -116,8 +126,11 @@ __device__ __forceinline__ Term sample_term(const DevConst& c, const PF pf, uint
     t.ka = k;
     t.kb = pstart + b_rank;
     const uint4 rb = c.recs[t.kb];
-    // :242-269 — choose an end of each node; the path position moves to that end
-    const uint32_t flip_a = coin(rng), flip_b = coin(rng);
+    // :242-269 — choose an end of each node; the path position moves to that end.
+    // flip(0,1) is the top bit of one draw (uniform_int_distribution never rejects for range 2).
+    const uint64_t draw_a = rng.next(), draw_b = rng.next();
+    const uint32_t flip_a = (uint32_t)(draw_a >> 63), flip_b = (uint32_t)(draw_b >> 63);
+    t.dither = (uint32_t)draw_a;
     const uint32_t h_a = ra.x, h_b = rb.x;
     uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32);
     uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
@@ -131,7 +144,38 @@ __device__ __forceinline__ Term sample_term(const DevConst& c, const PF pf, uint
     return t;
 }
 
-template <bool PF_LDS, int COORD_LOAD>
+// The displacement of one term in bp, fp32 (path_sgd_layout.cpp:280-352); dx,dy = p_a - p_b.
+__device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy,
+                                                  float& r_x, float& r_y, float& abs_delta) {
+    const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
+    float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > 1.0f) mu = 1.0f;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    abs_delta = fabsf(Delta);
+    const float r = Delta / mag;
+    r_x = r * dx;
+    r_y = r * dy;
+}
+
+// UPD: how a term's displacement reaches memory.
+//   kUpdAtomic: atomic adds — every concurrent displacement is applied (they accumulate).
+//   kUpdStore : the reference CPU's Hogwild form (path_sgd_layout.cpp:360-363: load, subtract,
+//               store): the new position of an end is computed from the loaded one and written back
+//               with one 8-byte agent-scope store; a concurrent update of the same end in between is
+//               overwritten, never summed.  A scattered 8-byte store costs ~1/3 of an atomic on
+//               MI355X (tools/microbench.hip) and cannot overshoot, whatever the concurrency.
+enum : int { kUpdAtomic = 0, kUpdStore = 1 };
+
+// ABL: profiling ablations (never used by the product path; PGSGD_FLAG_ABLATE selects them)
+//   1 = no atomics, 3 = no coordinate loads, 4 = neither
+template <bool PF_LDS, int COORD_LOAD, int FMT, int UPD, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterArgs a) {
     extern __shared__ uint64_t s_pf[];
     if (PF_LDS) {
@@ -150,31 +194,63 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     float dmax = 0.0f;
     for (uint64_t ti = g; ti < a.n_terms; ti += L) {
         const Term t = sample_term(c, pf, a.cooling, rng);
-        const float2 pa = load_end<COORD_LOAD>(c.coords, t.end_a);
-        const float2 pb = load_end<COORD_LOAD>(c.coords, t.end_b);
-        // :280-363 in fp32
-        const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
-        float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
-        if (d == 0.0f) d = 1e-9f;
-        const float w = 1.0f / d;
-        float mu = a.eta * w;
-        if (mu > 1.0f) mu = 1.0f;
-        float dx = pa.x - pb.x;
-        const float dy = pa.y - pb.y;
-        if (dx == 0.0f) dx = 1e-9f;
-        const float dx2 = dx * dx;
-        const float dy2 = dy * dy;
-        const float mag = sqrtf(dx2 + dy2);
-        const float Delta = (mu * (mag - d)) / 2.0f;
-        dmax = fmaxf(dmax, fabsf(Delta));
-        const float r = Delta / mag;
-        const float r_x = r * dx, r_y = r * dy;
-        float* ca = c.coords + 2 * (uint64_t)t.end_a;
-        float* cb = c.coords + 2 * (uint64_t)t.end_b;
-        unsafeAtomicAdd(ca, -r_x);
-        unsafeAtomicAdd(ca + 1, -r_y);
-        unsafeAtomicAdd(cb, r_x);
-        unsafeAtomicAdd(cb + 1, r_y);
+        uint64_t wa, wb;
+        if (ABL == 3 || ABL == 4) {
+            wa = (uint64_t)t.end_a * 0x100000001ull;
+            wb = (uint64_t)t.end_b * 0x100000003ull;
+        } else {
+            wa = load_word<COORD_LOAD>(c.coords, t.end_a);
+            wb = load_word<COORD_LOAD>(c.coords, t.end_b);
+        }
+        float dx, dy;
+        if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
+            dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+            dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+        } else {
+            dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
+            dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
+        }
+        float r_x, r_y, abs_delta;
+        term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+        dmax = fmaxf(dmax, abs_delta);
+        if (ABL == 1 || ABL == 4) {
+            dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
+        } else if (FMT == kFmtQ32) {
+            // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
+            // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum of
+            // all coordinates is conserved exactly.
+            const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+            const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+            float fx = r_x * c.xf.scale;
+            float fy = r_y * c.xf.scale;
+            fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+            fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+            const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+            if (UPD == kUpdAtomic) {
+                const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_a), (unsigned long long)(0 - delta));
+                atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
+            } else if (t.end_a != t.end_b) {  // same end twice: the reference's two load/store pairs cancel
+                const uint64_t na = (uint64_t)(uint32_t)((int64_t)(uint32_t)wa - qx) | ((uint64_t)(uint32_t)((int64_t)(wa >> 32) - qy) << 32);
+                const uint64_t nb = (uint64_t)(uint32_t)((int64_t)(uint32_t)wb + qx) | ((uint64_t)(uint32_t)((int64_t)(wb >> 32) + qy) << 32);
+                __hip_atomic_store(c.coords + t.end_a, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c.coords + t.end_b, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (UPD == kUpdAtomic) {
+            float* ca = reinterpret_cast<float*>(c.coords + t.end_a);
+            float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
+            unsafeAtomicAdd(ca, -r_x);
+            unsafeAtomicAdd(ca + 1, -r_y);
+            unsafeAtomicAdd(cb, r_x);
+            unsafeAtomicAdd(cb + 1, r_y);
+        } else if (t.end_a != t.end_b) {
+            const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
+            const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
+            __hip_atomic_store(c.coords + t.end_a, (uint64_t)__float_as_uint(ax) | ((uint64_t)__float_as_uint(ay) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.coords + t.end_b, (uint64_t)__float_as_uint(bx) | ((uint64_t)__float_as_uint(by) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     c.rng[g] = rng.s0;
     c.rng[L + g] = rng.s1;
@@ -231,49 +307,88 @@ __global__ void build_step_records(const uint32_t* step_handle, const uint64_t* 
     }
 }
 
-// host X[2N],Y[2N] (staged on the device) <-> interleaved coords[4N]
-__global__ void interleave_coords(const float* X, const float* Y, uint64_t n_ends, float* coords) {
+__device__ __forceinline__ uint32_t quantize(float v, double off, float scale) {
+    double q = rint(((double)v - off) * (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
+    return (uint32_t)q;
+}
+__device__ __forceinline__ float dequantize(uint32_t q, double off, float inv_scale) {
+    return (float)(off + (double)q * (double)inv_scale);
+}
+
+// host X[2N],Y[2N] (staged on the device) <-> coordinate words
+template <int FMT>
+__global__ void pack_coords(const float* X, const float* Y, uint64_t n_ends, Xform xf, uint64_t* coords) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
-        coords[2 * i] = X[i];
-        coords[2 * i + 1] = Y[i];
+        uint32_t lo, hi;
+        if (FMT == kFmtQ32) {
+            lo = quantize(X[i], xf.x_off, xf.scale);
+            hi = quantize(Y[i], xf.y_off, xf.scale);
+        } else {
+            lo = __float_as_uint(X[i]);
+            hi = __float_as_uint(Y[i]);
+        }
+        coords[i] = (uint64_t)lo | ((uint64_t)hi << 32);
     }
 }
-__global__ void deinterleave_coords(const float* coords, uint64_t n_ends, float* X, float* Y) {
+template <int FMT>
+__global__ void unpack_coords(const uint64_t* coords, uint64_t n_ends, Xform xf, float* X, float* Y) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
-        X[i] = coords[2 * i];
-        Y[i] = coords[2 * i + 1];
+        const uint64_t w = coords[i];
+        if (FMT == kFmtQ32) {
+            X[i] = dequantize((uint32_t)w, xf.x_off, xf.inv_scale);
+            Y[i] = dequantize((uint32_t)(w >> 32), xf.y_off, xf.inv_scale);
+        } else {
+            X[i] = __uint_as_float((uint32_t)w);
+            Y[i] = __uint_as_float((uint32_t)(w >> 32));
+        }
     }
 }
 
-// Multi-GPU exchange, step 1: buf[0..4N) = coords - start (what this rank changed since the last
-// exchange), buf[4N + e] = |delta of node end e|^2.  One fused buffer -> one all-reduce.
-__global__ void exchange_prepare_kernel(const float4* coords, const float4* start, uint64_t n_nodes, float* buf) {
-    float4* S = reinterpret_cast<float4*>(buf);
-    float2* Q = reinterpret_cast<float2*>(buf + 4 * n_nodes);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float4 c = coords[i], s = start[i];
-        const float4 d = make_float4(c.x - s.x, c.y - s.y, c.z - s.z, c.w - s.w);
-        S[i] = d;
-        Q[i] = make_float2(d.x * d.x + d.y * d.y, d.z * d.z + d.w * d.w);
+// Multi-GPU exchange, step 1: buf[2e], buf[2e+1] = what this rank moved node end e by since the
+// last exchange (bp), buf[4N + e] = squared length of that move.  One fused buffer, one all-reduce.
+template <int FMT>
+__global__ void exchange_prepare_kernel(const uint64_t* coords, const uint64_t* base, uint64_t n_ends, Xform xf, float* buf) {
+    float2* S = reinterpret_cast<float2*>(buf);
+    float* Q = buf + 2 * n_ends;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = coords[i], b = base[i];
+        float dx, dy;
+        if (FMT == kFmtQ32) {
+            dx = (float)((int64_t)(uint32_t)c - (int64_t)(uint32_t)b) * xf.inv_scale;
+            dy = (float)((int64_t)(c >> 32) - (int64_t)(b >> 32)) * xf.inv_scale;
+        } else {
+            dx = __uint_as_float((uint32_t)c) - __uint_as_float((uint32_t)b);
+            dy = __uint_as_float((uint32_t)(c >> 32)) - __uint_as_float((uint32_t)(b >> 32));
+        }
+        S[i] = make_float2(dx, dy);
+        Q[i] = dx * dx + dy * dy;
     }
 }
 
-// step 2, after the all-reduce (SUM) over G ranks: S = sum of the ranks' deltas, Q = sum of their
+// step 2, after the all-reduce (SUM) over G ranks: S = sum of the ranks' moves, Q = sum of their
 // squared lengths.  Each node end moves by S * f with f = clamp(Q / |S|^2, 1/G, 1): ranks that
-// pulled the end the same way (coherent deltas, |S|^2 = G*Q: every rank already made the full
+// pulled the end the same way (coherent moves, |S|^2 = G*Q: every rank already made the full
 // correction) are averaged, f = 1/G; uncorrelated small steps (|S|^2 ~ Q) add up, f = 1.
-__global__ void exchange_apply_kernel(float4* coords, float4* start, uint64_t n_nodes, const float* buf, float inv_world) {
-    const float4* S = reinterpret_cast<const float4*>(buf);
-    const float2* Q = reinterpret_cast<const float2*>(buf + 4 * n_nodes);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float4 d = S[i], s = start[i];
-        const float2 q = Q[i];
-        const float s0 = d.x * d.x + d.y * d.y, s1 = d.z * d.z + d.w * d.w;
-        const float f0 = s0 > 0.0f ? fminf(fmaxf(q.x / s0, inv_world), 1.0f) : 1.0f;
-        const float f1 = s1 > 0.0f ? fminf(fmaxf(q.y / s1, inv_world), 1.0f) : 1.0f;
-        const float4 c = make_float4(s.x + d.x * f0, s.y + d.y * f0, s.z + d.z * f1, s.w + d.w * f1);
-        coords[i] = c;
-        start[i] = c;
+template <int FMT>
+__global__ void exchange_apply_kernel(uint64_t* coords, uint64_t* base, uint64_t n_ends, Xform xf, const float* buf, float inv_world) {
+    const float2* S = reinterpret_cast<const float2*>(buf);
+    const float* Q = buf + 2 * n_ends;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float2 d = S[i];
+        const float s2 = d.x * d.x + d.y * d.y;
+        const float f = s2 > 0.0f ? fminf(fmaxf(Q[i] / s2, inv_world), 1.0f) : 1.0f;
+        const uint64_t b = base[i];
+        uint64_t w;
+        if (FMT == kFmtQ32) {
+            const int64_t qx = (int64_t)rintf(d.x * f * xf.scale), qy = (int64_t)rintf(d.y * f * xf.scale);
+            w = (uint64_t)(uint32_t)((int64_t)(uint32_t)b + qx) | ((uint64_t)(uint32_t)((int64_t)(b >> 32) + qy) << 32);
+        } else {
+            w = (uint64_t)__float_as_uint(__uint_as_float((uint32_t)b) + d.x * f) |
+                ((uint64_t)__float_as_uint(__uint_as_float((uint32_t)(b >> 32)) + d.y * f) << 32);
+        }
+        coords[i] = w;
+        base[i] = w;
     }
 }
 
@@ -298,19 +413,21 @@ struct pgsgd_session {
     bool own_stream = false;
     pgsgd_params params{};
     uint64_t n_nodes = 0, n_steps = 0, n_paths = 0;
+    uint64_t max_path_bp = 0;
     uint32_t n_streams = 0;
+    int fmt = pgsgd::kFmtQ32;
+    int upd = pgsgd::kUpdAtomic;
     bool pf_lds = false;
     size_t lds_bytes = 0;
     // device buffers
     uint4* d_recs = nullptr;
     uint64_t* d_path_first = nullptr;
     double* d_zetas = nullptr;
-    float* d_coords = nullptr;
-    bool own_coords = true;
+    uint64_t* d_coords = nullptr;         // [2N] coordinate words
+    uint64_t* d_base = nullptr;           // coordinates at the last exchange (multi-GPU only)
     uint64_t* d_rng = nullptr;
     unsigned int* d_delta_max = nullptr;
     unsigned int* h_delta_max = nullptr;  // pinned
-    float* d_start = nullptr;             // coordinates at the last exchange (multi-GPU only)
     pgsgd::DevConst dc{};
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
@@ -350,13 +467,37 @@ static int collect_events(pgsgd_session* s) {
 static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
     // Full residency of the update kernel, but never more concurrent terms than the graph can take:
     // atomic adds of concurrent terms on one node end accumulate (the reference's Hogwild stores
-    // overwrite instead), so the number of in-flight terms is kept below 1/8 of the node ends.
+    // overwrite instead), and with mu = 1 summed projections overshoot.  Measured on MI355X
+    // (profiles/r01/sweep_v1.jsonl): layouts stay at oracle quality up to ~2N/4 concurrent terms and
+    // diverge from ~2N/2 on; the cap is 2N/8 node ends per in-flight term.
     uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
-    uint64_t cap = (2 * s->n_nodes) / 8;
+    // Hogwild stores overwrite instead of accumulating: safe at any concurrency, but an update is
+    // wasted when another lands on the same end inside its load->store window, so in-flight terms
+    // are still kept below the number of node ends.
+    uint64_t cap = s->upd == pgsgd::kUpdStore ? (2 * s->n_nodes) / 2 : (2 * s->n_nodes) / 8;
     uint64_t n = std::min(full, std::max<uint64_t>(cap, 64));
     n = std::max<uint64_t>(64, (n / 64) * 64);
     if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
     return (uint32_t)n;
+}
+
+// every (PF_LDS, COORD_LOAD, FMT, UPD, ABL) instance the host can launch
+typedef void (*iter_kernel_t)(pgsgd::DevConst, pgsgd::IterArgs);
+template <int FMT, int UPD>
+static iter_kernel_t select_kernel_fu(bool pf_lds, bool plain, uint32_t abl) {
+    using namespace pgsgd;
+    if (abl) {
+        if (!pf_lds) return nullptr;
+        return abl == 1 ? sgd_iteration_kernel<true, 1, FMT, UPD, 1> : abl == 3 ? sgd_iteration_kernel<true, 1, FMT, UPD, 3>
+                                                                                : sgd_iteration_kernel<true, 1, FMT, UPD, 4>;
+    }
+    if (pf_lds) return plain ? sgd_iteration_kernel<true, 0, FMT, UPD, 0> : sgd_iteration_kernel<true, 1, FMT, UPD, 0>;
+    return plain ? sgd_iteration_kernel<false, 0, FMT, UPD, 0> : sgd_iteration_kernel<false, 1, FMT, UPD, 0>;
+}
+static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, uint32_t abl) {
+    using namespace pgsgd;
+    if (fmt == kFmtQ32) return upd == kUpdStore ? select_kernel_fu<kFmtQ32, kUpdStore>(pf_lds, plain, abl) : select_kernel_fu<kFmtQ32, kUpdAtomic>(pf_lds, plain, abl);
+    return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, abl);
 }
 
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
@@ -380,6 +521,15 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     s->n_nodes = g->n_nodes;
     s->n_steps = g->n_steps;
     s->n_paths = g->n_paths;
+    s->fmt = (p->flags & PGSGD_FLAG_FP32_ATOMICS) ? pgsgd::kFmtF32 : pgsgd::kFmtQ32;
+    s->upd = (p->flags & PGSGD_FLAG_HOGWILD_STORES) ? pgsgd::kUpdStore : pgsgd::kUpdAtomic;
+    for (uint64_t i = 0; i < g->n_paths; ++i) {
+        const uint64_t e = g->path_first[i + 1];
+        if (e > g->path_first[i]) {
+            const uint64_t last = e - 1;
+            s->max_path_bp = std::max(s->max_path_bp, g->step_pos[last] + g->node_len[g->step_handle[last] >> 1]);
+        }
+    }
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
         return code;
@@ -405,10 +555,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = p->n_streams;
     } else {
         int bpc = 0;
-        if (s->pf_lds)
-            S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_iteration_kernel<true, 1>, pgsgd::kBlock, s->lds_bytes));
-        else
-            S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_iteration_kernel<false, 1>, pgsgd::kBlock, 0));
+        iter_kernel_t k = select_kernel(s->pf_lds, false, s->fmt, s->upd, 0);
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k, pgsgd::kBlock, s->lds_bytes));
         if (bpc < 1) bpc = 1;
         s->n_streams = auto_streams(s, prop.multiProcessorCount, bpc);
     }
@@ -442,8 +590,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         S_TRY(hipMalloc(&s->d_zetas, nz * sizeof(double)));
         S_TRY(hipMemcpy(s->d_zetas, z.data(), nz * sizeof(double), hipMemcpyHostToDevice));
     }
-    S_TRY(hipMalloc(&s->d_coords, g->n_nodes * 4 * sizeof(float)));
-    S_TRY(hipMemset(s->d_coords, 0, g->n_nodes * 4 * sizeof(float)));
+    S_TRY(hipMalloc(&s->d_coords, g->n_nodes * 2 * sizeof(uint64_t)));
+    S_TRY(hipMemset(s->d_coords, 0, g->n_nodes * 2 * sizeof(uint64_t)));
     S_TRY(hipMalloc(&s->d_rng, (size_t)s->n_streams * 4 * sizeof(uint64_t)));
     S_TRY(hipMalloc(&s->d_delta_max, sizeof(unsigned int)));
     S_TRY(hipMemset(s->d_delta_max, 0, sizeof(unsigned int)));
@@ -470,6 +618,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.space_max = p->space_max;
     c.space_quant = p->space_quantization_step;
     c.zc.init(p->theta);
+    c.xf.x_off = c.xf.y_off = 0.0;
+    c.xf.scale = c.xf.inv_scale = 1.0f;
     *out = s;
     return PGSGD_OK;
 #undef S_TRY
@@ -484,13 +634,33 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_recs) (void)hipFree(s->d_recs);
     if (s->d_path_first) (void)hipFree(s->d_path_first);
     if (s->d_zetas) (void)hipFree(s->d_zetas);
-    if (s->d_coords && s->own_coords) (void)hipFree(s->d_coords);
+    if (s->d_coords) (void)hipFree(s->d_coords);
+    if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_rng) (void)hipFree(s->d_rng);
     if (s->d_delta_max) (void)hipFree(s->d_delta_max);
-    if (s->d_start) (void)hipFree(s->d_start);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+// Fixed-point frame for kFmtQ32: a power-of-two number of quanta per bp such that 2^32 quanta span
+// 8x the larger of the initial layout's extent and the longest path (the scale a path-guided
+// layout settles at), centred on the initial layout.
+static void choose_xform(pgsgd_session* s, const float* X, const float* Y) {
+    const uint64_t n_ends = 2 * s->n_nodes;
+    double minx = X[0], maxx = X[0], miny = Y[0], maxy = Y[0];
+    for (uint64_t i = 0; i < n_ends; ++i) {
+        if (std::isfinite(X[i])) { minx = std::min<double>(minx, X[i]); maxx = std::max<double>(maxx, X[i]); }
+        if (std::isfinite(Y[i])) { miny = std::min<double>(miny, Y[i]); maxy = std::max<double>(maxy, Y[i]); }
+    }
+    const double extent = std::max({maxx - minx, maxy - miny, (double)s->max_path_bp, 1.0});
+    const int span_log2 = (int)std::ceil(std::log2(8.0 * extent));
+    const double span = std::ldexp(1.0, span_log2);
+    pgsgd::Xform& xf = s->dc.xf;
+    xf.scale = (float)std::ldexp(1.0, 32 - span_log2);
+    xf.inv_scale = (float)std::ldexp(1.0, span_log2 - 32);
+    xf.x_off = 0.5 * (minx + maxx) - 0.5 * span;
+    xf.y_off = 0.5 * (miny + maxy) - 0.5 * span;
 }
 
 extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y) {
@@ -498,13 +668,17 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
     const uint64_t n_ends = 2 * s->n_nodes;
+    if (s->fmt == pgsgd::kFmtQ32) choose_xform(s, X, Y);
     float *dX = nullptr, *dY = nullptr;
     HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
     HIP_TRY(hipMalloc(&dY, n_ends * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(dX, X, n_ends * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(dY, Y, n_ends * sizeof(float), hipMemcpyHostToDevice, s->stream));
     const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
-    hipLaunchKernelGGL(pgsgd::interleave_coords, dim3(grid), dim3(256), 0, s->stream, dX, dY, n_ends, s->d_coords);
+    if (s->fmt == pgsgd::kFmtQ32)
+        hipLaunchKernelGGL(pgsgd::pack_coords<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, dX, dY, n_ends, s->dc.xf, s->d_coords);
+    else
+        hipLaunchKernelGGL(pgsgd::pack_coords<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, dX, dY, n_ends, s->dc.xf, s->d_coords);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(dX);
@@ -521,7 +695,10 @@ extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* 
     HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
     HIP_TRY(hipMalloc(&dY, n_ends * sizeof(float)));
     const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
-    hipLaunchKernelGGL(pgsgd::deinterleave_coords, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends, dX, dY);
+    if (s->fmt == pgsgd::kFmtQ32)
+        hipLaunchKernelGGL(pgsgd::unpack_coords<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends, s->dc.xf, dX, dY);
+    else
+        hipLaunchKernelGGL(pgsgd::unpack_coords<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends, s->dc.xf, dX, dY);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(X, dX, n_ends * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(Y, dY, n_ends * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -533,16 +710,21 @@ extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* 
 
 extern "C" void* pgsgd_session_coords_ptr(pgsgd_session* s) { return s ? (void*)s->d_coords : nullptr; }
 
-extern "C" int pgsgd_session_bind_coords(pgsgd_session* s, void* dptr) {
+extern "C" int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words) {
     pgsgd::clear_error();
-    if (!s || !dptr) return PGSGD_E_INVALID;
-    if (((uintptr_t)dptr & 15u) != 0) { set_error("coordinate buffer must be 16-byte aligned"); return PGSGD_E_INVALID; }
+    if (!s || !words) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(words, s->d_coords, s->n_nodes * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->d_coords && s->own_coords) (void)hipFree(s->d_coords);
-    s->d_coords = (float*)dptr;
-    s->own_coords = false;
-    s->dc.coords = s->d_coords;
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_coord_format(const pgsgd_session* s, int* fixed_point, double* x_off, double* y_off, double* quanta_per_bp) {
+    if (!s) return PGSGD_E_INVALID;
+    if (fixed_point) *fixed_point = s->fmt == pgsgd::kFmtQ32 ? 1 : 0;
+    if (x_off) *x_off = s->dc.xf.x_off;
+    if (y_off) *y_off = s->dc.xf.y_off;
+    if (quanta_per_bp) *quanta_per_bp = (double)s->dc.xf.scale;
     return PGSGD_OK;
 }
 
@@ -572,6 +754,10 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
         int rc = collect_events(s);
         if (rc) return rc;
     }
+    const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
+    const uint32_t abl = (s->params.flags >> 8) & 0xfu;
+    iter_kernel_t kernel = select_kernel(s->pf_lds, plain, s->fmt, s->upd, abl);
+    if (!kernel) { set_error("no kernel instance for these debug flags"); return PGSGD_E_UNSUPPORTED; }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!s->free_events.empty()) {
         ev = s->free_events.back();
@@ -587,15 +773,8 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
     a.cooling = cooling ? 1u : 0u;
     const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
     const uint32_t grid = (s->n_streams + block - 1) / block;
-    const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
     HIP_TRY(hipEventRecord(ev.first, s->stream));
-    if (s->pf_lds) {
-        if (plain) hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<true, 0>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
-        else hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<true, 1>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
-    } else {
-        if (plain) hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<false, 0>), dim3(grid), dim3(block), 0, s->stream, s->dc, a);
-        else hipLaunchKernelGGL((pgsgd::sgd_iteration_kernel<false, 1>), dim3(grid), dim3(block), 0, s->stream, s->dc, a);
-    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, s->stream));
     s->pending_events.push_back(ev);
@@ -627,37 +806,44 @@ extern "C" int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uin
 }
 
 // ---- multi-GPU exchange (see odgi_amd/distributed.py) ------------------------------------------
-extern "C" int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats) {
-    pgsgd::clear_error();
-    if (!s || !device_buf_6N_floats) return PGSGD_E_INVALID;
-    HIP_TRY(hipSetDevice(s->device));
-    const int grid = (int)std::min<uint64_t>((s->n_nodes + 255) / 256, 2048);
-    if (!s->d_start) {  // first exchange: nothing was changed yet relative to "now"
-        HIP_TRY(hipMalloc(&s->d_start, s->n_nodes * 4 * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(s->d_start, s->d_coords, s->n_nodes * 4 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    }
-    hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel, dim3(grid), dim3(256), 0, s->stream, (const float4*)s->d_coords,
-                       (const float4*)s->d_start, s->n_nodes, (float*)device_buf_6N_floats);
-    HIP_TRY(hipGetLastError());
-    return PGSGD_OK;
-}
-
 extern "C" int pgsgd_session_exchange_mark(pgsgd_session* s) {
     pgsgd::clear_error();
     if (!s) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
-    if (!s->d_start) HIP_TRY(hipMalloc(&s->d_start, s->n_nodes * 4 * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(s->d_start, s->d_coords, s->n_nodes * 4 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (!s->d_base) HIP_TRY(hipMalloc(&s->d_base, s->n_nodes * 2 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(s->d_base, s->d_coords, s->n_nodes * 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s->stream));
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats) {
+    pgsgd::clear_error();
+    if (!s || !device_buf_6N_floats) return PGSGD_E_INVALID;
+    if (!s->d_base) {
+        int rc = pgsgd_session_exchange_mark(s);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    if (s->fmt == pgsgd::kFmtQ32)
+        hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (float*)device_buf_6N_floats);
+    else
+        hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (float*)device_buf_6N_floats);
+    HIP_TRY(hipGetLastError());
     return PGSGD_OK;
 }
 
 extern "C" int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size) {
     pgsgd::clear_error();
-    if (!s || !device_buf_6N_floats || world_size < 1 || !s->d_start) return PGSGD_E_INVALID;
+    if (!s || !device_buf_6N_floats || world_size < 1 || !s->d_base) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
-    const int grid = (int)std::min<uint64_t>((s->n_nodes + 255) / 256, 2048);
-    hipLaunchKernelGGL(pgsgd::exchange_apply_kernel, dim3(grid), dim3(256), 0, s->stream, (float4*)s->d_coords, (float4*)s->d_start,
-                       s->n_nodes, (const float*)device_buf_6N_floats, 1.0f / (float)world_size);
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    const float inv_world = 1.0f / (float)world_size;
+    if (s->fmt == pgsgd::kFmtQ32)
+        hipLaunchKernelGGL(pgsgd::exchange_apply_kernel<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (const float*)device_buf_6N_floats, inv_world);
+    else
+        hipLaunchKernelGGL(pgsgd::exchange_apply_kernel<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (const float*)device_buf_6N_floats, inv_world);
     HIP_TRY(hipGetLastError());
     return PGSGD_OK;
 }

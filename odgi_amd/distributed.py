@@ -41,17 +41,18 @@ def split_blocks(n_terms, blocks):
 
 
 class HipEngine:
-    """The product engine: a LayoutSession whose coordinate buffer is a torch tensor."""
+    """The product engine: a LayoutSession launching on torch's current stream, so the RCCL
+    all-reduce of the exchange buffer (a torch tensor) is ordered with the kernels."""
 
     def __init__(self, graph, params: LayoutParams, X, Y):
         self.session = LayoutSession(graph, params)
         self.session.upload(X, Y)
-        self.coords = self.session.coords_tensor()
         self.session.use_torch_stream()
         self.n_nodes = graph.n_nodes
+        self.device = torch.device("cuda", torch.cuda.current_device() if params.device < 0 else params.device)
 
     def new_exchange_buffer(self):
-        return torch.empty(6 * self.n_nodes, dtype=torch.float32, device=self.coords.device)
+        return torch.empty(6 * self.n_nodes, dtype=torch.float32, device=self.device)
 
     def iteration(self, eta, cooling, n_terms):
         self.session.iteration(eta, cooling, n_terms)
@@ -69,10 +70,7 @@ class HipEngine:
         check(lib.pgsgd_session_exchange_end(self.session._h, C.c_void_p(buf.data_ptr()), int(world)), "exchange_end")
 
     def result(self):
-        c = self.coords.detach().cpu().numpy()
-        X = c[:, [0, 2]].reshape(-1).copy()
-        Y = c[:, [1, 3]].reshape(-1).copy()
-        return X, Y
+        return self.session.download()
 
     def close(self):
         self.session.close()

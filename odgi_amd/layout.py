@@ -126,7 +126,6 @@ class LayoutSession:
         self._h = C.c_void_p()
         self._cparams = params.to_c()
         check(lib.pgsgd_session_create(C.byref(graph.view), C.byref(self._cparams), C.byref(self._h)), "session_create")
-        self._bound = None
 
     def close(self):
         if self._h:
@@ -157,24 +156,17 @@ class LayoutSession:
         check(lib.pgsgd_session_download_coords(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
         return X, Y
 
-    def coords_tensor(self):
-        """The device coordinate buffer as a torch float32 tensor [N, 4] = {x0, y0, x1, y1}.
+    def download_words(self):
+        """Raw device coordinate words, uint64 [2N] (see coord_format)."""
+        w = np.zeros(2 * self.graph.n_nodes, dtype=np.uint64)
+        check(lib.pgsgd_session_download_words(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "download_words")
+        return w
 
-        The tensor is allocated by torch (so RCCL collectives and torch streams see it) and bound
-        into the session; the previous contents are carried over."""
-        import torch
-        if self._bound is None:
-            X, Y = self.download()
-            dev = torch.device("cuda", torch.cuda.current_device() if self.params.device < 0 else self.params.device)
-            t = torch.empty((self.graph.n_nodes, 4), dtype=torch.float32, device=dev)
-            t[:, 0] = torch.from_numpy(X[0::2]).to(dev)
-            t[:, 1] = torch.from_numpy(Y[0::2]).to(dev)
-            t[:, 2] = torch.from_numpy(X[1::2]).to(dev)
-            t[:, 3] = torch.from_numpy(Y[1::2]).to(dev)
-            torch.cuda.synchronize(dev)
-            check(lib.pgsgd_session_bind_coords(self._h, C.c_void_p(t.data_ptr())), "bind_coords")
-            self._bound = t
-        return self._bound
+    def coord_format(self):
+        """(fixed_point, x_off, y_off, quanta_per_bp) of the device coordinate words."""
+        fp, xo, yo, q = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        check(lib.pgsgd_session_coord_format(self._h, C.byref(fp), C.byref(xo), C.byref(yo), C.byref(q)), "coord_format")
+        return bool(fp.value), xo.value, yo.value, q.value
 
     def use_torch_stream(self):
         """Launch on torch's current stream so torch ops and collectives order with the kernels."""

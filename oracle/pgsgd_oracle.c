@@ -176,7 +176,11 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
     const uint32_t h_a = g->step_handle[t->ka], h_b = g->step_handle[t->kb]; /* :242-243 */
     uint64_t pos_a = g->step_pos[t->ka], pos_b = g->step_pos[t->kb];   /* :248-249 */
     const uint32_t rev_a = h_a & 1u, rev_b = h_b & 1u;                  /* :252,261 */
-    if (orc_flip(s)) {                                                 /* :253 */
+    /* flip(0,1) is the top bit of one draw (range 2 never rejects; check_libstdcxx.cpp pins that);
+     * the device reuses the low 32 bits of this draw as rounding dither */
+    const uint64_t draw_a = orc_rng_next(s);
+    t->dither = (uint32_t)draw_a;
+    if (draw_a >> 63) {                                                /* :253 */
         pos_a += g->node_len[h_a >> 1];
         t->off_a = !rev_a;
     } else {
@@ -225,7 +229,7 @@ static inline double update_f64(const orc_graph* g, const orc_term* t, double et
 
 /* fp32 mirror of the HIP kernel's arithmetic (odgi_amd/csrc/pgsgd_kernels.hip, term_update).
  * Compiled with -ffp-contract=off on both sides, so a 1-stream GPU run matches bit for bit. */
-static inline float update_f32(const orc_graph* g, const orc_term* t, float eta, float* X, float* Y) {
+static inline float update_f32(const orc_graph* g, const orc_term* t, float eta, float* X, float* Y, int stores) {
     const int64_t diff = (int64_t)t->pos_a - (int64_t)t->pos_b;
     const uint64_t ad = (uint64_t)(diff < 0 ? -diff : diff);
     float d = (float)ad;
@@ -244,11 +248,61 @@ static inline float update_f32(const orc_graph* g, const orc_term* t, float eta,
     const float Delta = (mu * (mag - d)) / 2.0f;
     const float r = Delta / mag;
     const float r_x = r * dx, r_y = r * dy;
+    /* store mode writes positions computed from the loaded ones and skips a term whose two ends are
+     * the same node end (the reference's two load/store pairs cancel there) */
+    if (stores && i == j) return fabsf(Delta);
     /* the device issues four atomic adds: a.x, a.y, b.x, b.y (same order) */
     X[i] = X[i] + (-r_x);
     Y[i] = Y[i] + (-r_y);
     X[j] = X[j] + r_x;
     Y[j] = Y[j] + r_y;
+    return fabsf(Delta);
+}
+
+/* mirror of the device's kFmtQ32 path (odgi_amd/csrc/pgsgd_device.hip: sgd_iteration_kernel,
+ * pack_coords/unpack_coords) */
+static inline uint32_t q32_quantize(float v, double off, float scale) {
+    double q = rint(((double)v - off) * (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
+    return (uint32_t)q;
+}
+
+static inline float update_q32(const orc_graph* g, const orc_term* t, float eta, float scale, float inv_scale, uint64_t* W, int stores) {
+    const uint64_t i = 2 * (uint64_t)(g->step_handle[t->ka] >> 1) + t->off_a;
+    const uint64_t j = 2 * (uint64_t)(g->step_handle[t->kb] >> 1) + t->off_b;
+    const uint64_t wa = W[i], wb = W[j];
+    float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
+    const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
+    const int64_t diff = (int64_t)t->pos_a - (int64_t)t->pos_b;
+    float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > 1.0f) mu = 1.0f;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    const float r = Delta / mag;
+    const float r_x = r * dx, r_y = r * dy;
+    const float ux = (float)(t->dither & 0xffffu) * (1.0f / 65536.0f);
+    const float uy = (float)(t->dither >> 16) * (1.0f / 65536.0f);
+    float fx = r_x * scale;
+    float fy = r_y * scale;
+    fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+    fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+    const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+    if (stores) {
+        if (i != j) {
+            W[i] = (uint64_t)(uint32_t)((int64_t)(uint32_t)wa - qx) | ((uint64_t)(uint32_t)((int64_t)(wa >> 32) - qy) << 32);
+            W[j] = (uint64_t)(uint32_t)((int64_t)(uint32_t)wb + qx) | ((uint64_t)(uint32_t)((int64_t)(wb >> 32) + qy) << 32);
+        }
+        return fabsf(Delta);
+    }
+    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+    W[i] += (uint64_t)0 - delta;   /* the device issues the add on end a first, then on end b */
+    W[j] += delta;
     return fabsf(Delta);
 }
 
@@ -298,7 +352,7 @@ static int has_multistep_path(const orc_graph* g) {
 }
 
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
-                            uint32_t n_streams, uint32_t stream_offset, float* X, float* Y,
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, float* X, float* Y,
                             double* last_delta_max) {
     if (last_delta_max) *last_delta_max = 0.0;
     if (!has_multistep_path(g)) return;                                /* :64-74 */
@@ -313,13 +367,58 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
             uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
             orc_term term;
             sample_valid(g, p, r.zetas, cooling, s, &term);
-            const float da = update_f32(g, &term, eta, X, Y);
+            const float da = update_f32(g, &term, eta, X, Y, hogwild_stores);
             if (da > dmax) dmax = da;
         }
         if (last_delta_max) *last_delta_max = dmax;
         if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;  /* :142 */
     }
     stream_run_free(&r);
+}
+
+void orc_layout_streams_q32(const orc_graph* g, const orc_params* p, uint64_t seed,
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, double x_off, double y_off,
+                            double quanta_per_bp, float* X, float* Y, double* last_delta_max,
+                            uint64_t* checksum) {
+    if (last_delta_max) *last_delta_max = 0.0;
+    const uint64_t n_ends = 2 * g->n_nodes;
+    const float scale = (float)quanta_per_bp, inv_scale = (float)(1.0 / quanta_per_bp);
+    uint64_t* W = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
+    for (uint64_t i = 0; i < n_ends; ++i)
+        W[i] = (uint64_t)q32_quantize(X[i], x_off, scale) | ((uint64_t)q32_quantize(Y[i], y_off, scale) << 32);
+    if (checksum) {
+        checksum[0] = checksum[1] = 0;
+        for (uint64_t i = 0; i < n_ends; ++i) { checksum[0] += (uint32_t)W[i]; checksum[1] += W[i] >> 32; }
+    }
+    if (has_multistep_path(g)) {
+        stream_run r;
+        stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+        const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+        for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
+            const float eta = (float)r.etas[iter];
+            const int cooling = iter >= first_cooling;
+            float dmax = 0.0f;
+            for (uint64_t t = 0; t < p->min_term_updates; ++t) {
+                uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
+                orc_term term;
+                sample_valid(g, p, r.zetas, cooling, s, &term);
+                const float da = update_q32(g, &term, eta, scale, inv_scale, W, hogwild_stores);
+                if (da > dmax) dmax = da;
+            }
+            if (last_delta_max) *last_delta_max = dmax;
+            if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;
+        }
+        stream_run_free(&r);
+    }
+    if (checksum) {
+        checksum[2] = checksum[3] = 0;
+        for (uint64_t i = 0; i < n_ends; ++i) { checksum[2] += (uint32_t)W[i]; checksum[3] += W[i] >> 32; }
+    }
+    for (uint64_t i = 0; i < n_ends; ++i) {
+        X[i] = (float)(x_off + (double)(uint32_t)W[i] * (double)inv_scale);
+        Y[i] = (float)(y_off + (double)(uint32_t)(W[i] >> 32) * (double)inv_scale);
+    }
+    free(W);
 }
 
 void orc_layout_streams_f64(const orc_graph* g, const orc_params* p, uint64_t seed,

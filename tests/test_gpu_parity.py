@@ -70,27 +70,75 @@ def test_single_step_and_ragged_paths(oa, orc, tmp_path):
         assert not np.any(got[..., 0] == 0)  # flat step 0 is the single-step path: never sampled
 
 
-def test_one_stream_run_is_bit_exact_with_fp32_oracle(oa, orc, graphs, ographs):
-    """A single stream is a sequential program: the GPU must reproduce the oracle's fp32 mirror of
-    the update arithmetic exactly (both built without FMA contraction)."""
-    g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
-    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000)
+def _run_session(oa, g, p, X0, Y0):
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        s.upload(X0, Y0)
+        fmt = s.coord_format()
+        w0 = s.download_words()
+        dmax = 0.0
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            dmax = s.sync()
+        X, Y = s.download()
+        return X, Y, dmax, fmt, w0, s.download_words()
+
+
+@pytest.mark.parametrize("stores", [False, True])
+def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ographs, stores):
+    """A single stream is a sequential program: the GPU must reproduce the oracle's mirror of the
+    update arithmetic exactly (both built without FMA contraction) — in the packed fixed-point and
+    the fp32 coordinate format, with atomic adds and with Hogwild stores."""
+    from odgi_amd import _lib
+    g, og = graphs("chr6.C4"), ographs("chr6.C4")   # loops: some terms hit the same node end twice
     X0, Y0 = oa.initial_layout(g, "d", seed=5)
+    sf = _lib.FLAG_HOGWILD_STORES if stores else 0
+    # {u32,u32} fixed point, one 64-bit integer atomic (or one 8-byte store) per node end
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000, flags=sf)
+    Xg, Yg, dmax_g, fmt, w0, w1 = _run_session(oa, g, p, X0, Y0)
+    fixed, x_off, y_off, q = fmt
+    assert fixed and q > 0
+    Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p), p.seed, 1, X0, Y0, x_off, y_off, q, stores=stores)
+    assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
+    assert dmax_g == dmax_o
+    # every term moves end a by -(qx,qy) and end b by +(qx,qy): the coordinate sums are conserved
+    sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
+    assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1])) == (int(ck[2]), int(ck[3]))
+    assert not np.array_equal(w0, w1)
+    # fp32 words: four fp32 atomic adds (or two 8-byte stores) per term
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000, flags=_lib.FLAG_FP32_ATOMICS | sf)
     Xg, Yg = X0.astype(np.float32), Y0.astype(np.float32)
     st = oa.path_linear_sgd_layout_gpu(g, p, Xg, Yg)
-    Xo, Yo, dmax = orc.layout_streams_f32(og, orc.params_from(p), p.seed, 1, X0, Y0)
+    Xo, Yo, dmax = orc.layout_streams_f32(og, orc.params_from(p), p.seed, 1, X0, Y0, stores=stores)
     assert st["iterations"] == 6 and st["term_updates"] == 18000 and st["n_streams"] == 1
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
-    assert st["last_delta_max"] == pytest.approx(dmax, rel=0, abs=0)
+    assert st["last_delta_max"] == dmax
 
 
-@pytest.mark.parametrize("name", ["DRB1-3123", "LPA", "chr6.C4"])
-def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name):
+def test_fixed_point_frame_and_roundtrip(oa, graphs):
+    """Upload/download through the fixed-point frame: error below one quantum, frame spans 8x the
+    larger of the initial extent and the longest path."""
+    g = graphs("LPA")
+    X0, Y0 = oa.initial_layout(g, "d", seed=1)
+    with oa.LayoutSession(g, _params(oa, g, n_streams=64)) as s:
+        s.upload(X0, Y0)
+        fixed, x_off, y_off, q = s.coord_format()
+        X, Y = s.download()
+    path_bp = max(int(g.step_pos[e - 1]) + int(g.node_len[g.step_handle[e - 1] >> 1]) for e in g.path_first[1:].astype(np.int64))
+    extent = max(X0.max() - X0.min(), Y0.max() - Y0.min(), path_bp)
+    assert fixed and 2.0 ** 32 / q >= 8 * extent and 2.0 ** 32 / q < 16 * extent
+    assert np.abs(X - X0.astype(np.float32)).max() <= 1.0 / q + np.abs(X0).max() * 2 ** -23
+    assert np.abs(Y - Y0.astype(np.float32)).max() <= 1.0 / q + np.abs(Y0).max() * 2 ** -23
+
+
+@pytest.mark.parametrize("name,flags", [("DRB1-3123", 0), ("LPA", 0), ("chr6.C4", 0), ("LPA", 2), ("LPA", 4), ("DRB1-3123", 6)])
+def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, flags):
     """BASELINE configs 1-3 with reference defaults.  The reference itself is Hogwild and not
     reproducible run to run; parity is on layout quality: sampled path stress of the GPU layout
     within 25 % (+0.02 absolute) of the CPU oracle's Hogwild layout from the same initial layout."""
+    from odgi_amd import _lib
     g, og = graphs(name), ographs(name)
-    p = _params(oa, g)
+    p = _params(oa, g, flags=flags)     # 0 default; 2 fp32 atomics; 4 Hogwild stores; 6 fp32 + stores
     X0, Y0 = oa.initial_layout(g, "d", seed=11)
     X, Y = X0.copy(), Y0.copy()
     st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
@@ -100,7 +148,7 @@ def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name):
     s_gpu = orc.path_stress_sampled(og, X, Y, 1_000_000)
     s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
     s_init = orc.path_stress_sampled(og, X0, Y0, 1_000_000)
-    print(f"{name}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
+    print(f"{name} flags {flags}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
     assert s_gpu <= 1.25 * s_cpu + 0.02
     d_gpu, d_cpu = orc.path_distance(og, X, Y)[0], orc.path_distance(og, Xo, Yo)[0]
     assert d_gpu <= 1.25 * d_cpu + 0.5          # `odgi stats -s` 2D figure, same tolerance
@@ -141,28 +189,35 @@ def test_delta_early_stop_and_counts(oa, graphs):
     assert st["last_delta_max"] > 0
 
 
-def test_session_torch_binding_and_snapshots(oa, orc, graphs, ographs, tmp_path):
+def test_session_api_exchange_and_snapshots(oa, orc, graphs, ographs, tmp_path):
     import torch
+    from odgi_amd.distributed import HipEngine, DistributedLayout
     g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
     p = _params(oa, g, n_streams=512)
     X0, Y0 = oa.initial_layout(g, "d", seed=9)
-    etas = oa.path_linear_sgd_layout_schedule(p)
-    with oa.LayoutSession(g, p) as s:
-        s.upload(X0, Y0)
-        t = s.coords_tensor()
-        assert t.shape == (g.n_nodes, 4) and t.is_cuda
-        assert np.array_equal(t[:, 0].cpu().numpy(), X0[0::2].astype(np.float32))
-        s.use_torch_stream()
-        for it in range(p.iter_max):
-            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
-            dmax = s.sync()
-            assert dmax > 0
-        ms, n = s.kernel_time()
-        assert n == p.iter_max and ms > 0
-        X, Y = s.download()
-        assert np.array_equal(t[:, 2].cpu().numpy(), X[1::2])
-    s_gpu = orc.path_stress_sampled(og, X, Y, 500_000)
-    assert s_gpu < 2.0
+    # the single-rank driver == the plain session loop (same streams, same launches)
+    eng = HipEngine(g, p, X0, Y0)
+    drv = DistributedLayout(p, eng)
+    assert drv.world == 1 and drv.run() == p.iter_max
+    ms, n = eng.session.kernel_time()
+    assert n == p.iter_max and ms > 0
+    X, Y = eng.result()
+    assert orc.path_stress_sampled(og, X, Y, 500_000) < 2.0
+    # a one-rank exchange is the identity up to one quantum: S = own move, f = clamp(Q/|S|^2, 1, 1) = 1
+    eng.exchange_mark()
+    eng.iteration(100.0, True, 50000)
+    buf = eng.new_exchange_buffer()
+    eng.exchange_begin(buf)
+    torch.cuda.synchronize()
+    X1, Y1 = eng.result()
+    moved = buf[: 4 * g.n_nodes].reshape(-1, 2).cpu().numpy()
+    assert np.abs(moved).max() > 0 and np.allclose(X1 - X, moved[:, 0], atol=1e-2) and np.allclose(Y1 - Y, moved[:, 1], atol=1e-2)
+    eng.exchange_end(buf, 1)
+    eng.sync()
+    X2, Y2 = eng.result()
+    _, _, _, q = eng.session.coord_format()
+    assert np.abs(X2 - X1).max() <= 1.5 / q + 1e-3 and np.abs(Y2 - Y1).max() <= 1.5 / q + 1e-3
+    eng.close()
     # snapshots: <prefix>1 .. <prefix>(iter_max-1), readable .lay files (path_sgd_layout.cpp:379-408)
     p2 = _params(oa, g, iter_max=4, snapshot_prefix=str(tmp_path / "snap_"))
     X, Y = X0.copy(), Y0.copy()
@@ -206,6 +261,12 @@ def test_synthetic_million_node_properties(oa, orc):
     st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
     assert st["term_updates"] == 10 * p.min_term_updates
     assert np.isfinite(X).all() and np.isfinite(Y).all()
+    # checksum of checksums at full concurrency: 4.7e9 concurrent 64-bit atomic adds must conserve
+    # the sums of the Xq and Yq fields exactly (each term adds -(qx,qy) to one end, +(qx,qy) to the other)
+    _, _, _, _, w0, w1 = _run_session(oa, g, _params(oa, g, iter_max=3), X0, Y0)
+    lo, hi = np.uint64(0xffffffff), np.uint64(32)
+    assert int((w0 & lo).sum()) == int((w1 & lo).sum()) and int((w0 >> hi).sum()) == int((w1 >> hi).sum())
+    assert np.count_nonzero(w0 != w1) > 1_900_000
     s_init = oa.path_stress(g, X0, Y0, 1_000_000)
     s_end = oa.path_stress(g, X, Y, 1_000_000)
     print(f"synthetic 1M: stress {s_init:.3f} -> {s_end:.4f}; {1e3 * st['term_updates'] / st['kernel_ms']:.3g} terms/s")

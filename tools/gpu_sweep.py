@@ -51,13 +51,13 @@ def exp_streams(args):
         Xo, Yo, hst = orc.layout_hogwild(og, orc.params_from(p0), min(8, os.cpu_count()), X0, Y0)
         s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
         emit(exp="streams", graph=name, engine="cpu_oracle_hogwild", stress=s_cpu, terms_per_s=hst["terms"] / hst["seconds"])
-        for flags in (0, _lib.FLAG_COORD_LOAD_PLAIN):
-            for ns in (64, 256, 1024, 4096, 16384, 0):
+        for flags in (0, _lib.FLAG_HOGWILD_STORES, _lib.FLAG_HOGWILD_STORES | _lib.FLAG_FP32_ATOMICS):
+            for ns in (256, 1024, 4096, 16384, 65536, 262144, 0):
                 p = oa.LayoutParams.defaults(g, device=0, n_streams=ns, flags=flags)
                 X, Y, st = run_layout(g, p, X0, Y0)
                 ok = bool(np.isfinite(X).all() and np.isfinite(Y).all())
                 s = orc.path_stress_sampled(og, X, Y, 1_000_000) if ok else float("nan")
-                emit(exp="streams", graph=name, plain_loads=bool(flags), n_streams=st["n_streams"], auto=(ns == 0), stress=s,
+                emit(exp="streams", graph=name, flags=flags, n_streams=st["n_streams"], auto=(ns == 0), stress=s,
                      stress_cpu=s_cpu, kernel_ms=st["kernel_ms"], terms_per_s=1e3 * st["term_updates"] / st["kernel_ms"])
 
 
