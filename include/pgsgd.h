@@ -93,6 +93,10 @@ typedef struct pgsgd_params {
     const char* snapshot_prefix;
     int32_t  progress;    /* 1 = progress line on stderr                                           */
     uint32_t flags;       /* PGSGD_FLAG_*                                                          */
+    uint32_t terms_per_anchor; /* partners drawn per first step; 0/1 = the reference's term stream.     */
+                          /* m > 1 keeps each term's distribution (first step uniform, partner by    */
+                          /* the reference's rule) but fetches and updates the first step once per m  */
+                          /* terms — fewer scattered memory requests per term                         */
 } pgsgd_params;
 
 #define PGSGD_DEFAULT_SEED 9399220ull

@@ -35,7 +35,7 @@ class Params(C.Structure):
                 ("space", u64), ("space_max", u64), ("space_quantization_step", u64),
                 ("cooling_start", f64), ("seed", u64), ("n_streams", u32), ("stream_offset", u32),
                 ("device", i32), ("snapshot", i32), ("snapshot_prefix", C.c_char_p),
-                ("progress", i32), ("flags", u32)]
+                ("progress", i32), ("flags", u32), ("terms_per_anchor", u32)]
 
 
 class Stats(C.Structure):

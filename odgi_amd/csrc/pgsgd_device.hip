@@ -60,6 +60,7 @@ struct DevConst {
     uint32_t n_paths;
     uint32_t n_streams;
     uint64_t space, space_max, space_quant;
+    uint64_t terms_per_anchor;
     ZipfConst zc;
     Xform xf;
 };
@@ -92,50 +93,60 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t* coords, uint32_t e
     return __hip_atomic_load(coords + end_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+struct Anchor {
+    uint64_t k, pstart, cnt, s_rank;
+    uint4 rec;
+};
+
 struct Term {
-    uint64_t ka, kb;
+    uint64_t kb;
     uint64_t pos_a, pos_b;
     uint32_t end_a, end_b;  // 2*rank + end offset
     uint32_t dither;        // low 32 bits of the draw whose top bit chose end a (otherwise unused)
 };
 
-// The sampler: path_sgd_layout.cpp:182-270 on the lowered index.
+// The sampler: path_sgd_layout.cpp:182-270 on the lowered index, split at the point where the
+// first step is fixed.  One anchor followed by one partner is exactly the reference's sequence of
+// draws; `terms_per_anchor` > 1 draws further partners (:205-270) for the same first step.
 template <typename PF>
-__device__ __forceinline__ Term sample_term(const DevConst& c, const PF pf, uint32_t cooling, Xoshiro256Plus& rng) {
-    Term t;
-    uint64_t k, pstart, cnt;
+__device__ __forceinline__ Anchor sample_anchor(const DevConst& c, const PF pf, Xoshiro256Plus& rng) {
+    Anchor a;
     do {  // :182-192 — a single-step path makes the reference draw again without counting a term
-        k = uniform_below(rng, c.n_steps);
-        const uint32_t p = find_path(pf, c.n_paths, k);
-        pstart = pf[p];
-        cnt = pf[p + 1] - pstart;
-    } while (cnt == 1);
-    const uint4 ra = c.recs[k];  // issued early; consumed after the partner is chosen
-    const uint64_t s_rank = k - pstart;
+        a.k = uniform_below(rng, c.n_steps);
+        const uint32_t p = find_path(pf, c.n_paths, a.k);
+        a.pstart = pf[p];
+        a.cnt = pf[p + 1] - a.pstart;
+    } while (a.cnt == 1);
+    a.rec = c.recs[a.k];  // issued early; consumed after the partner is chosen
+    a.s_rank = a.k - a.pstart;
+    return a;
+}
+
+__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng) {
+    Term t;
     uint64_t b_rank;
-    if (cooling || coin(rng)) {                                          // :205
-        const bool back = (s_rank > 0 && coin(rng)) || s_rank == cnt - 1;  // :206
-        const uint64_t room = back ? s_rank : cnt - s_rank - 1;
+    if (cooling || coin(rng)) {                                               // :205
+        const bool back = (a.s_rank > 0 && coin(rng)) || a.s_rank == a.cnt - 1;  // :206
+        const uint64_t room = back ? a.s_rank : a.cnt - a.s_rank - 1;
         const uint64_t jump = c.space < room ? c.space : room;
         const double zeta_n = c.zetas[zeta_index(jump, c.space_max, c.space_quant)];
         const uint64_t z = zipf(rng, c.zc, jump, zeta_n);
-        b_rank = back ? s_rank - z : s_rank + z;
+        b_rank = back ? a.s_rank - z : a.s_rank + z;
     } else {
-        b_rank = uniform_below(rng, cnt);                                // :235-237
+        b_rank = uniform_below(rng, a.cnt);                                   // :235-237
     }
-    t.ka = k;
-    t.kb = pstart + b_rank;
+    t.kb = a.pstart + b_rank;
     const uint4 rb = c.recs[t.kb];
     // :242-269 — choose an end of each node; the path position moves to that end.
     // flip(0,1) is the top bit of one draw (uniform_int_distribution never rejects for range 2).
     const uint64_t draw_a = rng.next(), draw_b = rng.next();
     const uint32_t flip_a = (uint32_t)(draw_a >> 63), flip_b = (uint32_t)(draw_b >> 63);
     t.dither = (uint32_t)draw_a;
-    const uint32_t h_a = ra.x, h_b = rb.x;
-    uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32);
+    const uint32_t h_a = a.rec.x, h_b = rb.x;
+    uint64_t pos_a = (uint64_t)a.rec.z | ((uint64_t)a.rec.w << 32);
     uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
     uint32_t off_a = h_a & 1u, off_b = h_b & 1u;
-    if (flip_a) { pos_a += ra.y; off_a ^= 1u; }
+    if (flip_a) { pos_a += a.rec.y; off_a ^= 1u; }
     if (flip_b) { pos_b += rb.y; off_b ^= 1u; }
     t.pos_a = pos_a;
     t.pos_b = pos_b;
@@ -164,18 +175,32 @@ __device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uin
     r_y = r * dy;
 }
 
+__device__ __forceinline__ uint64_t pack_f32(float x, float y) {
+    return (uint64_t)__float_as_uint(x) | ((uint64_t)__float_as_uint(y) << 32);
+}
+__device__ __forceinline__ uint64_t q32_shift(uint64_t w, int64_t qx, int64_t qy) {  // per-field add, no carry between fields
+    return (uint64_t)(uint32_t)((int64_t)(uint32_t)w + qx) | ((uint64_t)(uint32_t)((int64_t)(w >> 32) + qy) << 32);
+}
+
 // UPD: how a term's displacement reaches memory.
 //   kUpdAtomic: atomic adds — every concurrent displacement is applied (they accumulate).
 //   kUpdStore : the reference CPU's Hogwild form (path_sgd_layout.cpp:360-363: load, subtract,
 //               store): the new position of an end is computed from the loaded one and written back
 //               with one 8-byte agent-scope store; a concurrent update of the same end in between is
-//               overwritten, never summed.  A scattered 8-byte store costs ~1/3 of an atomic on
-//               MI355X (tools/microbench.hip) and cannot overshoot, whatever the concurrency.
+//               overwritten, never summed.
 enum : int { kUpdAtomic = 0, kUpdStore = 1 };
 
 // ABL: profiling ablations (never used by the product path; PGSGD_FLAG_ABLATE selects them)
 //   1 = no atomics, 3 = no coordinate loads, 4 = neither
-template <bool PF_LDS, int COORD_LOAD, int FMT, int UPD, int ABL = 0>
+//
+// One anchor group = one first step `a` with `terms_per_anchor` partners.  The anchor's record and
+// both of its node ends are fetched once per group; the anchor-side displacement of each term is
+// applied to the lane's private copy at once (the next partner sees it) and reaches memory as ONE
+// update per touched end when the group ends.  Partner-side updates go out term by term.
+// terms_per_anchor = 1 is the reference's term stream.
+// GROUPED = false is the terms_per_anchor == 1 instance: same results, no group bookkeeping, fewer
+// registers (7 instead of 5 resident waves per SIMD).
+template <bool PF_LDS, int COORD_LOAD, int FMT, int UPD, bool GROUPED, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterArgs a) {
     extern __shared__ uint64_t s_pf[];
     if (PF_LDS) {
@@ -192,64 +217,168 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     rng.s2 = c.rng[2 * L + g];
     rng.s3 = c.rng[3 * L + g];
     float dmax = 0.0f;
-    for (uint64_t ti = g; ti < a.n_terms; ti += L) {
-        const Term t = sample_term(c, pf, a.cooling, rng);
-        uint64_t wa, wb;
-        if (ABL == 3 || ABL == 4) {
-            wa = (uint64_t)t.end_a * 0x100000001ull;
-            wb = (uint64_t)t.end_b * 0x100000003ull;
-        } else {
-            wa = load_word<COORD_LOAD>(c.coords, t.end_a);
-            wb = load_word<COORD_LOAD>(c.coords, t.end_b);
-        }
-        float dx, dy;
-        if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
-            dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
-            dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
-        } else {
-            dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
-            dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
-        }
-        float r_x, r_y, abs_delta;
-        term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
-        dmax = fmaxf(dmax, abs_delta);
-        if (ABL == 1 || ABL == 4) {
-            dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
-        } else if (FMT == kFmtQ32) {
-            // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
-            // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum of
-            // all coordinates is conserved exactly.
-            const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
-            const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
-            float fx = r_x * c.xf.scale;
-            float fy = r_y * c.xf.scale;
-            fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
-            fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
-            const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
-            if (UPD == kUpdAtomic) {
-                const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-                atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_a), (unsigned long long)(0 - delta));
-                atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
-            } else if (t.end_a != t.end_b) {  // same end twice: the reference's two load/store pairs cancel
-                const uint64_t na = (uint64_t)(uint32_t)((int64_t)(uint32_t)wa - qx) | ((uint64_t)(uint32_t)((int64_t)(wa >> 32) - qy) << 32);
-                const uint64_t nb = (uint64_t)(uint32_t)((int64_t)(uint32_t)wb + qx) | ((uint64_t)(uint32_t)((int64_t)(wb >> 32) + qy) << 32);
-                __hip_atomic_store(c.coords + t.end_a, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(c.coords + t.end_b, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!GROUPED) {
+        for (uint64_t ti = g; ti < a.n_terms; ti += L) {
+            const Anchor an = sample_anchor(c, pf, rng);
+            const Term t = sample_partner(c, an, a.cooling, rng);
+            uint64_t wa, wb;
+            if (ABL == 3 || ABL == 4) {
+                wa = (uint64_t)t.end_a * 0x100000001ull;
+                wb = (uint64_t)t.end_b * 0x100000003ull;
+            } else {
+                wa = load_word<COORD_LOAD>(c.coords, t.end_a);
+                wb = load_word<COORD_LOAD>(c.coords, t.end_b);
             }
-        } else if (UPD == kUpdAtomic) {
-            float* ca = reinterpret_cast<float*>(c.coords + t.end_a);
-            float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
-            unsafeAtomicAdd(ca, -r_x);
-            unsafeAtomicAdd(ca + 1, -r_y);
-            unsafeAtomicAdd(cb, r_x);
-            unsafeAtomicAdd(cb + 1, r_y);
-        } else if (t.end_a != t.end_b) {
-            const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
-            const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
-            __hip_atomic_store(c.coords + t.end_a, (uint64_t)__float_as_uint(ax) | ((uint64_t)__float_as_uint(ay) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(c.coords + t.end_b, (uint64_t)__float_as_uint(bx) | ((uint64_t)__float_as_uint(by) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float dx, dy;
+            if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
+                dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+                dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+            } else {
+                dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
+                dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
+            }
+            float r_x, r_y, abs_delta;
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            dmax = fmaxf(dmax, abs_delta);
+            if (ABL == 1 || ABL == 4) {
+                dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
+                continue;
+            }
+            if (UPD == kUpdStore && t.end_a == t.end_b) continue;  // the reference's two load/store pairs cancel
+            if (FMT == kFmtQ32) {
+                // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
+                // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum
+                // of all coordinates is conserved exactly.
+                const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                    // partner end first, anchor end second: the order of the grouped path and of the oracle mirror
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_a), (unsigned long long)(0 - delta));
+                } else {
+                    __hip_atomic_store(c.coords + t.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(c.coords + t.end_a, q32_shift(wa, -qx, -qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (UPD == kUpdAtomic) {
+                float* ca = reinterpret_cast<float*>(c.coords + t.end_a);
+                float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
+                unsafeAtomicAdd(cb, r_x);
+                unsafeAtomicAdd(cb + 1, r_y);
+                unsafeAtomicAdd(ca, -r_x);
+                unsafeAtomicAdd(ca + 1, -r_y);
+            } else {
+                const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
+                const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
+                __hip_atomic_store(c.coords + t.end_b, pack_f32(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c.coords + t.end_a, pack_f32(ax, ay), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    const uint64_t m = c.terms_per_anchor;
+    const uint64_t n_groups = GROUPED ? (a.n_terms + m - 1) / m : 0;
+    for (uint64_t grp = g; grp < n_groups; grp += L) {
+        const uint64_t first = grp * m;
+        const uint32_t mt = (uint32_t)(a.n_terms - first < m ? a.n_terms - first : m);
+        const Anchor an = sample_anchor(c, pf, rng);
+        const uint32_t node_a = an.rec.x & ~1u;  // word index of the anchor node's start end
+        // private copy of the anchor node's two ends (loaded on first use) and what this group
+        // moved each of them by; scalars and bit masks, not arrays: a dynamically indexed array
+        // would live in scratch memory
+        uint64_t la0 = 0, la1 = 0, dq0 = 0, dq1 = 0;
+        float dfx0 = 0.0f, dfy0 = 0.0f, dfx1 = 0.0f, dfy1 = 0.0f;
+        uint32_t have = 0, touched = 0;
+        for (uint32_t r = 0; r < mt; ++r) {
+            const Term t = sample_partner(c, an, a.cooling, rng);
+            const uint32_t ea = t.end_a & 1u, bit = 1u << ea;
+            if (!(have & bit)) {
+                const uint64_t w = (ABL == 3 || ABL == 4) ? (uint64_t)t.end_a * 0x100000001ull : load_word<COORD_LOAD>(c.coords, t.end_a);
+                if (ea) la1 = w; else la0 = w;
+                have |= bit;
+            }
+            const uint64_t wa = ea ? la1 : la0;
+            uint64_t wb;
+            if (ABL == 3 || ABL == 4) wb = (uint64_t)t.end_b * 0x100000003ull;
+            else wb = load_word<COORD_LOAD>(c.coords, t.end_b);
+            float dx, dy;
+            if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
+                dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+                dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+            } else {
+                dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
+                dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
+            }
+            float r_x, r_y, abs_delta;
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            dmax = fmaxf(dmax, abs_delta);
+            if (ABL == 1 || ABL == 4) {
+                dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
+                continue;
+            }
+            // a term on one and the same node end: the reference's two load/store pairs cancel
+            if (UPD == kUpdStore && t.end_a == t.end_b) continue;
+            touched |= bit;
+            uint64_t na;  // the anchor end after this term
+            if (FMT == kFmtQ32) {
+                // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
+                // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum
+                // of all coordinates is conserved exactly.
+                const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                    na = wa - delta;   // what the word will hold once the group's add has landed
+                    if (ea) dq1 += delta; else dq0 += delta;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
+                } else {
+                    na = q32_shift(wa, -qx, -qy);
+                    __hip_atomic_store(c.coords + t.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
+                na = pack_f32(ax, ay);
+                if (UPD == kUpdAtomic) {
+                    if (ea) { dfx1 += -r_x; dfy1 += -r_y; } else { dfx0 += -r_x; dfy0 += -r_y; }
+                    float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
+                    unsafeAtomicAdd(cb, r_x);
+                    unsafeAtomicAdd(cb + 1, r_y);
+                } else {
+                    const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
+                    __hip_atomic_store(c.coords + t.end_b, pack_f32(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (ea) la1 = na; else la0 = na;
+        }
+        // the anchor side reaches memory once per touched end
+        if (ABL != 1 && ABL != 4) {
+            if (touched & 1u) {
+                if (UPD == kUpdStore) __hip_atomic_store(c.coords + node_a, la0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (FMT == kFmtQ32) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + node_a), (unsigned long long)(0 - dq0));
+                else {
+                    float* ca = reinterpret_cast<float*>(c.coords + node_a);
+                    unsafeAtomicAdd(ca, dfx0);
+                    unsafeAtomicAdd(ca + 1, dfy0);
+                }
+            }
+            if (touched & 2u) {
+                if (UPD == kUpdStore) __hip_atomic_store(c.coords + node_a + 1, la1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (FMT == kFmtQ32) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + node_a + 1), (unsigned long long)(0 - dq1));
+                else {
+                    float* ca = reinterpret_cast<float*>(c.coords + node_a + 1);
+                    unsafeAtomicAdd(ca, dfx1);
+                    unsafeAtomicAdd(ca + 1, dfy1);
+                }
+            }
         }
     }
     c.rng[g] = rng.s0;
@@ -275,10 +404,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cool
     const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
     Xoshiro256Plus rng;
     rng.seed(seed_base + g);
+    Anchor an{};
     for (uint64_t j = 0; j < terms_per_stream; ++j) {
-        const Term t = sample_term(c, pf, cooling, rng);
+        if (j % c.terms_per_anchor == 0) an = sample_anchor(c, pf, rng);
+        const Term t = sample_partner(c, an, cooling, rng);
         uint64_t* o = out + (j * (uint64_t)c.n_streams + g) * 4;
-        o[0] = t.ka;
+        o[0] = an.k;
         o[1] = t.kb;
         o[2] = t.end_a & 1u;
         o[3] = t.end_b & 1u;
@@ -414,6 +545,7 @@ struct pgsgd_session {
     pgsgd_params params{};
     uint64_t n_nodes = 0, n_steps = 0, n_paths = 0;
     uint64_t max_path_bp = 0;
+    uint64_t max_node_steps = 0;  // path steps on the most visited node
     uint32_t n_streams = 0;
     int fmt = pgsgd::kFmtQ32;
     int upd = pgsgd::kUpdAtomic;
@@ -465,39 +597,44 @@ static int collect_events(pgsgd_session* s) {
 }
 
 static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
-    // Full residency of the update kernel, but never more concurrent terms than the graph can take:
-    // atomic adds of concurrent terms on one node end accumulate (the reference's Hogwild stores
-    // overwrite instead), and with mu = 1 summed projections overshoot.  Measured on MI355X
-    // (profiles/r01/sweep_v1.jsonl): layouts stay at oracle quality up to ~2N/4 concurrent terms and
-    // diverge from ~2N/2 on; the cap is 2N/8 node ends per in-flight term.
-    uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
-    // Hogwild stores overwrite instead of accumulating: safe at any concurrency, but an update is
-    // wasted when another lands on the same end inside its load->store window, so in-flight terms
-    // are still kept below the number of node ends.
-    uint64_t cap = s->upd == pgsgd::kUpdStore ? (2 * s->n_nodes) / 2 : (2 * s->n_nodes) / 8;
+    // Full residency of the update kernel, unless the graph cannot take that many concurrent terms.
+    // Concurrent displacements of one node end are all computed from the same (stale) position and
+    // then added together; with mu = 1 each of them is a full projection, so about four or more in
+    // flight on one end overshoot and the layout oscillates apart.  What matters is the HOTTEST
+    // node: a term touches a node in proportion to the path steps on it, so with L terms in flight
+    // the busiest node sees L * max_node_steps / S of them.  Measured on MI355X
+    // (profiles/r01/sweep_*.jsonl, tools/gpu_replicates.py): layouts keep oracle quality up to 4-16
+    // in flight on the busiest node and diverge beyond; the cap is 2.  (Hogwild stores never
+    // diverge but lose quality at about the same point, so they share the rule.)
+    const uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
+    const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
     uint64_t n = std::min(full, std::max<uint64_t>(cap, 64));
     n = std::max<uint64_t>(64, (n / 64) * 64);
     if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
     return (uint32_t)n;
 }
 
-// every (PF_LDS, COORD_LOAD, FMT, UPD, ABL) instance the host can launch
+// every (PF_LDS, COORD_LOAD, FMT, UPD, GROUPED, ABL) instance the host can launch
 typedef void (*iter_kernel_t)(pgsgd::DevConst, pgsgd::IterArgs);
-template <int FMT, int UPD>
-static iter_kernel_t select_kernel_fu(bool pf_lds, bool plain, uint32_t abl) {
+template <int FMT, int UPD, bool GROUPED>
+static iter_kernel_t select_kernel_fug(bool pf_lds, bool plain, uint32_t abl) {
     using namespace pgsgd;
     if (abl) {
         if (!pf_lds) return nullptr;
-        return abl == 1 ? sgd_iteration_kernel<true, 1, FMT, UPD, 1> : abl == 3 ? sgd_iteration_kernel<true, 1, FMT, UPD, 3>
-                                                                                : sgd_iteration_kernel<true, 1, FMT, UPD, 4>;
+        return abl == 1 ? sgd_iteration_kernel<true, 1, FMT, UPD, GROUPED, 1> : abl == 3 ? sgd_iteration_kernel<true, 1, FMT, UPD, GROUPED, 3>
+                                                                                         : sgd_iteration_kernel<true, 1, FMT, UPD, GROUPED, 4>;
     }
-    if (pf_lds) return plain ? sgd_iteration_kernel<true, 0, FMT, UPD, 0> : sgd_iteration_kernel<true, 1, FMT, UPD, 0>;
-    return plain ? sgd_iteration_kernel<false, 0, FMT, UPD, 0> : sgd_iteration_kernel<false, 1, FMT, UPD, 0>;
+    if (pf_lds) return plain ? sgd_iteration_kernel<true, 0, FMT, UPD, GROUPED, 0> : sgd_iteration_kernel<true, 1, FMT, UPD, GROUPED, 0>;
+    return plain ? sgd_iteration_kernel<false, 0, FMT, UPD, GROUPED, 0> : sgd_iteration_kernel<false, 1, FMT, UPD, GROUPED, 0>;
 }
-static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, uint32_t abl) {
+template <int FMT, int UPD>
+static iter_kernel_t select_kernel_fu(bool pf_lds, bool plain, bool grouped, uint32_t abl) {
+    return grouped ? select_kernel_fug<FMT, UPD, true>(pf_lds, plain, abl) : select_kernel_fug<FMT, UPD, false>(pf_lds, plain, abl);
+}
+static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bool grouped, uint32_t abl) {
     using namespace pgsgd;
-    if (fmt == kFmtQ32) return upd == kUpdStore ? select_kernel_fu<kFmtQ32, kUpdStore>(pf_lds, plain, abl) : select_kernel_fu<kFmtQ32, kUpdAtomic>(pf_lds, plain, abl);
-    return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, abl);
+    if (fmt == kFmtQ32) return upd == kUpdStore ? select_kernel_fu<kFmtQ32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtQ32, kUpdAtomic>(pf_lds, plain, grouped, abl);
+    return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, grouped, abl);
 }
 
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
@@ -530,6 +667,15 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             s->max_path_bp = std::max(s->max_path_bp, g->step_pos[last] + g->node_len[g->step_handle[last] >> 1]);
         }
     }
+    if (!p->n_streams) {  // only the automatic stream count needs the hottest node
+        std::vector<uint32_t> per_node(g->n_nodes, 0);
+        for (uint64_t k = 0; k < g->n_steps; ++k) {
+            const uint32_t r = g->step_handle[k] >> 1;
+            if (r >= g->n_nodes) { set_error("step %llu names node rank %u of %llu", (unsigned long long)k, r, (unsigned long long)g->n_nodes); delete s; return PGSGD_E_INVALID; }
+            per_node[r]++;
+        }
+        for (uint32_t v : per_node) s->max_node_steps = std::max<uint64_t>(s->max_node_steps, v);
+    }
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
         return code;
@@ -555,7 +701,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = p->n_streams;
     } else {
         int bpc = 0;
-        iter_kernel_t k = select_kernel(s->pf_lds, false, s->fmt, s->upd, 0);
+        iter_kernel_t k = select_kernel(s->pf_lds, false, s->fmt, s->upd, p->terms_per_anchor > 1, 0);
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k, pgsgd::kBlock, s->lds_bytes));
         if (bpc < 1) bpc = 1;
         s->n_streams = auto_streams(s, prop.multiProcessorCount, bpc);
@@ -617,6 +763,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.space = p->space;
     c.space_max = p->space_max;
     c.space_quant = p->space_quantization_step;
+    c.terms_per_anchor = p->terms_per_anchor ? p->terms_per_anchor : 1;
     c.zc.init(p->theta);
     c.xf.x_off = c.xf.y_off = 0.0;
     c.xf.scale = c.xf.inv_scale = 1.0f;
@@ -756,7 +903,7 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
     const uint32_t abl = (s->params.flags >> 8) & 0xfu;
-    iter_kernel_t kernel = select_kernel(s->pf_lds, plain, s->fmt, s->upd, abl);
+    iter_kernel_t kernel = select_kernel(s->pf_lds, plain, s->fmt, s->upd, s->dc.terms_per_anchor > 1, abl);
     if (!kernel) { set_error("no kernel instance for these debug flags"); return PGSGD_E_UNSUPPORTED; }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!s->free_events.empty()) {

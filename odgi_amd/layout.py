@@ -43,6 +43,7 @@ class LayoutParams:
     snapshot_prefix: str = ""
     progress: bool = False
     flags: int = 0
+    terms_per_anchor: int = 1
 
     @classmethod
     def defaults(cls, graph: Graph, **overrides):
@@ -63,7 +64,7 @@ class LayoutParams:
         p = _lib.Params()
         for f in ("iter_max", "iter_with_max_learning_rate", "min_term_updates", "delta", "eps", "eta_max",
                   "theta", "space", "space_max", "space_quantization_step", "cooling_start", "seed",
-                  "n_streams", "stream_offset", "device", "flags"):
+                  "n_streams", "stream_offset", "device", "flags", "terms_per_anchor"):
             setattr(p, f, getattr(self, f))
         p.snapshot = 1 if self.snapshot_prefix else 0
         self._prefix_bytes = self.snapshot_prefix.encode() if self.snapshot_prefix else None

@@ -60,11 +60,11 @@ def _load(name):
     lib.orc_zeta_size.restype = C.c_size_t
     lib.orc_zetas.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _F64P]
     lib.orc_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32,
-                                    C.c_int, C.c_uint64, _U64P]
+                                    C.c_int, C.c_uint32, C.c_uint64, _U64P]
     lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
-                                           C.c_uint32, C.c_int, _F32P, _F32P, _F64P]
+                                           C.c_uint32, C.c_int, C.c_uint32, _F32P, _F32P, _F64P]
     lib.orc_layout_streams_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
-                                           C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_double, _F32P, _F32P, _F64P, _U64P]
+                                           C.c_uint32, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double, _F32P, _F32P, _F64P, _U64P]
     lib.orc_layout_streams_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, _F64P, _F64P]
     lib.orc_layout_batched_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
@@ -145,29 +145,30 @@ def zetas(theta, space, space_max, quant):
     return z
 
 
-def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream):
+def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream, terms_per_anchor=1):
     out = np.zeros((terms_per_stream, n_streams, 4), dtype=np.uint64)
     lib().orc_trace_terms(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if cooling else 0,
-                          terms_per_stream, out.ctypes.data_as(_U64P))
+                          terms_per_anchor, terms_per_stream, out.ctypes.data_as(_U64P))
     return out
 
 
-def layout_streams_f32(g, p, seed, n_streams, X, Y, stream_offset=0, stores=False):
+def layout_streams_f32(g, p, seed, n_streams, X, Y, stream_offset=0, stores=False, terms_per_anchor=1):
     X = np.ascontiguousarray(X, dtype=np.float32).copy()
     Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
     d = C.c_double()
-    lib().orc_layout_streams_f32(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if stores else 0,
+    lib().orc_layout_streams_f32(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if stores else 0, terms_per_anchor,
                                  X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P), C.byref(d))
     return X, Y, d.value
 
 
-def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp, stream_offset=0, stores=False):
+def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp, stream_offset=0, stores=False,
+                       terms_per_anchor=1):
     """Mirror of the device's packed fixed-point path. Returns X, Y (fp32), last delta_max, checksums[4]."""
     X = np.ascontiguousarray(X, dtype=np.float32).copy()
     Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
     d = C.c_double()
     ck = np.zeros(4, dtype=np.uint64)
-    lib().orc_layout_streams_q32(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if stores else 0,
+    lib().orc_layout_streams_q32(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if stores else 0, terms_per_anchor,
                                  x_off, y_off, quanta_per_bp,
                                  X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P), C.byref(d), ck.ctypes.data_as(_U64P))
     return X, Y, d.value, ck

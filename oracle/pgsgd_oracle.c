@@ -141,15 +141,24 @@ void orc_zetas(double theta, uint64_t space, uint64_t space_max, uint64_t quant,
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* sampler: path_sgd_layout.cpp:182-270.  RNG draw order is the reference's. */
-int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
-                    uint64_t s[4], orc_term* t) {
+/* sampler: path_sgd_layout.cpp:182-270, split where the first step is fixed.  RNG draw order is the
+ * reference's: orc_sample_anchor then orc_sample_partner is one reference term. */
+typedef struct orc_anchor { uint64_t k, pstart, cnt, s_rank; } orc_anchor;
+
+static int orc_sample_anchor(const orc_graph* g, uint64_t s[4], orc_anchor* a) {
     const uint64_t step_index = orc_uniform_u64(s, g->n_steps);        /* :182 */
     const uint64_t path_i = g->step_path[step_index];                  /* :186 npi_iv */
-    const uint64_t pstart = g->path_first[path_i];
-    const uint64_t path_step_count = g->path_first[path_i + 1] - pstart; /* :189 */
-    if (path_step_count == 1) return 0;                                /* :190-192 */
-    const uint64_t s_rank = step_index - pstart;                       /* :200 nr_iv - 1 */
+    a->pstart = g->path_first[path_i];
+    a->cnt = g->path_first[path_i + 1] - a->pstart;                    /* :189 */
+    if (a->cnt == 1) return 0;                                         /* :190-192 */
+    a->k = step_index;
+    a->s_rank = step_index - a->pstart;                                /* :200 nr_iv - 1 */
+    return 1;
+}
+
+static void orc_sample_partner(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
+                               const orc_anchor* a, uint64_t s[4], orc_term* t) {
+    const uint64_t s_rank = a->s_rank, path_step_count = a->cnt;
     uint64_t b_rank;
     if (cooling || orc_flip(s)) {                                      /* :205 */
         if ((s_rank > 0 && orc_flip(s)) || s_rank == path_step_count - 1) { /* :206 backward */
@@ -171,8 +180,8 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
     } else {
         b_rank = orc_uniform_u64(s, path_step_count);                  /* :235-237 */
     }
-    t->ka = step_index;
-    t->kb = pstart + b_rank;
+    t->ka = a->k;
+    t->kb = a->pstart + b_rank;
     const uint32_t h_a = g->step_handle[t->ka], h_b = g->step_handle[t->kb]; /* :242-243 */
     uint64_t pos_a = g->step_pos[t->ka], pos_b = g->step_pos[t->kb];   /* :248-249 */
     const uint32_t rev_a = h_a & 1u, rev_b = h_b & 1u;                  /* :252,261 */
@@ -194,6 +203,13 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
     }
     t->pos_a = pos_a;
     t->pos_b = pos_b;
+}
+
+int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
+                    uint64_t s[4], orc_term* t) {
+    orc_anchor a;
+    if (!orc_sample_anchor(g, s, &a)) return 0;
+    orc_sample_partner(g, p, zetas, cooling, &a, s, t);
     return 1;
 }
 
@@ -201,6 +217,9 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
 static inline void sample_valid(const orc_graph* g, const orc_params* p, const double* zetas,
                                 int cooling, uint64_t s[4], orc_term* t) {
     while (!orc_sample_term(g, p, zetas, cooling, s, t)) { }
+}
+static inline void anchor_valid(const orc_graph* g, uint64_t s[4], orc_anchor* a) {
+    while (!orc_sample_anchor(g, s, a)) { }
 }
 
 /* update in fp64, exactly path_sgd_layout.cpp:283-363 (single-threaded view of the same loads/stores) */
@@ -227,53 +246,13 @@ static inline double update_f64(const orc_graph* g, const orc_term* t, double et
     return fabs(Delta);
 }
 
-/* fp32 mirror of the HIP kernel's arithmetic (odgi_amd/csrc/pgsgd_kernels.hip, term_update).
- * Compiled with -ffp-contract=off on both sides, so a 1-stream GPU run matches bit for bit. */
-static inline float update_f32(const orc_graph* g, const orc_term* t, float eta, float* X, float* Y, int stores) {
-    const int64_t diff = (int64_t)t->pos_a - (int64_t)t->pos_b;
-    const uint64_t ad = (uint64_t)(diff < 0 ? -diff : diff);
-    float d = (float)ad;
-    if (d == 0.0f) d = 1e-9f;
-    const float w = 1.0f / d;
-    float mu = eta * w;
-    if (mu > 1.0f) mu = 1.0f;
-    const uint64_t i = 2 * (uint64_t)(g->step_handle[t->ka] >> 1) + t->off_a;
-    const uint64_t j = 2 * (uint64_t)(g->step_handle[t->kb] >> 1) + t->off_b;
-    float dx = X[i] - X[j];
-    const float dy = Y[i] - Y[j];
-    if (dx == 0.0f) dx = 1e-9f;
-    const float dx2 = dx * dx;
-    const float dy2 = dy * dy;
-    const float mag = sqrtf(dx2 + dy2);
-    const float Delta = (mu * (mag - d)) / 2.0f;
-    const float r = Delta / mag;
-    const float r_x = r * dx, r_y = r * dy;
-    /* store mode writes positions computed from the loaded ones and skips a term whose two ends are
-     * the same node end (the reference's two load/store pairs cancel there) */
-    if (stores && i == j) return fabsf(Delta);
-    /* the device issues four atomic adds: a.x, a.y, b.x, b.y (same order) */
-    X[i] = X[i] + (-r_x);
-    Y[i] = Y[i] + (-r_y);
-    X[j] = X[j] + r_x;
-    Y[j] = Y[j] + r_y;
-    return fabsf(Delta);
-}
-
-/* mirror of the device's kFmtQ32 path (odgi_amd/csrc/pgsgd_device.hip: sgd_iteration_kernel,
- * pack_coords/unpack_coords) */
-static inline uint32_t q32_quantize(float v, double off, float scale) {
-    double q = rint(((double)v - off) * (double)scale);
-    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
-    return (uint32_t)q;
-}
-
-static inline float update_q32(const orc_graph* g, const orc_term* t, float eta, float scale, float inv_scale, uint64_t* W, int stores) {
-    const uint64_t i = 2 * (uint64_t)(g->step_handle[t->ka] >> 1) + t->off_a;
-    const uint64_t j = 2 * (uint64_t)(g->step_handle[t->kb] >> 1) + t->off_b;
-    const uint64_t wa = W[i], wb = W[j];
-    float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
-    const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
-    const int64_t diff = (int64_t)t->pos_a - (int64_t)t->pos_b;
+/* ---- mirrors of the HIP kernel (odgi_amd/csrc/pgsgd_device.hip: sgd_iteration_kernel) ----------
+ * One anchor group = one first step with `mt` partners.  The anchor node's two ends are loaded once,
+ * each term's anchor-side displacement is applied to that private copy at once and reaches memory as
+ * one update per touched end when the group ends; partner-side updates go out term by term.
+ * Built with -ffp-contract=off on both sides, so a 1-stream GPU run matches bit for bit. */
+static inline float displacement_f32(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy, float* r_x, float* r_y) {
+    const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
     float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
     if (d == 0.0f) d = 1e-9f;
     const float w = 1.0f / d;
@@ -285,38 +264,127 @@ static inline float update_q32(const orc_graph* g, const orc_term* t, float eta,
     const float mag = sqrtf(dx2 + dy2);
     const float Delta = (mu * (mag - d)) / 2.0f;
     const float r = Delta / mag;
-    const float r_x = r * dx, r_y = r * dy;
-    const float ux = (float)(t->dither & 0xffffu) * (1.0f / 65536.0f);
-    const float uy = (float)(t->dither >> 16) * (1.0f / 65536.0f);
-    float fx = r_x * scale;
-    float fy = r_y * scale;
-    fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
-    fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
-    const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
-    if (stores) {
-        if (i != j) {
-            W[i] = (uint64_t)(uint32_t)((int64_t)(uint32_t)wa - qx) | ((uint64_t)(uint32_t)((int64_t)(wa >> 32) - qy) << 32);
-            W[j] = (uint64_t)(uint32_t)((int64_t)(uint32_t)wb + qx) | ((uint64_t)(uint32_t)((int64_t)(wb >> 32) + qy) << 32);
-        }
-        return fabsf(Delta);
-    }
-    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-    W[i] += (uint64_t)0 - delta;   /* the device issues the add on end a first, then on end b */
-    W[j] += delta;
+    *r_x = r * dx;
+    *r_y = r * dy;
     return fabsf(Delta);
 }
 
+static inline uint64_t q32_shift(uint64_t w, int64_t qx, int64_t qy) {
+    return (uint64_t)(uint32_t)((int64_t)(uint32_t)w + qx) | ((uint64_t)(uint32_t)((int64_t)(w >> 32) + qy) << 32);
+}
+
+static inline uint32_t q32_quantize(float v, double off, float scale) {
+    double q = rint(((double)v - off) * (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
+    return (uint32_t)q;
+}
+
+/* fp32 words {x, y}: X[e], Y[e] per node end */
+static float group_f32(const orc_graph* g, const orc_params* p, const double* zetas, int cooling, uint64_t s[4],
+                       uint32_t mt, float eta, int stores, float* X, float* Y) {
+    orc_anchor an;
+    anchor_valid(g, s, &an);
+    const uint64_t node_a = (uint64_t)(g->step_handle[an.k] & ~1u);
+    float lx[2] = {0.0f, 0.0f}, ly[2] = {0.0f, 0.0f};   /* private copy of the anchor ends, loaded on first use */
+    int have[2] = {0, 0};
+    float dfx[2] = {0.0f, 0.0f}, dfy[2] = {0.0f, 0.0f};
+    int touched[2] = {0, 0};
+    float dmax = 0.0f;
+    for (uint32_t r = 0; r < mt; ++r) {
+        orc_term t;
+        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+        const uint32_t ea = t.off_a;
+        const uint64_t j = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+        if (!have[ea]) { lx[ea] = X[node_a + ea]; ly[ea] = Y[node_a + ea]; have[ea] = 1; }
+        const float dx = lx[ea] - X[j], dy = ly[ea] - Y[j];
+        float r_x, r_y;
+        const float da = displacement_f32(eta, t.pos_a, t.pos_b, dx, dy, &r_x, &r_y);
+        if (da > dmax) dmax = da;
+        if (stores && node_a + ea == j) continue;
+        touched[ea] = 1;
+        lx[ea] = lx[ea] + (-r_x);
+        ly[ea] = ly[ea] + (-r_y);
+        if (stores) {
+            const float bx = X[j] + r_x, by = Y[j] + r_y;
+            X[j] = bx; Y[j] = by;
+        } else {
+            dfx[ea] += -r_x;
+            dfy[ea] += -r_y;
+            X[j] = X[j] + r_x;
+            Y[j] = Y[j] + r_y;
+        }
+    }
+    for (int e = 0; e < 2; ++e) {
+        if (!touched[e]) continue;
+        if (stores) { X[node_a + e] = lx[e]; Y[node_a + e] = ly[e]; }
+        else { X[node_a + e] = X[node_a + e] + dfx[e]; Y[node_a + e] = Y[node_a + e] + dfy[e]; }
+    }
+    return dmax;
+}
+
+/* packed {u32 Xq, u32 Yq} words */
+static float group_q32(const orc_graph* g, const orc_params* p, const double* zetas, int cooling, uint64_t s[4],
+                       uint32_t mt, float eta, int stores, float scale, float inv_scale, uint64_t* W) {
+    orc_anchor an;
+    anchor_valid(g, s, &an);
+    const uint64_t node_a = (uint64_t)(g->step_handle[an.k] & ~1u);
+    uint64_t la[2] = {0, 0}, dq[2] = {0, 0};
+    int have[2] = {0, 0};
+    int touched[2] = {0, 0};
+    float dmax = 0.0f;
+    for (uint32_t r = 0; r < mt; ++r) {
+        orc_term t;
+        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+        const uint32_t ea = t.off_a;
+        const uint64_t j = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+        if (!have[ea]) { la[ea] = W[node_a + ea]; have[ea] = 1; }
+        const uint64_t wa = la[ea], wb = W[j];
+        const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
+        const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
+        float r_x, r_y;
+        const float da = displacement_f32(eta, t.pos_a, t.pos_b, dx, dy, &r_x, &r_y);
+        if (da > dmax) dmax = da;
+        if (stores && node_a + ea == j) continue;
+        touched[ea] = 1;
+        const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+        const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+        float fx = r_x * scale;
+        float fy = r_y * scale;
+        fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+        fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+        const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+        if (stores) {
+            la[ea] = q32_shift(wa, -qx, -qy);
+            W[j] = q32_shift(wb, qx, qy);
+        } else {
+            const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+            la[ea] = wa - delta;
+            dq[ea] += delta;
+            W[j] += delta;
+        }
+    }
+    for (int e = 0; e < 2; ++e) {
+        if (!touched[e]) continue;
+        if (stores) W[node_a + e] = la[e];
+        else W[node_a + e] += (uint64_t)0 - dq[e];
+    }
+    return dmax;
+}
+
 void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams,
-                     uint32_t stream_offset, int cooling, uint64_t terms_per_stream, uint64_t* out) {
+                     uint32_t stream_offset, int cooling, uint32_t terms_per_anchor, uint64_t terms_per_stream, uint64_t* out) {
     const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
     double* zetas = (double*)malloc(nz * sizeof(double));
     orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    if (terms_per_anchor == 0) terms_per_anchor = 1;
     for (uint32_t gi = 0; gi < n_streams; ++gi) {
         uint64_t s[4];
         orc_rng_seed(seed + stream_offset + gi, s);
+        orc_anchor an;
         for (uint64_t j = 0; j < terms_per_stream; ++j) {
             orc_term t;
-            sample_valid(g, p, zetas, cooling, s, &t);
+            if (j % terms_per_anchor == 0) anchor_valid(g, s, &an);
+            orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
             uint64_t* o = out + (j * (uint64_t)n_streams + gi) * 4;
             o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
         }
@@ -351,23 +419,25 @@ static int has_multistep_path(const orc_graph* g) {
     return 0;
 }
 
+/* group q of an iteration (terms q*m .. q*m+m-1) belongs to stream q % n_streams; groups run in order */
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
-                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, float* X, float* Y,
-                            double* last_delta_max) {
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
+                            float* X, float* Y, double* last_delta_max) {
     if (last_delta_max) *last_delta_max = 0.0;
     if (!has_multistep_path(g)) return;                                /* :64-74 */
     stream_run r;
     stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+    const uint64_t m = terms_per_anchor ? terms_per_anchor : 1;
     const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max); /* :39 */
+    const uint64_t n_groups = (p->min_term_updates + m - 1) / m;
     for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
         const float eta = (float)r.etas[iter];
         const int cooling = iter >= first_cooling;
         float dmax = 0.0f;
-        for (uint64_t t = 0; t < p->min_term_updates; ++t) {
-            uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
-            orc_term term;
-            sample_valid(g, p, r.zetas, cooling, s, &term);
-            const float da = update_f32(g, &term, eta, X, Y, hogwild_stores);
+        for (uint64_t q = 0; q < n_groups; ++q) {
+            const uint64_t left = p->min_term_updates - q * m;
+            const float da = group_f32(g, p, r.zetas, cooling, r.states + 4 * (size_t)(q % n_streams),
+                                       (uint32_t)(left < m ? left : m), eta, hogwild_stores, X, Y);
             if (da > dmax) dmax = da;
         }
         if (last_delta_max) *last_delta_max = dmax;
@@ -377,9 +447,9 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 }
 
 void orc_layout_streams_q32(const orc_graph* g, const orc_params* p, uint64_t seed,
-                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, double x_off, double y_off,
-                            double quanta_per_bp, float* X, float* Y, double* last_delta_max,
-                            uint64_t* checksum) {
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
+                            double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
+                            double* last_delta_max, uint64_t* checksum) {
     if (last_delta_max) *last_delta_max = 0.0;
     const uint64_t n_ends = 2 * g->n_nodes;
     const float scale = (float)quanta_per_bp, inv_scale = (float)(1.0 / quanta_per_bp);
@@ -393,16 +463,17 @@ void orc_layout_streams_q32(const orc_graph* g, const orc_params* p, uint64_t se
     if (has_multistep_path(g)) {
         stream_run r;
         stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+        const uint64_t m = terms_per_anchor ? terms_per_anchor : 1;
         const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+        const uint64_t n_groups = (p->min_term_updates + m - 1) / m;
         for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
             const float eta = (float)r.etas[iter];
             const int cooling = iter >= first_cooling;
             float dmax = 0.0f;
-            for (uint64_t t = 0; t < p->min_term_updates; ++t) {
-                uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
-                orc_term term;
-                sample_valid(g, p, r.zetas, cooling, s, &term);
-                const float da = update_q32(g, &term, eta, scale, inv_scale, W, hogwild_stores);
+            for (uint64_t q = 0; q < n_groups; ++q) {
+                const uint64_t left = p->min_term_updates - q * m;
+                const float da = group_q32(g, p, r.zetas, cooling, r.states + 4 * (size_t)(q % n_streams),
+                                           (uint32_t)(left < m ? left : m), eta, hogwild_stores, scale, inv_scale, W);
                 if (da > dmax) dmax = da;
             }
             if (last_delta_max) *last_delta_max = dmax;

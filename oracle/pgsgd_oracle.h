@@ -71,17 +71,17 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
  * i, i+n, i+2n, ... of each iteration; here executed round-robin in term order.
  * trace: out[(j*n_streams+g)*4+{0..3}] = {ka,kb,off_a,off_b} for fresh streams (first iteration). */
 void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams,
-                     uint32_t stream_offset, int cooling, uint64_t terms_per_stream, uint64_t* out);
+                     uint32_t stream_offset, int cooling, uint32_t terms_per_anchor, uint64_t terms_per_stream, uint64_t* out);
 /* fp32 mirror of the device arithmetic; bit-exact with the GPU for n_streams == 1 */
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
-                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, float* X, float* Y,
-                            double* last_delta_max);
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
+                            float* X, float* Y, double* last_delta_max);
 /* mirror of the device's default coordinate format: {u32 Xq, u32 Yq} fixed point, x = x_off + Xq/scale,
  * stochastic rounding of each step with the term's spare random bits; X,Y are quantised on entry and
  * de-quantised on exit exactly as the device's upload/download do.  Bit-exact for n_streams == 1. */
 void orc_layout_streams_q32(const orc_graph* g, const orc_params* p, uint64_t seed,
-                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, double x_off, double y_off,
-                            double quanta_per_bp, float* X, float* Y, double* last_delta_max,
+                            uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
+                            double x_off, double y_off, double quanta_per_bp, float* X, float* Y, double* last_delta_max,
                             uint64_t* checksum_before_after /* [4]: sum Xq, sum Yq before; after */);
 /* same schedule of terms, fp64 arithmetic exactly as path_sgd_layout.cpp:283-363 */
 void orc_layout_streams_f64(const orc_graph* g, const orc_params* p, uint64_t seed,

@@ -32,6 +32,22 @@ def test_sampler_streams_bit_exact(oa, orc, graphs, ographs, name, n_streams, of
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("m", [2, 4, 7])
+def test_sampler_streams_with_anchor_groups(oa, orc, graphs, ographs, m):
+    """terms_per_anchor = m: one first step, m partners — same per-term draws, bit-exact."""
+    g, og = graphs("chr6.C4"), ographs("chr6.C4")
+    for cooling in (False, True):
+        p = _params(oa, g, n_streams=256, terms_per_anchor=m)
+        with oa.LayoutSession(g, p) as s:
+            got = s.trace_terms(cooling, 21)
+        want = orc.trace_terms(og, orc.params_from(p), p.seed, 256, 0, cooling, 21, terms_per_anchor=m)
+        assert np.array_equal(got, want)
+        ka = got[..., 0]
+        for j in range(21):
+            if j % m:
+                assert np.array_equal(ka[j], ka[j - 1])          # the anchor is kept inside a group
+
+
 def test_sampler_matches_committed_golden_vectors(oa, graphs):
     gv = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
     g = graphs("DRB1-3123")
@@ -84,8 +100,8 @@ def _run_session(oa, g, p, X0, Y0):
         return X, Y, dmax, fmt, w0, s.download_words()
 
 
-@pytest.mark.parametrize("stores", [False, True])
-def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ographs, stores):
+@pytest.mark.parametrize("stores,m", [(False, 1), (True, 1), (False, 4), (True, 3)])
+def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ographs, stores, m):
     """A single stream is a sequential program: the GPU must reproduce the oracle's mirror of the
     update arithmetic exactly (both built without FMA contraction) — in the packed fixed-point and
     the fp32 coordinate format, with atomic adds and with Hogwild stores."""
@@ -94,11 +110,12 @@ def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ograph
     X0, Y0 = oa.initial_layout(g, "d", seed=5)
     sf = _lib.FLAG_HOGWILD_STORES if stores else 0
     # {u32,u32} fixed point, one 64-bit integer atomic (or one 8-byte store) per node end
-    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000, flags=sf)
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3001, flags=sf, terms_per_anchor=m)
     Xg, Yg, dmax_g, fmt, w0, w1 = _run_session(oa, g, p, X0, Y0)
     fixed, x_off, y_off, q = fmt
     assert fixed and q > 0
-    Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p), p.seed, 1, X0, Y0, x_off, y_off, q, stores=stores)
+    Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p), p.seed, 1, X0, Y0, x_off, y_off, q, stores=stores,
+                                                terms_per_anchor=m)
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
     assert dmax_g == dmax_o
     # every term moves end a by -(qx,qy) and end b by +(qx,qy): the coordinate sums are conserved
@@ -106,11 +123,11 @@ def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ograph
     assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1])) == (int(ck[2]), int(ck[3]))
     assert not np.array_equal(w0, w1)
     # fp32 words: four fp32 atomic adds (or two 8-byte stores) per term
-    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3000, flags=_lib.FLAG_FP32_ATOMICS | sf)
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3001, flags=_lib.FLAG_FP32_ATOMICS | sf, terms_per_anchor=m)
     Xg, Yg = X0.astype(np.float32), Y0.astype(np.float32)
     st = oa.path_linear_sgd_layout_gpu(g, p, Xg, Yg)
-    Xo, Yo, dmax = orc.layout_streams_f32(og, orc.params_from(p), p.seed, 1, X0, Y0, stores=stores)
-    assert st["iterations"] == 6 and st["term_updates"] == 18000 and st["n_streams"] == 1
+    Xo, Yo, dmax = orc.layout_streams_f32(og, orc.params_from(p), p.seed, 1, X0, Y0, stores=stores, terms_per_anchor=m)
+    assert st["iterations"] == 6 and st["term_updates"] == 18006 and st["n_streams"] == 1
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
     assert st["last_delta_max"] == dmax
 
@@ -131,14 +148,15 @@ def test_fixed_point_frame_and_roundtrip(oa, graphs):
     assert np.abs(Y - Y0.astype(np.float32)).max() <= 1.0 / q + np.abs(Y0).max() * 2 ** -23
 
 
-@pytest.mark.parametrize("name,flags", [("DRB1-3123", 0), ("LPA", 0), ("chr6.C4", 0), ("LPA", 2), ("LPA", 4), ("DRB1-3123", 6)])
-def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, flags):
+@pytest.mark.parametrize("name,flags,m", [("DRB1-3123", 0, 1), ("LPA", 0, 1), ("chr6.C4", 0, 1), ("LPA", 2, 1), ("LPA", 4, 1),
+                                          ("DRB1-3123", 6, 1), ("LPA", 0, 4), ("chr6.C4", 0, 4)])
+def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, flags, m):
     """BASELINE configs 1-3 with reference defaults.  The reference itself is Hogwild and not
     reproducible run to run; parity is on layout quality: sampled path stress of the GPU layout
     within 25 % (+0.02 absolute) of the CPU oracle's Hogwild layout from the same initial layout."""
     from odgi_amd import _lib
     g, og = graphs(name), ographs(name)
-    p = _params(oa, g, flags=flags)     # 0 default; 2 fp32 atomics; 4 Hogwild stores; 6 fp32 + stores
+    p = _params(oa, g, flags=flags, terms_per_anchor=m)  # 0 default; 2 fp32 atomics; 4 Hogwild stores; 6 fp32 + stores
     X0, Y0 = oa.initial_layout(g, "d", seed=11)
     X, Y = X0.copy(), Y0.copy()
     st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
@@ -148,7 +166,7 @@ def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, f
     s_gpu = orc.path_stress_sampled(og, X, Y, 1_000_000)
     s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
     s_init = orc.path_stress_sampled(og, X0, Y0, 1_000_000)
-    print(f"{name} flags {flags}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
+    print(f"{name} flags {flags} m {m}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
     assert s_gpu <= 1.25 * s_cpu + 0.02
     d_gpu, d_cpu = orc.path_distance(og, X, Y)[0], orc.path_distance(og, Xo, Yo)[0]
     assert d_gpu <= 1.25 * d_cpu + 0.5          # `odgi stats -s` 2D figure, same tolerance

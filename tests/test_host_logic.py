@@ -178,7 +178,7 @@ def test_c_abi_exports_every_declared_symbol(oa):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 48 and C.sizeof(_lib.Params) == 128
+    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 48 and C.sizeof(_lib.Params) == 136
 
 
 def test_no_cpu_fallback_without_a_device(oa, graphs):
