@@ -1,0 +1,125 @@
+// pgsgd_handlegraph.hpp — the reference-side shim: `path_linear_sgd_layout_gpu` with the reference's
+// own signature (src/algorithms/path_sgd_layout.hpp:59-80), implemented over the C ABI of pgsgd.h.
+//
+// It is what replaces the body of the reference's `path_linear_sgd_layout_gpu`
+// (src/algorithms/path_sgd_layout.cpp:470-503, which fills cuda::layout_config_t and calls
+// cuda::gpu_layout): instead it lowers `graph` into the flat path-step index — the same walk the
+// reference's CUDA host code does (src/cuda/layout.cu:325-410) — and calls pgsgd_layout_run.
+//
+// Header-only and duck-typed: libhandlegraph is not needed to compile it.  `Graph` must offer the
+// PathHandleGraph calls used below; handles must be odgi's packed integers (2*rank + is_reverse,
+// handlegraph::number_bool_packing, pinned in-tree by src/algorithms/layout.cpp:76-79) reachable
+// through an ADL `as_integer(handle)`.  `PathIndex` (xp::XP) is accepted for signature
+// compatibility and not read: like the reference's CUDA route, the GPU path builds its own index.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "pgsgd.h"
+
+namespace pgsgd {
+
+// graph_t + paths -> pgsgd_graph_view (owned arrays)
+struct lowered_graph {
+    std::vector<uint32_t> node_len, step_path, step_handle;
+    std::vector<uint64_t> path_first, step_pos;
+    pgsgd_graph_view view() const {
+        pgsgd_graph_view v;
+        v.n_nodes = node_len.size();
+        v.n_steps = step_handle.size();
+        v.n_paths = path_first.size() - 1;
+        v.node_len = node_len.data();
+        v.path_first = path_first.data();
+        v.step_path = step_path.data();
+        v.step_handle = step_handle.data();
+        v.step_pos = step_pos.data();
+        return v;
+    }
+};
+
+template <class Graph>
+lowered_graph lower_graph(const Graph& graph) {
+    lowered_graph lg;
+    lg.node_len.assign(graph.get_node_count(), 0);
+    graph.for_each_handle([&](const auto& h) {
+        lg.node_len[as_integer(h) >> 1] = (uint32_t)graph.get_length(h);  // src/odgi.cpp:65-71
+    });
+    lg.path_first.push_back(0);
+    graph.for_each_path_handle([&](const auto& path) {  // path ids in creation order (odgi.cpp:261-270)
+        uint64_t pos = 0;
+        const uint32_t pid = (uint32_t)(lg.path_first.size() - 1);
+        graph.for_each_step_in_path(path, [&](const auto& step) {
+            const auto h = graph.get_handle_of_step(step);
+            const uint64_t hi = as_integer(h);
+            lg.step_path.push_back(pid);
+            lg.step_handle.push_back((uint32_t)hi);
+            lg.step_pos.push_back(pos);  // xp.cpp:607-617
+            pos += lg.node_len[hi >> 1];
+        });
+        lg.path_first.push_back(lg.step_handle.size());
+    });
+    return lg;
+}
+
+}  // namespace pgsgd
+
+namespace odgi {
+namespace algorithms {
+
+// Same parameter list as the reference.  X, Y: 2*node_count doubles, pre-initialised, updated in
+// place.  Errors print a message and exit(1), as the reference's GPU route does
+// (src/cuda/layout.cu:6-13,320-323).
+template <class Graph, class PathIndex, class PathHandle>
+void path_linear_sgd_layout_gpu(const Graph& graph, const PathIndex& /*path_index*/,
+                                const std::vector<PathHandle>& /*path_sgd_use_paths*/, const uint64_t& iter_max,
+                                const uint64_t& iter_with_max_learning_rate, const uint64_t& min_term_updates,
+                                const double& delta, const double& eps, const double& eta_max, const double& theta,
+                                const uint64_t& space, const uint64_t& space_max, const uint64_t& space_quantization_step,
+                                const double& cooling_start, const uint64_t& /*nthreads*/, const bool& progress,
+                                const bool& snapshot, const std::string& snapshot_prefix,
+                                std::vector<std::atomic<double>>& X, std::vector<std::atomic<double>>& Y) {
+    const pgsgd::lowered_graph lg = pgsgd::lower_graph(graph);
+    const pgsgd_graph_view view = lg.view();
+    pgsgd_params p;
+    if (pgsgd_params_defaults(&view, &p) != PGSGD_OK) {
+        std::fprintf(stderr, "[odgi::path_linear_sgd_layout_gpu] error: %s\n", pgsgd_last_error());
+        std::exit(1);
+    }
+    p.iter_max = iter_max;
+    p.iter_with_max_learning_rate = iter_with_max_learning_rate;
+    p.min_term_updates = min_term_updates;
+    p.delta = delta;
+    p.eps = eps;
+    p.eta_max = eta_max;
+    p.theta = theta;
+    p.space = space;
+    p.space_max = space_max;
+    p.space_quantization_step = space_quantization_step;
+    p.cooling_start = cooling_start;
+    p.progress = progress ? 1 : 0;
+    p.snapshot = snapshot ? 1 : 0;
+    p.snapshot_prefix = snapshot ? snapshot_prefix.c_str() : nullptr;
+    std::vector<float> xf(X.size()), yf(Y.size());
+    for (size_t i = 0; i < X.size(); ++i) {
+        xf[i] = (float)X[i].load();
+        yf[i] = (float)Y[i].load();
+    }
+    pgsgd_stats st;
+    const int rc = pgsgd_layout_run(&view, &p, xf.data(), yf.data(), &st);
+    if (rc != PGSGD_OK) {
+        std::fprintf(stderr, "[odgi::path_linear_sgd_layout_gpu] error: %s: %s\n", pgsgd_strerror(rc), pgsgd_last_error());
+        std::exit(1);
+    }
+    for (size_t i = 0; i < X.size(); ++i) {
+        X[i].store((double)xf[i]);
+        Y[i].store((double)yf[i]);
+    }
+}
+
+}  // namespace algorithms
+}  // namespace odgi

@@ -297,3 +297,11 @@ def test_synthetic_million_node_properties(oa, orc):
     with oa.LayoutSession(g, p2) as s:
         got = s.trace_terms(True, 4)
     assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p2), p2.seed, 256, 0, True, 4))
+
+
+def test_reference_signature_shim_runs_on_gpu(tmp_path):
+    """The C++ shim with the reference's path_linear_sgd_layout_gpu signature, end to end."""
+    import subprocess
+    from test_host_logic import _build_shim_mock
+    r = subprocess.run([str(_build_shim_mock(tmp_path))], capture_output=True, text=True)
+    assert r.returncode == 0 and "stress" in r.stdout, r.stdout + r.stderr

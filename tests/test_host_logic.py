@@ -217,3 +217,22 @@ def test_cli_argument_handling(oa, tmp_path, capfd):
     if not torch.cuda.is_available():  # a valid command line still ends in a loud device error
         assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "t.lay")]) == 1
         assert "no usable HIP device" in capfd.readouterr().err
+
+
+def _build_shim_mock(tmp_path):
+    import subprocess
+    exe = tmp_path / "shim_mock"
+    libdir = os.path.join(ROOT, "odgi_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_mock.cpp"),
+                           "-o", str(exe), "-L" + libdir, "-lpgsgd", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_reference_signature_shim_compiles_and_lowers(tmp_path):
+    """include/pgsgd_handlegraph.hpp: path_linear_sgd_layout_gpu with the reference's signature over a
+    mock PathHandleGraph; the lowering reproduces pathindex.cpp's step positions (0, 4, 6)."""
+    import subprocess
+    import torch
+    r = subprocess.run([str(_build_shim_mock(tmp_path))], capture_output=True, text=True)
+    assert "pos=0,4,6 handle_last=5" in r.stdout
+    assert r.returncode == (0 if torch.cuda.is_available() else 3), r.stdout + r.stderr

@@ -14,4 +14,4 @@ find "$OUT" -type f | head -50
 find "$OUT" -type f -size +8M -delete
 for f in $(find "$OUT" -name "*stats*.csv" | head -5); do echo "== $f"; head -12 "$f"; done
 for f in $(find "$OUT" -name "*counter_collection*.csv" | head -2); do echo "== $f"; head -5 "$f"; done
-tail -3 "$OUT"/*.err
+for f in "$OUT"/*.err; do tail -n 2 "$f"; done
