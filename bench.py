@@ -52,11 +52,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the layout kernels have no CPU fallback")
+    # one rank per GPU; PGSGD_DIST_BACKEND=gloo lets several ranks share one GPU (used to exercise this
+    # multi-rank path on the single-GPU test box — RCCL refuses two ranks on one device)
+    backend = os.environ.get("PGSGD_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
 
@@ -71,12 +78,9 @@ def main():
     if rank == 0:
         log(f"[bench] graph N={g.n_nodes} S={g.n_steps} P={g.n_paths} terms/iter={p.min_term_updates} "
             f"built in {time.time() - t0:.1f}s")
+    p.stream_offset = rank * (1 << 20)   # disjoint sampler stream ids per rank (a GPU runs < 2^20 streams)
     eng = HipEngine(g, p, X0, Y0)
     p.n_streams = eng.session.n_streams
-    p.stream_offset = rank * p.n_streams
-    if world > 1:  # disjoint sampler streams per rank: recreate the session with this rank's offset
-        eng.close()
-        eng = HipEngine(g, p, X0, Y0)
     drv = DistributedLayout(p, eng)
 
     def fence():
@@ -131,7 +135,8 @@ def main():
     }
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
+    same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0
+    if os.path.exists(prof) and same_workload:
         try:
             with open(prof) as f:
                 pj = json.load(f)
@@ -144,6 +149,8 @@ def main():
         X, Y = eng.result()
         out["stress_sampled"] = oa.path_stress(g, X, Y, 2_000_000)
         out["stress_initial"] = oa.path_stress(g, X0, Y0, 2_000_000)
+    if world > 1:
+        out["config"]["collective_backend"] = backend
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # CPU baseline: the oracle's Hogwild restatement of path_sgd_layout.cpp:165-377 (fp64, 1 ms
