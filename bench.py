@@ -4,10 +4,12 @@
 Workload (BASELINE.json configs[3], the one the HBM-roofline claim is quoted on; it fits one GPU):
 synthetic linearised pangenome, 1,000,000 nodes / 50 haplotype paths / ~4.6e7 path steps, seed 42,
 reference defaults (iter_max 30, 10*S terms per iteration, theta 0.99, cooling from iteration 15).
+The first half of the schedule draws half of the partners uniformly over the path (more far
+partners, slower), the cooling half draws all of them by Zipf; the default window times both.
 A "step" is one SGD iteration (one learning-rate step): 10*S node-pair updates, sharded 1/G per
 GPU, followed by the coordinate-delta all-reduce when G > 1 (strong scaling: total terms fixed).
 
-  python bench.py --gpus 1 --steps 10 --warmup 2
+  python bench.py --gpus 1 --steps 28 --warmup 2        # = the reference's whole 30-iteration schedule
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 Prints ONE JSON line on rank 0.  `roofline` is computed from HIP-event kernel durations measured
@@ -34,13 +36,14 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=28, help="timed iterations (default: with --warmup 2 the whole 30-iteration schedule)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--paths", type=int, default=50)
     ap.add_argument("--streams", type=int, default=0, help="sampler streams per GPU (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stress", action="store_true", help="also report sampled path stress of the final layout")
+    ap.add_argument("--no-tiles", action="store_true", help="force the per-lane kernel (PGSGD_FLAG_NO_TILES)")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,7 +76,9 @@ def main():
     t0 = time.time()
     g = oa.Graph.synthetic(args.nodes, args.paths, seed=42)
     iters = max(30, args.warmup + args.steps)
-    p = oa.LayoutParams.defaults(g, iter_max=iters, n_streams=args.streams, device=local_rank)
+    from odgi_amd import _lib
+    p = oa.LayoutParams.defaults(g, iter_max=iters, n_streams=args.streams, device=local_rank,
+                                 flags=_lib.FLAG_NO_TILES if args.no_tiles else 0)
     X0, Y0 = oa.initial_layout(g, "d", seed=42)
     if rank == 0:
         log(f"[bench] graph N={g.n_nodes} S={g.n_steps} P={g.n_paths} terms/iter={p.min_term_updates} "
@@ -126,16 +131,17 @@ def main():
         "config": {"workload": f"synthetic linearised pangenome N={g.n_nodes} S={g.n_steps} P={g.n_paths} seed 42 "
                                f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
                                f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
-                   "streams_per_gpu": int(p.n_streams),
+                   "streams_per_gpu": int(p.n_streams), "kernel_launches_per_step": launches / args.steps,
                    "parallelism": f"term-sharded x{world}, graph replicated, {drv.blocks} delta all-reduce(s) per eta step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "pgsgd::sgd_iteration_kernel", "avg_kernel_ms": 1e3 * avg_kernel_s,
+                     "kernel": "pgsgd::sgd_tile_kernel" if eng.session.tile_info()["tiled"] else "pgsgd::sgd_iteration_kernel",
+                     "avg_kernel_ms": 1e3 * avg_kernel_s,
                      "terms_per_launch": my_terms, "bytes_per_term": BYTES_PER_TERM},
     }
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0
+    same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
     if os.path.exists(prof) and same_workload:
         try:
             with open(prof) as f:

@@ -69,6 +69,10 @@ typedef struct pgsgd_graph_view {
                                            /* point with one 64-bit integer atomic add per node end  */
 #define PGSGD_FLAG_HOGWILD_STORES     0x4u /* update by load -> store like the reference CPU loop    */
                                            /* (path_sgd_layout.cpp:360-363) instead of atomic adds   */
+#define PGSGD_FLAG_NO_TILES           0x8u /* never use the region-exclusive tile kernel.  By default  */
+                                           /* graphs that suit it (large, sorted, no hub node; default  */
+                                           /* format/update/term stream, automatic stream count) run     */
+                                           /* it: first steps stratified by tile, node windows in LDS   */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -159,6 +163,9 @@ int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
+/* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel */
+int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
+                            uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
 /* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.
  *   mark : remember the current coordinates as the exchange base (call once, after upload);
  *   begin: buf[2e..2e+1] = (dx, dy) node end e moved since the base, in bp; buf[4N+e] = dx^2+dy^2;

@@ -46,6 +46,7 @@ class Stats(C.Structure):
 FLAG_COORD_LOAD_PLAIN = 0x1
 FLAG_FP32_ATOMICS = 0x2
 FLAG_HOGWILD_STORES = 0x4
+FLAG_NO_TILES = 0x8
 DEFAULT_SEED = 9399220
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)
@@ -74,6 +75,7 @@ SIGNATURES = [
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),
     ("pgsgd_session_exchange_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_exchange_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_synthetic", C.c_int, [u64, u64, u64, P(C.c_void_p)]),

@@ -48,6 +48,7 @@ const Opt kOpts[] = {
     {0, "seed", true, "N", "Seed for the initial layout and the sampler streams (default: random initial layout, sampler seed 9399220)."},
     {0, "gpu-streams", true, "N", "Number of concurrent sampler streams on the GPU (default: from graph size)."},
     {0, "device", true, "N", "HIP device ordinal (default: current)."},
+    {0, "gpu-no-tiles", false, "", "Always use the per-lane kernel (one reference worker stream per GPU lane), never the tiled one."},
     {0, "gpu-terms-per-anchor", true, "N", "Partners drawn per sampled first step (default: 1 = the reference's term stream)."},
     {0, "stress", false, "", "Print sampled path stress and the odgi-stats 2D path distance of the result to stderr."},
     {'P', "progress", false, "", "Write the current progress to stderr."},
@@ -264,6 +265,7 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     uint64_t tpa = 1;
     if (a.has("gpu-terms-per-anchor") && !to_u64(a.get("gpu-terms-per-anchor"), &tpa)) return finish(bad("gpu-terms-per-anchor"));
     p.terms_per_anchor = (uint32_t)std::max<uint64_t>(1, tpa);
+    if (a.has("gpu-no-tiles")) p.flags |= PGSGD_FLAG_NO_TILES;
     p.device = -1;
     if (a.has("device")) {
         if (!to_u64(a.get("device"), &device)) return finish(bad("device"));

@@ -59,6 +59,7 @@ struct DevConst {
     uint64_t n_steps;
     uint32_t n_paths;
     uint32_t n_streams;
+    uint32_t n_nodes;
     uint64_t space, space_max, space_quant;
     uint64_t terms_per_anchor;
     ZipfConst zc;
@@ -122,7 +123,13 @@ __device__ __forceinline__ Anchor sample_anchor(const DevConst& c, const PF pf, 
     return a;
 }
 
-__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng) {
+struct GlobalRecs {  // partner records straight from HBM
+    const uint4* recs;
+    __device__ __forceinline__ uint4 operator()(uint64_t k) const { return recs[k]; }
+};
+
+template <class RecFetch>
+__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng, const RecFetch& fetch) {
     Term t;
     uint64_t b_rank;
     if (cooling || coin(rng)) {                                               // :205
@@ -136,7 +143,7 @@ __device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& 
         b_rank = uniform_below(rng, a.cnt);                                   // :235-237
     }
     t.kb = a.pstart + b_rank;
-    const uint4 rb = c.recs[t.kb];
+    const uint4 rb = fetch(t.kb);
     // :242-269 — choose an end of each node; the path position moves to that end.
     // flip(0,1) is the top bit of one draw (uniform_int_distribution never rejects for range 2).
     const uint64_t draw_a = rng.next(), draw_b = rng.next();
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     if (!GROUPED) {
         for (uint64_t ti = g; ti < a.n_terms; ti += L) {
             const Anchor an = sample_anchor(c, pf, rng);
-            const Term t = sample_partner(c, an, a.cooling, rng);
+            const Term t = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
             uint64_t wa, wb;
             if (ABL == 3 || ABL == 4) {
                 wa = (uint64_t)t.end_a * 0x100000001ull;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
         float dfx0 = 0.0f, dfy0 = 0.0f, dfx1 = 0.0f, dfy1 = 0.0f;
         uint32_t have = 0, touched = 0;
         for (uint32_t r = 0; r < mt; ++r) {
-            const Term t = sample_partner(c, an, a.cooling, rng);
+            const Term t = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
             const uint32_t ea = t.end_a & 1u, bit = 1u << ea;
             if (!(have & bit)) {
                 const uint64_t w = (ABL == 3 || ABL == 4) ? (uint64_t)t.end_a * 0x100000001ull : load_word<COORD_LOAD>(c.coords, t.end_a);
@@ -390,6 +397,158 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Region-exclusive tiles — the kernel large sorted graphs run by default (PGSGD_FLAG_NO_TILES turns
+// it off): the same terms, but grouped so that most memory requests never leave the CU.
+//
+// The default kernel pays ~6 scattered memory requests per term (2 record gathers, 2 coordinate
+// loads, 2 atomics) and the memory system retires ~55 G of them per second; nothing else limits
+// it.  Here the steps of every path are cut into tiles of T consecutive steps and node ranks into
+// regions of R nodes.  A work item is one region r0 with every tile whose nodes fall inside the
+// window [r0*R, (r0+2)*R) (the input of `odgi layout` is a sorted graph, so a run of path steps
+// visits a run of node ranks).  A workgroup that takes a work item
+//   * stages the window's 4R coordinate words in LDS (plus a copy of what it staged),
+//   * runs each of its tiles: the tile's records go to LDS; every term draws its first step
+//     uniformly inside the tile (each tile gets its exact share of the iteration's terms, so the
+//     first step is uniform over all steps, as in the reference) and its partner by the
+//     reference's rule; ends inside the window are read from LDS and moved with LDS atomics,
+//     only ends outside it touch global memory (record gather, agent-scope load, atomic add),
+//   * adds (staged now - staged then) back to global memory, one atomic per word that moved.
+// Windows of regions of one parity are disjoint, so one launch per parity gives every window a
+// single owner: no two private copies of a node end exist at the same time, which is what makes
+// private copies safe (summing the moves of several stale copies of one end overshoots — the
+// failure mode of a plain-sum multi-GPU merge, reproduced for tiles in tools/tile_sim.c).
+// Tiles that do not fit a window (unsorted stretches) run with every end in global memory.
+struct Tile {
+    uint64_t t0;   // first flat step
+    uint64_t cum;  // steps of all tiles before this one, in tile order (for the term partition)
+    uint32_t n;    // steps in the tile
+    uint32_t path;
+};
+struct WorkItem {
+    uint32_t tile_begin, tile_end;
+    uint32_t win0;   // first node rank of the window
+    uint32_t local;  // 1 = window staged in LDS, 0 = every end in global memory
+};
+struct TileArgs {
+    const Tile* tiles;
+    const WorkItem* items;
+    uint32_t* queue;      // work-item counter of this launch
+    uint32_t n_items;
+    uint32_t region;      // R
+    uint32_t tile_steps;  // T
+    uint64_t steps_total; // steps covered by tiles (paths of one step have none)
+    uint32_t sub, n_sub;  // this launch applies part `sub` of `n_sub` of every tile's terms
+};
+
+constexpr int kTileBlock = 256;
+
+struct TileRecs {  // partner records from the tile staged in LDS when they are in it
+    const uint4* lds;
+    const uint4* recs;
+    uint64_t t0;
+    uint32_t n;
+    __device__ __forceinline__ uint4 operator()(uint64_t k) const { return (k - t0 < (uint64_t)n) ? lds[k - t0] : recs[k]; }
+};
+
+__device__ __forceinline__ uint64_t mul_div(uint64_t a, uint64_t b, uint64_t c) {
+    return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) / (unsigned __int128)c);
+}
+
+template <int COORD_LOAD>
+__global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileArgs ta, IterArgs a) {
+    extern __shared__ uint64_t lds[];
+    uint64_t* win = lds;                                   // [4R] window words
+    uint64_t* orig = lds + 4 * (size_t)ta.region;          // [4R] as staged
+    uint4* trec = reinterpret_cast<uint4*>(lds + 8 * (size_t)ta.region);  // [T] tile records
+    __shared__ uint32_t s_item;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    float dmax = 0.0f;
+    const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
+    const uint32_t win_words = 4 * ta.region;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ta.queue, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= ta.n_items) break;
+        const WorkItem wi = ta.items[item];
+        const uint64_t wbase = 2 * (uint64_t)wi.win0;  // first coordinate word of the window
+        if (wi.local) {
+            for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x) {
+                const uint64_t w = wbase + i < n_ends ? load_word<COORD_LOAD>(c.coords, (uint32_t)(wbase + i)) : 0;
+                win[i] = w;
+                orig[i] = w;
+            }
+        }
+        for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
+            const Tile t = ta.tiles[ti];
+            __syncthreads();  // previous tile's terms are done with trec; window staging is complete
+            for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = c.recs[t.t0 + i];
+            __syncthreads();
+            const uint64_t tile_begin = mul_div(t.cum, a.n_terms, ta.steps_total);
+            const uint64_t tile_terms = mul_div(t.cum + t.n, a.n_terms, ta.steps_total) - tile_begin;
+            const uint64_t term_begin = tile_begin + tile_terms * ta.sub / ta.n_sub;
+            const uint64_t term_end = tile_begin + tile_terms * (ta.sub + 1) / ta.n_sub;
+            const uint64_t pstart = c.path_first[t.path];
+            const uint64_t cnt = c.path_first[t.path + 1] - pstart;
+            for (uint64_t q = term_begin + threadIdx.x; q < term_end; q += blockDim.x) {
+                // first step: uniform inside the tile; partner: the shared sampler (path_sgd_layout.cpp:205-270)
+                Anchor an;
+                an.k = t.t0 + uniform_below(rng, t.n);
+                an.pstart = pstart;
+                an.cnt = cnt;
+                an.s_rank = an.k - pstart;
+                an.rec = trec[an.k - t.t0];
+                const Term tm = sample_partner(c, an, a.cooling, rng, TileRecs{trec, c.recs, t.t0, t.n});
+                const uint32_t end_a = tm.end_a, end_b = tm.end_b, dither = tm.dither;
+                const uint64_t pos_a = tm.pos_a, pos_b = tm.pos_b;
+                // ends inside the staged window live in LDS (unsigned compare covers "below the window")
+                const uint32_t la = end_a - (uint32_t)wbase, lb = end_b - (uint32_t)wbase;
+                const bool in_a = wi.local && la < win_words, in_b = wi.local && lb < win_words;
+                const uint64_t wa = in_a ? win[la] : load_word<COORD_LOAD>(c.coords, end_a);
+                const uint64_t wb = in_b ? win[lb] : load_word<COORD_LOAD>(c.coords, end_b);
+                const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+                const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+                float r_x, r_y, abs_delta;
+                term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta);
+                dmax = fmaxf(dmax, abs_delta);
+                const float ux = (float)(dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                const unsigned long long delta = (unsigned long long)((uint64_t)qx + ((uint64_t)qy << 32));
+                if (in_b) atomicAdd(reinterpret_cast<unsigned long long*>(win + lb), delta);
+                else atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_b), delta);
+                if (in_a) atomicAdd(reinterpret_cast<unsigned long long*>(win + la), 0ull - delta);
+                else atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_a), 0ull - delta);
+            }
+        }
+        __syncthreads();
+        if (wi.local) {  // what this workgroup moved, added to whatever others added meanwhile
+            for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x) {
+                const uint64_t d = win[i] - orig[i];
+                if (d != 0 && wbase + i < n_ends) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + wbase + i), (unsigned long long)d);
+            }
+        }
+        __syncthreads();  // s_item and the window are reused
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
 // sampler-only launch for parity checks: fresh streams, nothing is modified
 template <bool PF_LDS>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cooling, uint64_t seed_base,
@@ -407,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cool
     Anchor an{};
     for (uint64_t j = 0; j < terms_per_stream; ++j) {
         if (j % c.terms_per_anchor == 0) an = sample_anchor(c, pf, rng);
-        const Term t = sample_partner(c, an, cooling, rng);
+        const Term t = sample_partner(c, an, cooling, rng, GlobalRecs{c.recs});
         uint64_t* o = out + (j * (uint64_t)c.n_streams + g) * 4;
         o[0] = an.k;
         o[1] = t.kb;
@@ -561,6 +720,17 @@ struct pgsgd_session {
     unsigned int* d_delta_max = nullptr;
     unsigned int* h_delta_max = nullptr;  // pinned
     pgsgd::DevConst dc{};
+    // region-exclusive tiles
+    bool tiled = false;
+    uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
+    pgsgd::Tile* d_tiles = nullptr;
+    pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
+    uint32_t n_items[2] = {0, 0};
+    uint32_t* d_queue = nullptr;          // [2] work-item counters
+    uint64_t tile_steps_total = 0;
+    uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
+    size_t tile_lds = 0;
+    uint32_t tile_grid = 0;
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
     double kernel_ms = 0;
@@ -637,6 +807,96 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
     return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, grouped, abl);
 }
 
+// Host side of the tiled kernel: cut paths into tiles, bind tiles to region windows, order the work.
+struct HostTiles {
+    std::vector<pgsgd::Tile> tiles;
+    std::vector<pgsgd::WorkItem> items[2];
+    uint64_t steps_total = 0, n_nonlocal = 0;
+};
+
+static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
+    struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax; };
+    std::vector<Raw> raw;
+    for (uint64_t p = 0; p < g->n_paths; ++p) {
+        const uint64_t b = g->path_first[p], cnt = g->path_first[p + 1] - b;
+        if (cnt <= 1) continue;  // single-step paths are never sampled (path_sgd_layout.cpp:189-192)
+        for (uint64_t o = 0; o < cnt; o += T) {
+            Raw r;
+            r.t0 = b + o;
+            r.n = (uint32_t)std::min<uint64_t>(T, cnt - o);
+            r.path = (uint32_t)p;
+            r.rmin = UINT32_MAX;
+            r.rmax = 0;
+            for (uint64_t k = r.t0; k < r.t0 + r.n; ++k) {
+                const uint32_t rank = g->step_handle[k] >> 1;
+                r.rmin = std::min(r.rmin, rank);
+                r.rmax = std::max(r.rmax, rank);
+            }
+            raw.push_back(r);
+        }
+    }
+    // local tiles grouped by (colour, region of rmin); a tile that does not fit two regions is its own global item
+    struct Group { uint32_t r0; uint64_t steps; std::vector<uint32_t> members; };
+    std::vector<Group> groups[2];
+    std::vector<uint32_t> nonlocal;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> key;  // (r0, raw index)
+        for (uint32_t i = 0; i < raw.size(); ++i) {
+            const uint32_t r0 = raw[i].rmin / R;
+            if ((uint64_t)raw[i].rmax < ((uint64_t)r0 + 2) * R) key.emplace_back(r0, i);
+            else nonlocal.push_back(i);
+        }
+        std::sort(key.begin(), key.end());
+        for (size_t i = 0; i < key.size();) {
+            Group gr;
+            gr.r0 = key[i].first;
+            gr.steps = 0;
+            size_t j = i;
+            for (; j < key.size() && key[j].first == gr.r0; ++j) {
+                gr.members.push_back(key[j].second);
+                gr.steps += raw[key[j].second].n;
+            }
+            groups[gr.r0 & 1u].push_back(std::move(gr));
+            i = j;
+        }
+    }
+    HostTiles ht;
+    ht.n_nonlocal = nonlocal.size();
+    auto emit_tile = [&](uint32_t i) {
+        pgsgd::Tile t;
+        t.t0 = raw[i].t0;
+        t.cum = ht.steps_total;
+        t.n = raw[i].n;
+        t.path = raw[i].path;
+        ht.steps_total += raw[i].n;
+        ht.tiles.push_back(t);
+    };
+    for (int colour = 0; colour < 2; ++colour) {
+        // big work items first: the persistent workgroups pull from a queue
+        std::sort(groups[colour].begin(), groups[colour].end(), [](const Group& a, const Group& b) { return a.steps > b.steps; });
+        for (const Group& gr : groups[colour]) {
+            pgsgd::WorkItem wi;
+            wi.tile_begin = (uint32_t)ht.tiles.size();
+            for (uint32_t i : gr.members) emit_tile(i);
+            wi.tile_end = (uint32_t)ht.tiles.size();
+            wi.win0 = gr.r0 * R;
+            wi.local = 1;
+            ht.items[colour].push_back(wi);
+        }
+        if (colour == 0)
+            for (uint32_t i : nonlocal) {
+                pgsgd::WorkItem wi;
+                wi.tile_begin = (uint32_t)ht.tiles.size();
+                emit_tile(i);
+                wi.tile_end = (uint32_t)ht.tiles.size();
+                wi.win0 = 0;
+                wi.local = 0;
+                ht.items[0].push_back(wi);
+            }
+    }
+    return ht;
+}
+
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
     pgsgd::clear_error();
     if (!out || !p) return PGSGD_E_INVALID;
@@ -707,6 +967,52 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = auto_streams(s, prop.multiProcessorCount, bpc);
     }
 
+    // region-exclusive tiles: with the default coordinate format, update mode and term stream, an
+    // automatic stream count, and a graph that is big enough and whose hottest node does not ask for
+    // fewer lanes than the GPU holds; everything else runs the per-lane kernel
+    if (!(p->flags & (PGSGD_FLAG_NO_TILES | PGSGD_FLAG_COORD_LOAD_PLAIN | PGSGD_FLAG_ABLATE(15))) && s->fmt == pgsgd::kFmtQ32 &&
+        s->upd == pgsgd::kUpdAtomic && !p->n_streams && p->terms_per_anchor <= 1) {
+        if (const char* e = getenv("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
+            const long r = atol(e);
+            if (r >= 32 && r <= 2048 && (r & (r - 1)) == 0) {
+                s->region = (uint32_t)r;
+                s->tile_steps = (uint32_t)(r - r / 8);
+            }
+        }
+        if (const char* e = getenv("PGSGD_TILE_SUBSTEPS")) {  // experiment knob: window refreshes per iteration
+            const long k = atol(e);
+            if (k >= 1 && k <= 64) s->tile_substeps = (uint32_t)k;
+        }
+        if (const char* e = getenv("PGSGD_TILE_BLOCK")) {  // experiment knob: lanes per workgroup
+            const long b = atol(e);
+            if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
+        }
+        const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
+        s->tile_lds = (size_t)8 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
+        int bpc = 0;
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_tile_kernel<1>, (int)s->tile_block, s->tile_lds));
+        if (bpc < 1) bpc = 1;
+        const uint64_t lanes = (uint64_t)prop.multiProcessorCount * bpc * s->tile_block;
+        if (cap >= lanes && g->n_nodes >= 8ull * s->region) {
+            HostTiles ht = build_tiles(g, s->region, s->tile_steps);
+            s->tiled = true;
+            s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
+            s->n_streams = s->tile_grid * s->tile_block;
+            s->tile_steps_total = ht.steps_total;
+            s->n_tiles = ht.tiles.size();
+            s->n_nonlocal_tiles = ht.n_nonlocal;
+            s->n_items[0] = (uint32_t)ht.items[0].size();
+            s->n_items[1] = (uint32_t)ht.items[1].size();
+            std::vector<pgsgd::WorkItem> all(ht.items[0]);
+            all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
+            S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
+            S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
+            S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
+            S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
+            S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
+        }
+    }
+
     // step records: upload the SoA arrays, pack on the device, drop the staging copies
     {
         uint32_t *d_handle = nullptr, *d_len = nullptr;
@@ -760,6 +1066,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.n_steps = g->n_steps;
     c.n_paths = (uint32_t)g->n_paths;
     c.n_streams = s->n_streams;
+    c.n_nodes = (uint32_t)g->n_nodes;
     c.space = p->space;
     c.space_max = p->space_max;
     c.space_quant = p->space_quantization_step;
@@ -785,6 +1092,9 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_rng) (void)hipFree(s->d_rng);
     if (s->d_delta_max) (void)hipFree(s->d_delta_max);
+    if (s->d_tiles) (void)hipFree(s->d_tiles);
+    if (s->d_items) (void)hipFree(s->d_items);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -892,6 +1202,17 @@ extern "C" int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream) {
 
 extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return s ? s->n_streams : 0; }
 
+extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles, uint64_t* n_work_items,
+                                       uint32_t* region_nodes, uint32_t* tile_steps) {
+    if (!s) return PGSGD_E_INVALID;
+    if (n_tiles) *n_tiles = s->tiled ? s->n_tiles : 0;
+    if (n_nonlocal_tiles) *n_nonlocal_tiles = s->n_nonlocal_tiles;
+    if (n_work_items) *n_work_items = (uint64_t)s->n_items[0] + s->n_items[1];
+    if (region_nodes) *region_nodes = s->region;
+    if (tile_steps) *tile_steps = s->tile_steps;
+    return s->tiled ? 1 : 0;
+}
+
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
     pgsgd::clear_error();
     if (!s) return PGSGD_E_INVALID;
@@ -900,6 +1221,43 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
         HIP_TRY(hipStreamSynchronize(s->stream));
         int rc = collect_events(s);
         if (rc) return rc;
+    }
+    if (s->tiled) {
+        pgsgd::IterArgs a;
+        a.n_terms = n_terms;
+        a.eta = (float)eta;
+        a.cooling = cooling ? 1u : 0u;
+        HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
+        for (uint32_t sub = 0; sub < s->tile_substeps; ++sub)
+        for (int colour = 0; colour < 2; ++colour) {
+            if (!s->n_items[colour]) continue;
+            HIP_TRY(hipMemsetAsync(s->d_queue + colour, 0, sizeof(uint32_t), s->stream));
+            std::pair<hipEvent_t, hipEvent_t> ev;
+            if (!s->free_events.empty()) {
+                ev = s->free_events.back();
+                s->free_events.pop_back();
+            } else {
+                HIP_TRY(hipEventCreate(&ev.first));
+                HIP_TRY(hipEventCreate(&ev.second));
+            }
+            pgsgd::TileArgs ta;
+            ta.tiles = s->d_tiles;
+            ta.items = s->d_items + (colour ? s->n_items[0] : 0);
+            ta.queue = s->d_queue + colour;
+            ta.n_items = s->n_items[colour];
+            ta.region = s->region;
+            ta.tile_steps = s->tile_steps;
+            ta.steps_total = s->tile_steps_total;
+            ta.sub = sub;
+            ta.n_sub = s->tile_substeps;
+            HIP_TRY(hipEventRecord(ev.first, s->stream));
+            hipLaunchKernelGGL(pgsgd::sgd_tile_kernel<1>, dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev.second, s->stream));
+            s->pending_events.push_back(ev);
+        }
+        HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        return PGSGD_OK;
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
     const uint32_t abl = (s->params.flags >> 8) & 0xfu;

@@ -163,6 +163,12 @@ class LayoutSession:
         check(lib.pgsgd_session_download_words(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "download_words")
         return w
 
+    def tile_info(self):
+        """dict(tiled, n_tiles, n_nonlocal_tiles, n_work_items, region_nodes, tile_steps) of the session (tiled=False: per-lane kernel)."""
+        a, b, c_, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
+        return dict(tiled=bool(on), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
+
     def coord_format(self):
         """(fixed_point, x_off, y_off, quanta_per_bp) of the device coordinate words."""
         fp, xo, yo, q = C.c_int(), C.c_double(), C.c_double(), C.c_double()

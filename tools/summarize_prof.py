@@ -26,7 +26,8 @@ with open(os.path.join(dst, f"rocprof_kernel_stats_{tag}.csv"), "w", newline="")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
     w.writerows(rows)
-disp = q("kt", "select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count from kernels where name like '%sgd_iteration_kernel%'")
+disp = q("kt", "select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count from kernels "
+               "where name like '%sgd_iteration_kernel%' or name like '%sgd_tile_kernel%'")
 counters = {}
 for db, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for name, val, dur in q(db, f"select kernel_name, value, duration from counters_collection where counter_name='{cname}'"):
@@ -37,7 +38,7 @@ with open(os.path.join(dst, f"rocprof_pmc_{tag}.csv"), "w", newline="") as f:
     for name, cs in counters.items():
         for cname, vals in cs.items():
             w.writerow([name, cname, len(vals), sum(v for v, _ in vals) / len(vals), sum(d for _, d in vals) / len(vals)])
-sgd = [k for k in counters if "sgd_iteration_kernel" in k]
+sgd = [k for k in counters if "sgd_iteration_kernel" in k or "sgd_tile_kernel" in k]
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --steps 5 --warmup 1` ({tag}); "
                  "profiles/" + os.path.basename(dst) + f"/rocprof_pmc_{tag}.csv"}
 if sgd:
