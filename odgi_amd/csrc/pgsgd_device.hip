@@ -424,6 +424,8 @@ struct Tile {
     uint64_t cum;  // steps of all tiles before this one, in tile order (for the term partition)
     uint32_t n;    // steps in the tile
     uint32_t path;
+    uint32_t lanes;  // lanes that may work on the tile at once: 2*n / (most visits of one node inside the tile),
+    uint32_t pad;    // the per-lane kernel's hot-node rule applied to the tile (tandem repeats, tiny tail tiles)
 };
 struct WorkItem {
     uint32_t tile_begin, tile_end;
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             const uint64_t term_end = tile_begin + tile_terms * (ta.sub + 1) / ta.n_sub;
             const uint64_t pstart = c.path_first[t.path];
             const uint64_t cnt = c.path_first[t.path + 1] - pstart;
-            for (uint64_t q = term_begin + threadIdx.x; q < term_end; q += blockDim.x) {
+            const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
+            for (uint64_t q = term_begin + threadIdx.x; threadIdx.x < lanes && q < term_end; q += lanes) {
                 // first step: uniform inside the tile; partner: the shared sampler (path_sgd_layout.cpp:205-270)
                 Anchor an;
                 an.k = t.t0 + uniform_below(rng, t.n);
@@ -815,8 +818,9 @@ struct HostTiles {
 };
 
 static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
-    struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax; };
+    struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
     std::vector<Raw> raw;
+    std::vector<uint32_t> ranks;
     for (uint64_t p = 0; p < g->n_paths; ++p) {
         const uint64_t b = g->path_first[p], cnt = g->path_first[p + 1] - b;
         if (cnt <= 1) continue;  // single-step paths are never sampled (path_sgd_layout.cpp:189-192)
@@ -827,10 +831,18 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
             r.path = (uint32_t)p;
             r.rmin = UINT32_MAX;
             r.rmax = 0;
+            ranks.clear();
             for (uint64_t k = r.t0; k < r.t0 + r.n; ++k) {
                 const uint32_t rank = g->step_handle[k] >> 1;
                 r.rmin = std::min(r.rmin, rank);
                 r.rmax = std::max(r.rmax, rank);
+                ranks.push_back(rank);
+            }
+            std::sort(ranks.begin(), ranks.end());
+            r.maxmult = 1;
+            for (size_t i = 0, j = 0; i < ranks.size(); i = j) {
+                while (j < ranks.size() && ranks[j] == ranks[i]) ++j;
+                r.maxmult = std::max<uint32_t>(r.maxmult, (uint32_t)(j - i));
             }
             raw.push_back(r);
         }
@@ -868,6 +880,8 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
         t.cum = ht.steps_total;
         t.n = raw[i].n;
         t.path = raw[i].path;
+        t.lanes = std::max<uint32_t>(1, 2 * raw[i].n / raw[i].maxmult);
+        t.pad = 0;
         ht.steps_total += raw[i].n;
         ht.tiles.push_back(t);
     };

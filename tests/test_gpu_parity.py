@@ -376,3 +376,42 @@ def test_small_and_hub_graphs_run_the_per_lane_kernel(oa, graphs):
         g = graphs(name)
         with oa.LayoutSession(g, _params(oa, g)) as s:
             assert not s.tile_info()["tiled"]
+
+
+def test_tiled_kernel_with_tandem_repeats(oa):
+    """Paths that loop through the same few nodes many times (tandem repeats): a tile then holds far
+    fewer distinct nodes than steps, and the per-tile lane cap keeps concurrent updates of one node end
+    bounded.  Tiled and per-lane layouts must both stay finite, conserve the coordinate sums and agree."""
+    from odgi_amd import _lib
+    g = oa.Graph.synthetic(300_000, 24, seed=9)
+    pf = g.path_first.astype(np.int64)
+    rs = np.random.RandomState(3)
+    new_handles, new_first = [], [0]
+    for p in range(g.n_paths):
+        h = g.step_handle[pf[p]:pf[p + 1]]
+        if p < 2:  # splice 40 tandem repeats (6 nodes x 10 copies) into the first two paths: the busiest node is
+            # visited 10 + 23 times, few enough for the tile kernel to be chosen, while the tiles that
+            # hold a repeat see one node up to 10 times
+            cuts = np.sort(rs.choice(len(h) - 100, 40, replace=False))
+            parts, last = [], 0
+            for c in cuts:
+                parts.append(h[last:c])
+                parts.append(np.tile(h[c:c + 6], 10))
+                last = c
+            parts.append(h[last:])
+            h = np.concatenate(parts)
+        new_handles.append(h)
+        new_first.append(new_first[-1] + len(h))
+    g2 = oa.Graph.from_arrays(g.node_len, np.array(new_first, dtype=np.uint64), np.concatenate(new_handles))
+    X0, Y0 = oa.initial_layout(g2, "d", seed=9)
+    res = {}
+    for name, flags in (("tiled", 0), ("per_lane", _lib.FLAG_NO_TILES)):
+        p = _params(oa, g2, flags=flags, min_term_updates=3 * g2.n_steps)
+        X, Y, dmax, fmt, w0, w1 = _run_session(oa, g2, p, X0, Y0)
+        assert _words_conserved(w0, w1) and np.isfinite(X).all() and np.isfinite(Y).all()
+        res[name] = oa.path_stress(g2, X, Y, 1_000_000, seed=1)
+    with oa.LayoutSession(g2, _params(oa, g2)) as s:
+        info = s.tile_info()
+    print(f"tandem repeats: tiled={info['tiled']} stress tiled {res['tiled']:.4f} per-lane {res['per_lane']:.4f}")
+    assert info["tiled"]
+    assert res["tiled"] <= 1.3 * res["per_lane"] + 0.05
