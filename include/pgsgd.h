@@ -158,11 +158,19 @@ void* pgsgd_session_stream(pgsgd_session* s);
 int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream);
 /* Asynchronously run `n_terms` terms with learning rate eta (cooling: 0/1) on the session stream. */
 int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms);
+/* Part `part` of `n_parts` of such an iteration (multi-GPU: one part per exchange).  The per-lane kernel runs
+ * the part-th slice of the n_terms terms; the tile kernel runs every n_parts-th tile with its whole share. */
+int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint64_t n_terms, uint32_t part, uint32_t n_parts);
 /* Wait for the stream; returns max |Delta| of the last iteration in *delta_max (may be NULL). */
 int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
+/* Multi-GPU sharding of the tile kernel: this device processes work items (node regions with all
+ * their tiles) rank, rank+world, ... and every iteration call takes the FULL term count of the
+ * block, of which only the owned tiles' share is applied.  Returns 1 when the session is tiled (the
+ * shard is in effect), 0 when it runs the per-lane kernel (shard the term count instead), < 0 on error. */
+int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world);
 /* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);

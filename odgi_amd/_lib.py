@@ -69,12 +69,14 @@ SIGNATURES = [
     ("pgsgd_session_stream", C.c_void_p, [C.c_void_p]),
     ("pgsgd_session_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_iteration", C.c_int, [C.c_void_p, f64, C.c_int, u64]),
+    ("pgsgd_session_iteration_part", C.c_int, [C.c_void_p, f64, C.c_int, u64, u32, u32]),
     ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),
     ("pgsgd_session_exchange_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_exchange_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("pgsgd_session_set_shard", C.c_int, [C.c_void_p, u32, u32]),
     ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),

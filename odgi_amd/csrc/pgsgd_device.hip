@@ -440,7 +440,8 @@ struct TileArgs {
     uint32_t region;      // R
     uint32_t tile_steps;  // T
     uint64_t steps_total; // steps covered by tiles (paths of one step have none)
-    uint32_t sub, n_sub;  // this launch applies part `sub` of `n_sub` of every tile's terms
+    uint32_t sub, n_sub;  // this launch runs the tiles with index = sub (mod n_sub), each with its whole share
+    uint32_t shard_rank, shard_world;  // multi-GPU: this device owns work items rank, rank+world, ...
 };
 
 constexpr int kTileBlock = 256;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ta.queue, 1u);
         __syncthreads();
-        const uint32_t item = s_item;
+        const uint32_t item = s_item * ta.shard_world + ta.shard_rank;
         if (item >= ta.n_items) break;
         const WorkItem wi = ta.items[item];
         const uint64_t wbase = 2 * (uint64_t)wi.win0;  // first coordinate word of the window
@@ -489,14 +490,13 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             }
         }
         for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
+            if (ti % ta.n_sub != ta.sub) continue;  // block-uniform
             const Tile t = ta.tiles[ti];
             __syncthreads();  // previous tile's terms are done with trec; window staging is complete
             for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = c.recs[t.t0 + i];
             __syncthreads();
-            const uint64_t tile_begin = mul_div(t.cum, a.n_terms, ta.steps_total);
-            const uint64_t tile_terms = mul_div(t.cum + t.n, a.n_terms, ta.steps_total) - tile_begin;
-            const uint64_t term_begin = tile_begin + tile_terms * ta.sub / ta.n_sub;
-            const uint64_t term_end = tile_begin + tile_terms * (ta.sub + 1) / ta.n_sub;
+            const uint64_t term_begin = mul_div(t.cum, a.n_terms, ta.steps_total);
+            const uint64_t term_end = mul_div(t.cum + t.n, a.n_terms, ta.steps_total);
             const uint64_t pstart = c.path_first[t.path];
             const uint64_t cnt = c.path_first[t.path + 1] - pstart;
             const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
@@ -726,6 +726,7 @@ struct pgsgd_session {
     // region-exclusive tiles
     bool tiled = false;
     uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
+    uint32_t shard_rank = 0, shard_world = 1;
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
@@ -1216,6 +1217,14 @@ extern "C" int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream) {
 
 extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return s ? s->n_streams : 0; }
 
+extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world) {
+    pgsgd::clear_error();
+    if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
+    s->shard_rank = rank;
+    s->shard_world = world;
+    return s->tiled ? 1 : 0;
+}
+
 extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles, uint64_t* n_work_items,
                                        uint32_t* region_nodes, uint32_t* tile_steps) {
     if (!s) return PGSGD_E_INVALID;
@@ -1228,8 +1237,19 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
 }
 
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
+    return pgsgd_session_iteration_part(s, eta, cooling, n_terms, 0, 1);
+}
+
+// Part `part` of `n_parts` of an iteration of n_terms terms: the per-lane kernel runs the part-th slice
+// of the terms; the tile kernel runs the tiles with index = part (mod n_parts) with their whole share
+// (visiting every tile once per iteration keeps the cost of an iteration independent of n_parts).
+extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint64_t n_terms, uint32_t part, uint32_t n_parts) {
     pgsgd::clear_error();
-    if (!s) return PGSGD_E_INVALID;
+    if (!s || n_parts == 0 || part >= n_parts) return PGSGD_E_INVALID;
+    if (!s->tiled && n_parts > 1) {
+        const uint64_t base = n_terms / n_parts, rem = n_terms % n_parts;
+        n_terms = base + (part < rem ? 1 : 0);
+    }
     HIP_TRY(hipSetDevice(s->device));
     if (s->pending_events.size() >= 64) {  // bound the event pool
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1242,7 +1262,8 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
         a.eta = (float)eta;
         a.cooling = cooling ? 1u : 0u;
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
-        for (uint32_t sub = 0; sub < s->tile_substeps; ++sub)
+        const uint32_t n_sub = n_parts * s->tile_substeps;
+        for (uint32_t sub = part * s->tile_substeps; sub < (part + 1) * s->tile_substeps; ++sub)
         for (int colour = 0; colour < 2; ++colour) {
             if (!s->n_items[colour]) continue;
             HIP_TRY(hipMemsetAsync(s->d_queue + colour, 0, sizeof(uint32_t), s->stream));
@@ -1263,7 +1284,9 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
             ta.tile_steps = s->tile_steps;
             ta.steps_total = s->tile_steps_total;
             ta.sub = sub;
-            ta.n_sub = s->tile_substeps;
+            ta.n_sub = n_sub;
+            ta.shard_rank = s->shard_rank;
+            ta.shard_world = s->shard_world;
             HIP_TRY(hipEventRecord(ev.first, s->stream));
             hipLaunchKernelGGL(pgsgd::sgd_tile_kernel<1>, dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
             HIP_TRY(hipGetLastError());

@@ -2,9 +2,10 @@
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  Every rank holds the
 whole lowered graph and a full copy of the coordinates.  In each iteration (learning-rate step)
-rank r applies its 1/G share of the iteration's terms with its own sampler streams (stream ids
-r*L .. r*L+L-1, disjoint across ranks), in `exchanges_per_iteration` blocks; after each block the
-ranks exchange what they changed since the previous exchange:
+rank r applies 1/G of the iteration's terms with its own sampler streams (disjoint stream ids across
+ranks), in `exchanges_per_iteration` parts (per-lane kernel: slices of the terms; tile kernel: every
+B-th tile with its whole share).  After each part the ranks exchange what they changed since the
+previous exchange:
 
     begin : buf[0..4N) = coords - base ; buf[4N..6N) = |delta of each node end|^2      (HIP kernel)
     all-reduce(SUM) of the one fused 6N-float buffer over the G ranks                    (RCCL)
@@ -49,6 +50,7 @@ class HipEngine:
         self.session.upload(X, Y)
         self.session.use_torch_stream()
         self.n_nodes = graph.n_nodes
+        self.tiled = bool(self.session.tile_info()["tiled"])
         self.device = torch.device("cuda", torch.cuda.current_device() if params.device < 0 else params.device)
 
     def new_exchange_buffer(self):
@@ -57,8 +59,19 @@ class HipEngine:
     def iteration(self, eta, cooling, n_terms):
         self.session.iteration(eta, cooling, n_terms)
 
+    def iteration_part(self, eta, cooling, n_terms, part, n_parts):
+        self.session.iteration_part(eta, cooling, n_terms, part, n_parts)
+
     def sync(self):
         return self.session.sync()
+
+    def set_shard(self, rank, world):
+        """True when the engine shards by node region (tile kernel): iteration() then takes the full
+        term count of a block; False when the caller must shard the term count (per-lane kernel)."""
+        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world))
+        if rc < 0:
+            check(rc, "set_shard")
+        return rc == 1
 
     def exchange_mark(self):
         check(lib.pgsgd_session_exchange_mark(self.session._h), "exchange_mark")
@@ -79,7 +92,7 @@ class HipEngine:
 class DistributedLayout:
     """Drives one engine per rank through the schedule with the exchange between blocks."""
 
-    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None):
+    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None, region_shard=False):
         self.params = params
         self.engine = engine
         self.group = group
@@ -87,27 +100,46 @@ class DistributedLayout:
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
         if exchanges_per_iteration is None:
-            exchanges_per_iteration = 1 if self.world == 1 else 4
+            # measured with G virtual ranks on one MI355X (profiles/r01/virtual_ranks_*.jsonl): the per-lane
+            # kernel (small graphs) needs 4 exchanges per iteration to keep G = 1 quality, the tile kernel is
+            # insensitive between 1 and 4 and pays ~5 % of kernel time per extra exchange at G = 8
+            exchanges_per_iteration = 1 if self.world == 1 else (2 if getattr(engine, "tiled", False) else 4)
         self.blocks = max(1, int(exchanges_per_iteration)) if self.world > 1 else 1
         self.etas = path_linear_sgd_layout_schedule(params)
         self.first_cooling = int(math.floor(params.cooling_start * float(params.iter_max)))
         self.iterations_done = 0
         self.stopped_early = False
         self._buf = None
+        # Every rank applies 1/G of each iteration's terms.  With the tile kernel, part b of an iteration runs
+        # every B-th tile with its whole (1/G) share, so the cost of an iteration does not grow with the
+        # number of exchanges.  region_shard=True instead gives each rank every G-th node region with all
+        # its tiles (disjoint private windows; pays off only when there are >= ~1000 regions per rank and
+        # launch, i.e. N >~ 1e6 * G nodes: fewer leave most of the GPU idle).
+        self.region_sharded = False
         if self.world > 1:
             self._buf = engine.new_exchange_buffer()
             engine.exchange_mark()
+            if region_shard and hasattr(engine, "set_shard"):
+                self.region_sharded = bool(engine.set_shard(self.rank, self.world))
+
+    def _iteration_terms(self):
+        """Term count this rank passes for one iteration: everything when it shards by region (only the
+        owned tiles' share is applied), 1/G of it otherwise."""
+        M = self.params.min_term_updates
+        return M if self.region_sharded else shard_terms(M, self.world, self.rank)
 
     def my_terms(self):
-        """Terms this rank applies per iteration."""
-        return sum(shard_terms(b, self.world, self.rank) for b in split_blocks(self.params.min_term_updates, self.blocks))
+        """Terms this rank applies per iteration (for a region-sharded engine: its expected share)."""
+        if self.region_sharded:
+            return self.params.min_term_updates // self.world
+        return shard_terms(self.params.min_term_updates, self.world, self.rank)
 
     def step(self, it):
         """Iteration `it` (0-based) on every rank with its exchanges.  Returns global max|Delta|."""
         eng = self.engine
         dmax = 0.0
-        for block_terms in split_blocks(self.params.min_term_updates, self.blocks):
-            eng.iteration(self.etas[it], it >= self.first_cooling, shard_terms(block_terms, self.world, self.rank))
+        for b in range(self.blocks):
+            eng.iteration_part(self.etas[it], it >= self.first_cooling, self._iteration_terms(), b, self.blocks)
             if self.world > 1:
                 eng.exchange_begin(self._buf)
                 dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)

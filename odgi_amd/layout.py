@@ -183,6 +183,11 @@ class LayoutSession:
     def iteration(self, eta, cooling, n_terms):
         check(lib.pgsgd_session_iteration(self._h, float(eta), 1 if cooling else 0, int(n_terms)), "iteration")
 
+    def iteration_part(self, eta, cooling, n_terms, part, n_parts):
+        """Part `part` of `n_parts` of an iteration of n_terms terms (one part per multi-GPU exchange)."""
+        check(lib.pgsgd_session_iteration_part(self._h, float(eta), 1 if cooling else 0, int(n_terms), int(part), int(n_parts)),
+              "iteration_part")
+
     def sync(self):
         d = C.c_double()
         check(lib.pgsgd_session_sync(self._h, C.byref(d)), "sync")

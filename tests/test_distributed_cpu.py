@@ -43,6 +43,10 @@ class OracleEngine:
         self.coords.copy_(torch.from_numpy(out))
         self._dmax = float(np.abs(out - c).max())
 
+    def iteration_part(self, eta, cooling, n_terms, part, n_parts):
+        base, rem = divmod(n_terms, n_parts)
+        self.iteration(eta, cooling, base + (1 if part < rem else 0))
+
     def sync(self):
         return self._dmax
 
@@ -125,12 +129,12 @@ def test_two_rank_delta_allreduce_matches_single_process_merge(tmp_path):
     etas = oa.path_linear_sgd_layout_schedule(p)
     cur = engines[0].coords.clone()
     for it in range(p.iter_max):
-        for block in split_blocks(p.min_term_updates, 4):
+        for b in range(4):
             total = torch.zeros(6 * len(cur))
             for r, e in enumerate(engines):
                 e.coords.copy_(cur)
                 e.base = cur.clone()
-                e.iteration(etas[it], it >= p.first_cooling_iteration(), shard_terms(block, world, r))
+                e.iteration_part(etas[it], it >= p.first_cooling_iteration(), shard_terms(p.min_term_updates, world, r), b, 4)
                 buf = e.new_exchange_buffer()
                 e.exchange_begin(buf)
                 total += buf
