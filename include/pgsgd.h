@@ -182,6 +182,15 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
 int pgsgd_session_exchange_mark(pgsgd_session* s);
 int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats);
 int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size);
+/* Parity hooks of the tile kernel.  Every term of a tiled iteration is a pure function of (seed +
+ * stream_offset, iteration number, term index); tile_table copies up to `capacity` tiles (in work order:
+ * first step, steps before the tile, steps, path) and returns their number; trace_tile_terms replays the
+ * terms tile `tile` draws in iteration `epoch` (1-based) of n_terms terms: out[4*j + {0..3}] = {flat step
+ * a, flat step b, end offset a, end offset b}; returns the number of terms. */
+int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0, uint64_t* cum, uint32_t* n, uint32_t* path,
+                                 uint64_t capacity, uint64_t* steps_total);
+int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t tile, int cooling, uint64_t epoch, uint64_t n_terms,
+                                       uint64_t* out, uint64_t capacity_terms);
 /* Parity hook: run the sampler only and write, for stream g and its j-th term (j < terms_per_stream),
  * out[(j*n_streams+g)*4 + {0,1,2,3}] = {flat step a, flat step b, end offset a, end offset b}
  * without touching coordinates or the persistent stream states. */

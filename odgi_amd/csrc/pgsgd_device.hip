@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgsgd_internal.hpp"
@@ -62,6 +63,7 @@ struct DevConst {
     uint32_t n_nodes;
     uint64_t space, space_max, space_quant;
     uint64_t terms_per_anchor;
+    uint64_t seed_base;  // params.seed + params.stream_offset
     ZipfConst zc;
     Xform xf;
 };
@@ -70,6 +72,7 @@ struct IterArgs {
     uint64_t n_terms;
     float eta;
     uint32_t cooling;
+    uint64_t epoch;  // tile kernel: iterations started so far (part of every term's seed)
 };
 
 constexpr int kBlock = 256;
@@ -454,6 +457,10 @@ struct TileRecs {  // partner records from the tile staged in LDS when they are 
     __device__ __forceinline__ uint4 operator()(uint64_t k) const { return (k - t0 < (uint64_t)n) ? lds[k - t0] : recs[k]; }
 };
 
+__device__ __forceinline__ uint64_t tile_term_seed(uint64_t seed_base, uint64_t epoch, uint64_t q) {
+    return seed_base + epoch * 0x9e3779b97f4a7c15ull + q;  // fed to SplitMix64 by Xoshiro256Plus::seed
+}
+
 __device__ __forceinline__ uint64_t mul_div(uint64_t a, uint64_t b, uint64_t c) {
     return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) / (unsigned __int128)c);
 }
@@ -465,13 +472,6 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     uint64_t* orig = lds + 4 * (size_t)ta.region;          // [4R] as staged
     uint4* trec = reinterpret_cast<uint4*>(lds + 8 * (size_t)ta.region);  // [T] tile records
     __shared__ uint32_t s_item;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    Xoshiro256Plus rng;
-    const size_t L = c.n_streams;
-    rng.s0 = c.rng[g];
-    rng.s1 = c.rng[L + g];
-    rng.s2 = c.rng[2 * L + g];
-    rng.s3 = c.rng[3 * L + g];
     float dmax = 0.0f;
     const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
     const uint32_t win_words = 4 * ta.region;
@@ -501,6 +501,11 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             const uint64_t cnt = c.path_first[t.path + 1] - pstart;
             const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
             for (uint64_t q = term_begin + threadIdx.x; threadIdx.x < lanes && q < term_end; q += lanes) {
+                // Every term owns a generator seeded from (seed, iteration, term index): which workgroup
+                // runs a tile, and when, changes nothing about the terms that are drawn, and the oracle can
+                // reproduce any of them (tests/test_gpu_parity.py: tile terms bit-exact).
+                Xoshiro256Plus rng;
+                rng.seed(tile_term_seed(c.seed_base, a.epoch, q));
                 // first step: uniform inside the tile; partner: the shared sampler (path_sgd_layout.cpp:205-270)
                 Anchor an;
                 an.k = t.t0 + uniform_below(rng, t.n);
@@ -544,12 +549,32 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
         }
         __syncthreads();  // s_item and the window are reused
     }
-    c.rng[g] = rng.s0;
-    c.rng[L + g] = rng.s1;
-    c.rng[2 * L + g] = rng.s2;
-    c.rng[3 * L + g] = rng.s3;
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
+// sampler-only replay of one tile's terms (parity hook): out[(q - first_term)*4 + {0..3}] = {ka, kb, off_a, off_b}
+__global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile t, uint64_t steps_total, IterArgs a, uint64_t* out) {
+    const uint64_t term_begin = mul_div(t.cum, a.n_terms, steps_total);
+    const uint64_t term_end = mul_div(t.cum + t.n, a.n_terms, steps_total);
+    const uint64_t pstart = c.path_first[t.path];
+    const uint64_t cnt = c.path_first[t.path + 1] - pstart;
+    for (uint64_t q = term_begin + blockIdx.x * blockDim.x + threadIdx.x; q < term_end; q += (uint64_t)gridDim.x * blockDim.x) {
+        Xoshiro256Plus rng;
+        rng.seed(tile_term_seed(c.seed_base, a.epoch, q));
+        Anchor an;
+        an.k = t.t0 + uniform_below(rng, t.n);
+        an.pstart = pstart;
+        an.cnt = cnt;
+        an.s_rank = an.k - pstart;
+        an.rec = c.recs[an.k];
+        const Term tm = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
+        uint64_t* o = out + (q - term_begin) * 4;
+        o[0] = an.k;
+        o[1] = tm.kb;
+        o[2] = tm.end_a & 1u;
+        o[3] = tm.end_b & 1u;
+    }
 }
 
 // sampler-only launch for parity checks: fresh streams, nothing is modified
@@ -727,6 +752,8 @@ struct pgsgd_session {
     bool tiled = false;
     uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;
+    uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
+    std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
@@ -821,7 +848,6 @@ struct HostTiles {
 static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
     struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
     std::vector<Raw> raw;
-    std::vector<uint32_t> ranks;
     for (uint64_t p = 0; p < g->n_paths; ++p) {
         const uint64_t b = g->path_first[p], cnt = g->path_first[p + 1] - b;
         if (cnt <= 1) continue;  // single-step paths are never sampled (path_sgd_layout.cpp:189-192)
@@ -832,21 +858,34 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
             r.path = (uint32_t)p;
             r.rmin = UINT32_MAX;
             r.rmax = 0;
-            ranks.clear();
-            for (uint64_t k = r.t0; k < r.t0 + r.n; ++k) {
-                const uint32_t rank = g->step_handle[k] >> 1;
-                r.rmin = std::min(r.rmin, rank);
-                r.rmax = std::max(r.rmax, rank);
-                ranks.push_back(rank);
-            }
-            std::sort(ranks.begin(), ranks.end());
             r.maxmult = 1;
-            for (size_t i = 0, j = 0; i < ranks.size(); i = j) {
-                while (j < ranks.size() && ranks[j] == ranks[i]) ++j;
-                r.maxmult = std::max<uint32_t>(r.maxmult, (uint32_t)(j - i));
-            }
             raw.push_back(r);
         }
+    }
+    {   // rank range and the most visits of one node, per tile, on a few host threads
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        auto scan = [&](unsigned tid) {
+            std::vector<uint32_t> ranks;
+            for (size_t i = tid; i < raw.size(); i += nt) {
+                Raw& r = raw[i];
+                ranks.clear();
+                for (uint64_t k = r.t0; k < r.t0 + r.n; ++k) {
+                    const uint32_t rank = g->step_handle[k] >> 1;
+                    r.rmin = std::min(r.rmin, rank);
+                    r.rmax = std::max(r.rmax, rank);
+                    ranks.push_back(rank);
+                }
+                std::sort(ranks.begin(), ranks.end());
+                for (size_t a = 0, b2 = 0; a < ranks.size(); a = b2) {
+                    while (b2 < ranks.size() && ranks[b2] == ranks[a]) ++b2;
+                    r.maxmult = std::max<uint32_t>(r.maxmult, (uint32_t)(b2 - a));
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto& t : th) t.join();
     }
     // local tiles grouped by (colour, region of rmin); a tile that does not fit two regions is its own global item
     struct Group { uint32_t r0; uint64_t steps; std::vector<uint32_t> members; };
@@ -943,13 +982,31 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         }
     }
     if (!p->n_streams) {  // only the automatic stream count needs the hottest node
-        std::vector<uint32_t> per_node(g->n_nodes, 0);
-        for (uint64_t k = 0; k < g->n_steps; ++k) {
-            const uint32_t r = g->step_handle[k] >> 1;
-            if (r >= g->n_nodes) { set_error("step %llu names node rank %u of %llu", (unsigned long long)k, r, (unsigned long long)g->n_nodes); delete s; return PGSGD_E_INVALID; }
-            per_node[r]++;
+        const unsigned nt = g->n_steps > (1u << 22) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<std::vector<uint32_t>> per_node(nt, std::vector<uint32_t>(g->n_nodes, 0));
+        std::vector<int> bad(nt, 0);
+        auto count = [&](unsigned tid) {
+            const uint64_t b = g->n_steps * tid / nt, e = g->n_steps * (tid + 1) / nt;
+            uint32_t* c = per_node[tid].data();
+            for (uint64_t k = b; k < e; ++k) {
+                const uint32_t r = g->step_handle[k] >> 1;
+                if (r >= g->n_nodes) { bad[tid] = 1; return; }
+                c[r]++;
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(count, t);
+            count(0);
+            for (auto& t : th) t.join();
         }
-        for (uint32_t v : per_node) s->max_node_steps = std::max<uint64_t>(s->max_node_steps, v);
+        for (unsigned t = 0; t < nt; ++t)
+            if (bad[t]) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
+        for (uint64_t i = 0; i < g->n_nodes; ++i) {
+            uint64_t v = 0;
+            for (unsigned t = 0; t < nt; ++t) v += per_node[t][i];
+            s->max_node_steps = std::max(s->max_node_steps, v);
+        }
     }
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
@@ -1015,6 +1072,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             s->n_streams = s->tile_grid * s->tile_block;
             s->tile_steps_total = ht.steps_total;
             s->n_tiles = ht.tiles.size();
+            s->h_tiles = ht.tiles;
             s->n_nonlocal_tiles = ht.n_nonlocal;
             s->n_items[0] = (uint32_t)ht.items[0].size();
             s->n_items[1] = (uint32_t)ht.items[1].size();
@@ -1086,6 +1144,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.space_max = p->space_max;
     c.space_quant = p->space_quantization_step;
     c.terms_per_anchor = p->terms_per_anchor ? p->terms_per_anchor : 1;
+    c.seed_base = p->seed + (uint64_t)p->stream_offset;
     c.zc.init(p->theta);
     c.xf.x_off = c.xf.y_off = 0.0;
     c.xf.scale = c.xf.inv_scale = 1.0f;
@@ -1217,6 +1276,48 @@ extern "C" int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream) {
 
 extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return s ? s->n_streams : 0; }
 
+// parity hooks for the tile kernel
+extern "C" int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0, uint64_t* cum, uint32_t* n, uint32_t* path, uint64_t capacity,
+                                            uint64_t* steps_total) {
+    if (!s) return PGSGD_E_INVALID;
+    if (steps_total) *steps_total = s->tile_steps_total;
+    const uint64_t cnt = s->h_tiles.size();
+    for (uint64_t i = 0; i < cnt && i < capacity; ++i) {
+        if (t0) t0[i] = s->h_tiles[i].t0;
+        if (cum) cum[i] = s->h_tiles[i].cum;
+        if (n) n[i] = s->h_tiles[i].n;
+        if (path) path[i] = s->h_tiles[i].path;
+    }
+    return (int64_t)cnt;
+}
+
+// replay the terms tile `tile` draws in iteration `epoch` (1-based, as counted by the session) of n_terms terms
+extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t tile, int cooling, uint64_t epoch, uint64_t n_terms,
+                                                  uint64_t* out, uint64_t capacity_terms) {
+    pgsgd::clear_error();
+    if (!s || !out || !s->tiled || tile >= s->h_tiles.size()) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const pgsgd::Tile t = s->h_tiles[tile];
+    auto md = [](uint64_t a, uint64_t b, uint64_t c) { return (uint64_t)(((unsigned __int128)a * b) / c); };
+    const uint64_t cnt = md(t.cum + t.n, n_terms, s->tile_steps_total) - md(t.cum, n_terms, s->tile_steps_total);
+    if (cnt > capacity_terms) { set_error("tile has %llu terms, buffer holds %llu", (unsigned long long)cnt, (unsigned long long)capacity_terms); return PGSGD_E_INVALID; }
+    if (cnt == 0) return 0;
+    uint64_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, cnt * 4 * sizeof(uint64_t)));
+    pgsgd::IterArgs a;
+    a.n_terms = n_terms;
+    a.eta = 0.0f;
+    a.cooling = cooling ? 1u : 0u;
+    a.epoch = epoch;
+    hipLaunchKernelGGL(pgsgd::tile_trace_kernel, dim3(8), dim3(pgsgd::kTileBlock), 0, s->stream, s->dc, t, s->tile_steps_total, a, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, cnt * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error("tile trace failed: %s", hipGetErrorString(e)); return PGSGD_E_HIP; }
+    return (int64_t)cnt;
+}
+
 extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world) {
     pgsgd::clear_error();
     if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
@@ -1261,6 +1362,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         a.n_terms = n_terms;
         a.eta = (float)eta;
         a.cooling = cooling ? 1u : 0u;
+        if (part == 0) s->tile_epoch++;
+        a.epoch = s->tile_epoch;
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
         const uint32_t n_sub = n_parts * s->tile_substeps;
         for (uint32_t sub = part * s->tile_substeps; sub < (part + 1) * s->tile_substeps; ++sub)
@@ -1313,6 +1416,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     a.n_terms = n_terms;
     a.eta = (float)eta;
     a.cooling = cooling ? 1u : 0u;
+    a.epoch = 0;
     const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
     const uint32_t grid = (s->n_streams + block - 1) / block;
     HIP_TRY(hipEventRecord(ev.first, s->stream));

@@ -169,6 +169,26 @@ class LayoutSession:
         on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
         return dict(tiled=bool(on), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
 
+    def tile_table(self):
+        """Tiles in work order: dict of arrays t0, cum, n, path, and steps_total."""
+        cnt = lib.pgsgd_session_tile_table(self._h, None, None, None, None, 0, None)
+        t0, cum = np.zeros(cnt, dtype=np.uint64), np.zeros(cnt, dtype=np.uint64)
+        n, path = np.zeros(cnt, dtype=np.uint32), np.zeros(cnt, dtype=np.uint32)
+        tot = C.c_uint64()
+        u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        lib.pgsgd_session_tile_table(self._h, t0.ctypes.data_as(u64p), cum.ctypes.data_as(u64p), n.ctypes.data_as(u32p),
+                                     path.ctypes.data_as(u32p), cnt, C.byref(tot))
+        return dict(t0=t0, cum=cum, n=n, path=path, steps_total=tot.value)
+
+    def trace_tile_terms(self, tile, cooling, epoch, n_terms, capacity=1 << 16):
+        """Replay of the terms one tile draws in iteration `epoch`: uint64 [terms, 4] = (ka, kb, off_a, off_b)."""
+        out = np.zeros((capacity, 4), dtype=np.uint64)
+        cnt = lib.pgsgd_session_trace_tile_terms(self._h, int(tile), 1 if cooling else 0, int(epoch), int(n_terms),
+                                                 out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity)
+        if cnt < 0:
+            check(int(cnt), "trace_tile_terms")
+        return out[:cnt]
+
     def coord_format(self):
         """(fixed_point, x_off, y_off, quanta_per_bp) of the device coordinate words."""
         fp, xo, yo, q = C.c_int(), C.c_double(), C.c_double(), C.c_double()

@@ -61,6 +61,9 @@ def _load(name):
     lib.orc_zetas.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, _F64P]
     lib.orc_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32,
                                     C.c_int, C.c_uint32, C.c_uint64, _U64P]
+    lib.orc_tile_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                   C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _U64P]
+    lib.orc_tile_terms.restype = C.c_uint64
     lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, _F32P, _F32P, _F64P]
     lib.orc_layout_streams_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
@@ -150,6 +153,13 @@ def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream,
     lib().orc_trace_terms(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if cooling else 0,
                           terms_per_anchor, terms_per_stream, out.ctypes.data_as(_U64P))
     return out
+
+
+def tile_terms(g, p, seed_base, epoch, n_terms, steps_total, t0, cum, n, path, cooling, capacity=1 << 16):
+    out = np.zeros((capacity, 4), dtype=np.uint64)
+    cnt = lib().orc_tile_terms(C.byref(g.view), C.byref(p), seed_base, epoch, n_terms, steps_total, int(t0), int(cum), int(n), int(path),
+                               1 if cooling else 0, out.ctypes.data_as(_U64P))
+    return out[:cnt]
 
 
 def layout_streams_f32(g, p, seed, n_streams, X, Y, stream_offset=0, stores=False, terms_per_anchor=1):

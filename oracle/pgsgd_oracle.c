@@ -392,6 +392,34 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
     free(zetas);
 }
 
+/* Terms of the tile kernel (odgi_amd/csrc/pgsgd_device.hip: sgd_tile_kernel / tile_trace_kernel): term q of an
+ * iteration of n_terms terms belongs to the tile whose share [cum*M/S_tot, (cum+n)*M/S_tot) contains q; it has
+ * its own generator seeded with seed_base + epoch*0x9e3779b97f4a7c15 + q, draws its first step uniformly in the
+ * tile and its partner by the reference rule. */
+uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
+                        uint64_t steps_total, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path, int cooling, uint64_t* out) {
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    const uint64_t term_begin = (uint64_t)(((unsigned __int128)cum * n_terms) / steps_total);
+    const uint64_t term_end = (uint64_t)(((unsigned __int128)(cum + n) * n_terms) / steps_total);
+    for (uint64_t q = term_begin; q < term_end; ++q) {
+        uint64_t s[4];
+        orc_rng_seed(seed_base + epoch * 0x9e3779b97f4a7c15ull + q, s);
+        orc_anchor an;
+        an.pstart = g->path_first[path];
+        an.cnt = g->path_first[path + 1] - an.pstart;
+        an.k = t0 + orc_uniform_u64(s, n);
+        an.s_rank = an.k - an.pstart;
+        orc_term t;
+        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+        uint64_t* o = out + (q - term_begin) * 4;
+        o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
+    }
+    free(zetas);
+    return term_end - term_begin;
+}
+
 /* iteration control shared by the serialised stream runs: path_sgd_layout.cpp:120-163 with exact
  * iteration lengths (min_term_updates terms each) instead of the 1 ms polling. */
 typedef struct stream_run {

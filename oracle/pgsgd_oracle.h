@@ -72,6 +72,9 @@ int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas
  * trace: out[(j*n_streams+g)*4+{0..3}] = {ka,kb,off_a,off_b} for fresh streams (first iteration). */
 void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams,
                      uint32_t stream_offset, int cooling, uint32_t terms_per_anchor, uint64_t terms_per_stream, uint64_t* out);
+/* the terms one tile of the device's tile kernel draws in iteration `epoch`; returns their number */
+uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
+                        uint64_t steps_total, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path, int cooling, uint64_t* out);
 /* fp32 mirror of the device arithmetic; bit-exact with the GPU for n_streams == 1 */
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
                             uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,

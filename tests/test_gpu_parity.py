@@ -345,6 +345,37 @@ def test_tiled_kernel_matches_per_lane_kernel_and_oracle(oa, orc):
     assert m_t <= 1.25 * s_cpu + 0.02 and m_p <= 1.25 * s_cpu + 0.02
 
 
+def test_tiled_kernel_terms_bit_exact_and_tile_table(oa, orc):
+    """Every term of the tile kernel is a function of (seed, iteration, term index): the oracle reproduces
+    the terms of any tile bit for bit; the tile table partitions the steps and the terms exactly."""
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    og = orc.Graph.from_product(g)
+    p = _params(oa, g, stream_offset=5)
+    M = p.min_term_updates
+    with oa.LayoutSession(g, p) as s:
+        assert s.tile_info()["tiled"]
+        tt = s.tile_table()
+        n_tiles = len(tt["t0"])
+        # the tiles partition the steps of all multi-step paths: cum is the running sum, no overlaps
+        assert tt["steps_total"] == g.n_steps and int(tt["n"].sum()) == g.n_steps
+        assert np.array_equal(tt["cum"], np.r_[0, np.cumsum(tt["n"].astype(np.uint64))[:-1]])
+        order = np.argsort(tt["t0"])
+        assert np.array_equal(tt["t0"][order][1:], (tt["t0"][order] + tt["n"][order])[:-1])
+        assert np.array_equal(g.step_path[tt["t0"].astype(np.int64)], tt["path"])
+        # term shares telescope to exactly M
+        shares = (tt["cum"].astype(object) + tt["n"].astype(object)) * M // tt["steps_total"] - tt["cum"].astype(object) * M // tt["steps_total"]
+        assert int(sum(shares)) == M
+        for tile in (0, 1, n_tiles // 2, n_tiles - 1, int(np.argmin(tt["n"]))):
+            for cooling, epoch in ((False, 1), (True, 17)):
+                got = s.trace_tile_terms(tile, cooling, epoch, M)
+                want = orc.tile_terms(og, orc.params_from(p), p.seed + 5, epoch, M, tt["steps_total"], tt["t0"][tile], tt["cum"][tile],
+                                      tt["n"][tile], tt["path"][tile], cooling)
+                assert len(got) == int(shares[tile]) and np.array_equal(got, want)
+                ka = got[:, 0].astype(np.int64)
+                assert ka.min() >= tt["t0"][tile] and ka.max() < tt["t0"][tile] + tt["n"][tile]   # first step inside the tile
+                assert np.array_equal(g.step_path[ka], g.step_path[got[:, 1].astype(np.int64)])        # partner on the same path
+
+
 def test_tiled_kernel_with_unsorted_stretches(oa):
     """Tiles whose nodes do not fit a two-region window (relabelled stretches) run with every end in
     global memory; invariants and quality hold."""
