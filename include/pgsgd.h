@@ -73,6 +73,8 @@ typedef struct pgsgd_graph_view {
                                            /* graphs that suit it (large, sorted, no hub node; default  */
                                            /* format/update/term stream, automatic stream count) run     */
                                            /* it: first steps stratified by tile, node windows in LDS   */
+#define PGSGD_FLAG_NO_FAR_CAP        0x10u /* tile kernel: do not cap the learning rate of terms whose   */
+                                           /* partner lies outside the staged window (debug / A-B)      */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

@@ -47,6 +47,7 @@ FLAG_COORD_LOAD_PLAIN = 0x1
 FLAG_FP32_ATOMICS = 0x2
 FLAG_HOGWILD_STORES = 0x4
 FLAG_NO_TILES = 0x8
+FLAG_NO_FAR_CAP = 0x10
 DEFAULT_SEED = 9399220
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)

@@ -167,13 +167,13 @@ __device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& 
 
 // The displacement of one term in bp, fp32 (path_sgd_layout.cpp:280-352); dx,dy = p_a - p_b.
 __device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy,
-                                                  float& r_x, float& r_y, float& abs_delta) {
+                                                  float& r_x, float& r_y, float& abs_delta, float mu_cap = 1.0f) {
     const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
     float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
     if (d == 0.0f) d = 1e-9f;
     const float w = 1.0f / d;
     float mu = eta * w;
-    if (mu > 1.0f) mu = 1.0f;
+    if (mu > mu_cap) mu = mu_cap;
     if (dx == 0.0f) dx = 1e-9f;
     const float dx2 = dx * dx;
     const float dy2 = dy * dy;
@@ -445,6 +445,8 @@ struct TileArgs {
     uint64_t steps_total; // steps covered by tiles (paths of one step have none)
     uint32_t sub, n_sub;  // this launch runs the tiles with index = sub (mod n_sub), each with its whole share
     uint32_t shard_rank, shard_world;  // multi-GPU: this device owns work items rank, rank+world, ...
+    float far_mu_cap;                  // learning-rate cap of terms whose partner is outside the window
+    unsigned long long* far_count;     // partner ends updated outside the window, this launch
 };
 
 constexpr int kTileBlock = 256;
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     uint4* trec = reinterpret_cast<uint4*>(lds + 8 * (size_t)ta.region);  // [T] tile records
     __shared__ uint32_t s_item;
     float dmax = 0.0f;
+    uint32_t n_far = 0;
     const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
     const uint32_t win_words = 4 * ta.region;
     for (;;) {
@@ -523,8 +526,16 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 const uint64_t wb = in_b ? win[lb] : load_word<COORD_LOAD>(c.coords, end_b);
                 const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                 const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+                // A partner outside the window is read as it was when its own window was staged, and what
+                // this term adds to it reaches its owner only at that owner's next staging: all the far
+                // pulls an end receives during one launch are computed against one stale position and land
+                // together.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
+                // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped
+                // at mu = 1/h, h = far pulls per node end per launch as counted in the previous launch:
+                // together they still amount to one projection.  Inactive once eta/d < 1/h.
                 float r_x, r_y, abs_delta;
-                term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta);
+                term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, in_b ? 1.0f : ta.far_mu_cap);
+                n_far += in_b ? 0u : 1u;
                 dmax = fmaxf(dmax, abs_delta);
                 const float ux = (float)(dither & 0xffffu) * (1.0f / 65536.0f);
                 const float uy = (float)(dither >> 16) * (1.0f / 65536.0f);
@@ -549,6 +560,8 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
         }
         __syncthreads();  // s_item and the window are reused
     }
+    for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
+    if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(ta.far_count, (unsigned long long)n_far);
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
 }
@@ -753,6 +766,9 @@ struct pgsgd_session {
     uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
+    unsigned long long* d_far = nullptr;  // [2] far-partner updates of the last launch of each colour
+    unsigned long long* h_far = nullptr;  // pinned copy
+    float far_mu_cap[2] = {1.0f, 1.0f};   // per colour, from the previous launch of that colour
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
@@ -1081,6 +1097,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
             S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
             S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
+            S_TRY(hipMalloc(&s->d_far, 2 * sizeof(unsigned long long)));
+            S_TRY(hipMemset(s->d_far, 0, 2 * sizeof(unsigned long long)));
+            S_TRY(hipHostMalloc(&s->h_far, 2 * sizeof(unsigned long long)));
+            s->h_far[0] = s->h_far[1] = 0;
             S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
             S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
         }
@@ -1169,6 +1189,8 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_tiles) (void)hipFree(s->d_tiles);
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_far) (void)hipFree(s->d_far);
+    if (s->h_far) (void)hipHostFree(s->h_far);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -1364,12 +1386,19 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         a.cooling = cooling ? 1u : 0u;
         if (part == 0) s->tile_epoch++;
         a.epoch = s->tile_epoch;
+        if (s->tile_epoch == 1 && part == 0) {
+            // nothing was counted yet: assume three quarters of the partners of this call's terms are far,
+            // half of them in each colour's launch
+            const double h = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)(2 * s->n_nodes);
+            s->far_mu_cap[0] = s->far_mu_cap[1] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
+        }
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
         const uint32_t n_sub = n_parts * s->tile_substeps;
         for (uint32_t sub = part * s->tile_substeps; sub < (part + 1) * s->tile_substeps; ++sub)
         for (int colour = 0; colour < 2; ++colour) {
             if (!s->n_items[colour]) continue;
             HIP_TRY(hipMemsetAsync(s->d_queue + colour, 0, sizeof(uint32_t), s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_far + colour, 0, sizeof(unsigned long long), s->stream));
             std::pair<hipEvent_t, hipEvent_t> ev;
             if (!s->free_events.empty()) {
                 ev = s->free_events.back();
@@ -1390,6 +1419,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.n_sub = n_sub;
             ta.shard_rank = s->shard_rank;
             ta.shard_world = s->shard_world;
+            ta.far_mu_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) ? 1.0f : s->far_mu_cap[colour];
+            ta.far_count = s->d_far + colour;
             HIP_TRY(hipEventRecord(ev.first, s->stream));
             hipLaunchKernelGGL(pgsgd::sgd_tile_kernel<1>, dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
             HIP_TRY(hipGetLastError());
@@ -1397,6 +1428,13 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             s->pending_events.push_back(ev);
         }
         HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->h_far, s->d_far, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        // the cap of the next launches comes from this call's counts: wait for them (the caller syncs anyway)
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        for (int colour = 0; colour < 2; ++colour) {
+            const double h = (double)s->h_far[colour] / (double)(2 * s->n_nodes);
+            s->far_mu_cap[colour] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
+        }
         return PGSGD_OK;
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
