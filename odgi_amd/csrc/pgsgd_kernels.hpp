@@ -1,0 +1,533 @@
+// pgsgd_kernels.hpp — device code of the per-lane SGD kernel: data structures, the sampler, the update,
+// and the streaming set-up / exchange kernels.  Included by pgsgd_session.hip only (one translation unit).
+//
+// The HIP side of the path-guided SGD 2D layout for MI355X (gfx950, wave64).
+//
+// One launch = one learning-rate step ("iteration") of the reference's worker loop
+// (src/algorithms/path_sgd_layout.cpp:165-377): every GPU lane is one reference worker.  Lane g
+// owns a persistent Xoshiro256+ stream seeded with seed+g (the reference seeds worker tid with
+// 9399220+tid, :168-169) and draws, per term, exactly the reference's sequence of variates
+// (:182,205-206,215/228,235-237,253,262).  Terms i, i+L, i+2L, ... of an iteration belong to lane i.
+//
+// HBM layout (built once per session from the caller's SoA view, see build_step_records):
+//   recs   [S] x 16 B  {u32 handle = 2*rank+rev, u32 node length, u64 bp position of the step}
+//                      one 16-byte gather returns everything the term needs about a step, so the
+//                      node_len[] gather and the separate handle/position gathers disappear;
+//   coords [2N] x 8 B  one word per node END, the two ends of a node adjacent: {u32 Xq, u32 Yq} fixed
+//                      point by default (one 64-bit atomic moves both), {f32 x, f32 y} optionally;
+//   path_first [P+1] u64 — staged into LDS, (path, rank) of a flat step index by binary search,
+//                      which replaces the npi_iv/nr_iv gathers of the reference (xp.cpp:421-434);
+//   zetas  [~space_max + space/quant] f64 — read-only, L2 resident;
+//   rng    [4][L] u64 — SoA stream states, read and written once per launch, coalesced.
+// Coordinates are read with agent-scope loads (they bypass the per-CU L1, which is never refreshed
+// by other CUs' atomics) and updated with hardware atomic adds at agent scope.
+//
+// Built with -ffp-contract=off: the sampler is integer/fp64 work that the CPU oracle reproduces
+// bit for bit, and the fp32 update arithmetic matches the oracle's mirrors for a one-stream run.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pgsgd_math.hpp"
+
+namespace pgsgd {
+
+// Coordinate formats.  Both keep one 8-byte word per node END (the two ends of a node share 16 B):
+//   kFmtQ32 (default): {u32 Xq, u32 Yq} fixed point, x = x_off + Xq / scale.  One 64-bit integer
+//            atomic add moves x and y together: for signed steps (qx, qy) the word changes by
+//            qx + qy*2^32 (mod 2^64), exact as long as each field stays inside [0, 2^32).  The
+//            atomic units of MI355X retire ~21-24 G scattered atomics/s whatever their width
+//            (tools/microbench.hip), so this halves the cost of the update, the kernel's limiter.
+//   kFmtF32: {f32 x, f32 y}, four fp32 atomic adds per term (the literal north-star form).
+enum : int { kFmtQ32 = 0, kFmtF32 = 1 };
+
+struct Xform {  // kFmtQ32 only
+    double x_off, y_off;
+    float scale, inv_scale;  // scale = 2^k quanta per bp
+};
+
+struct DevConst {
+    const uint4* recs;
+    const uint64_t* path_first;
+    const double* zetas;
+    uint64_t* coords;  // [2N] words
+    uint64_t* rng;
+    unsigned int* delta_max_bits;
+    uint64_t n_steps;
+    uint32_t n_paths;
+    uint32_t n_streams;
+    uint32_t n_nodes;
+    uint64_t space, space_max, space_quant;
+    uint64_t terms_per_anchor;
+    uint64_t seed_base;  // params.seed + params.stream_offset
+    ZipfConst zc;
+    Xform xf;
+};
+
+struct IterArgs {
+    uint64_t n_terms;
+    float eta;
+    uint32_t cooling;
+    uint64_t epoch;  // tile kernel: iterations started so far (part of every term's seed)
+};
+
+constexpr int kBlock = 256;
+constexpr uint32_t kPathLdsCap = 4096;  // path_first entries staged in LDS (32 KiB)
+
+// largest p with pf[p] <= k  (pf[0] = 0 <= k < pf[n_paths])
+template <typename PF>
+__device__ __forceinline__ uint32_t find_path(const PF pf, uint32_t n_paths, uint64_t k) {
+    uint32_t lo = 0, hi = n_paths;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pf[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Coordinates are read at agent scope (sc1): the load bypasses the per-CU L1, which other CUs'
+// atomics never refresh.  COORD_LOAD 0 is the plain (L1-cached) load, kept for A/B profiling.
+template <int COORD_LOAD>
+__device__ __forceinline__ uint64_t load_word(const uint64_t* coords, uint32_t end_idx) {
+    if (COORD_LOAD == 0) return coords[end_idx];
+    return __hip_atomic_load(coords + end_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Anchor {
+    uint64_t k, pstart, cnt, s_rank;
+    uint4 rec;
+};
+
+struct Term {
+    uint64_t kb;
+    uint64_t pos_a, pos_b;
+    uint32_t end_a, end_b;  // 2*rank + end offset
+    uint32_t dither;        // low 32 bits of the draw whose top bit chose end a (otherwise unused)
+};
+
+// The sampler: path_sgd_layout.cpp:182-270 on the lowered index, split at the point where the
+// first step is fixed.  One anchor followed by one partner is exactly the reference's sequence of
+// draws; `terms_per_anchor` > 1 draws further partners (:205-270) for the same first step.
+template <typename PF>
+__device__ __forceinline__ Anchor sample_anchor(const DevConst& c, const PF pf, Xoshiro256Plus& rng) {
+    Anchor a;
+    do {  // :182-192 — a single-step path makes the reference draw again without counting a term
+        a.k = uniform_below(rng, c.n_steps);
+        const uint32_t p = find_path(pf, c.n_paths, a.k);
+        a.pstart = pf[p];
+        a.cnt = pf[p + 1] - a.pstart;
+    } while (a.cnt == 1);
+    a.rec = c.recs[a.k];  // issued early; consumed after the partner is chosen
+    a.s_rank = a.k - a.pstart;
+    return a;
+}
+
+struct GlobalRecs {  // partner records straight from HBM
+    const uint4* recs;
+    __device__ __forceinline__ uint4 operator()(uint64_t k) const { return recs[k]; }
+};
+
+template <class RecFetch>
+__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng, const RecFetch& fetch) {
+    Term t;
+    uint64_t b_rank;
+    if (cooling || coin(rng)) {                                               // :205
+        const bool back = (a.s_rank > 0 && coin(rng)) || a.s_rank == a.cnt - 1;  // :206
+        const uint64_t room = back ? a.s_rank : a.cnt - a.s_rank - 1;
+        const uint64_t jump = c.space < room ? c.space : room;
+        const double zeta_n = c.zetas[zeta_index(jump, c.space_max, c.space_quant)];
+        const uint64_t z = zipf(rng, c.zc, jump, zeta_n);
+        b_rank = back ? a.s_rank - z : a.s_rank + z;
+    } else {
+        b_rank = uniform_below(rng, a.cnt);                                   // :235-237
+    }
+    t.kb = a.pstart + b_rank;
+    const uint4 rb = fetch(t.kb);
+    // :242-269 — choose an end of each node; the path position moves to that end.
+    // flip(0,1) is the top bit of one draw (uniform_int_distribution never rejects for range 2).
+    const uint64_t draw_a = rng.next(), draw_b = rng.next();
+    const uint32_t flip_a = (uint32_t)(draw_a >> 63), flip_b = (uint32_t)(draw_b >> 63);
+    t.dither = (uint32_t)draw_a;
+    const uint32_t h_a = a.rec.x, h_b = rb.x;
+    uint64_t pos_a = (uint64_t)a.rec.z | ((uint64_t)a.rec.w << 32);
+    uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+    uint32_t off_a = h_a & 1u, off_b = h_b & 1u;
+    if (flip_a) { pos_a += a.rec.y; off_a ^= 1u; }
+    if (flip_b) { pos_b += rb.y; off_b ^= 1u; }
+    t.pos_a = pos_a;
+    t.pos_b = pos_b;
+    t.end_a = (h_a & ~1u) | off_a;
+    t.end_b = (h_b & ~1u) | off_b;
+    return t;
+}
+
+// The displacement of one term in bp, fp32 (path_sgd_layout.cpp:280-352); dx,dy = p_a - p_b.
+__device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy,
+                                                  float& r_x, float& r_y, float& abs_delta, float mu_cap = 1.0f) {
+    const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
+    float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > mu_cap) mu = mu_cap;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    abs_delta = fabsf(Delta);
+    const float r = Delta / mag;
+    r_x = r * dx;
+    r_y = r * dy;
+}
+
+__device__ __forceinline__ uint64_t pack_f32(float x, float y) {
+    return (uint64_t)__float_as_uint(x) | ((uint64_t)__float_as_uint(y) << 32);
+}
+__device__ __forceinline__ uint64_t q32_shift(uint64_t w, int64_t qx, int64_t qy) {  // per-field add, no carry between fields
+    return (uint64_t)(uint32_t)((int64_t)(uint32_t)w + qx) | ((uint64_t)(uint32_t)((int64_t)(w >> 32) + qy) << 32);
+}
+
+// UPD: how a term's displacement reaches memory.
+//   kUpdAtomic: atomic adds — every concurrent displacement is applied (they accumulate).
+//   kUpdStore : the reference CPU's Hogwild form (path_sgd_layout.cpp:360-363: load, subtract,
+//               store): the new position of an end is computed from the loaded one and written back
+//               with one 8-byte agent-scope store; a concurrent update of the same end in between is
+//               overwritten, never summed.
+enum : int { kUpdAtomic = 0, kUpdStore = 1 };
+
+// ABL: profiling ablations (never used by the product path; PGSGD_FLAG_ABLATE selects them)
+//   1 = no atomics, 3 = no coordinate loads, 4 = neither
+//
+// One anchor group = one first step `a` with `terms_per_anchor` partners.  The anchor's record and
+// both of its node ends are fetched once per group; the anchor-side displacement of each term is
+// applied to the lane's private copy at once (the next partner sees it) and reaches memory as ONE
+// update per touched end when the group ends.  Partner-side updates go out term by term.
+// terms_per_anchor = 1 is the reference's term stream.
+// GROUPED = false is the terms_per_anchor == 1 instance: same results, no group bookkeeping, fewer
+// registers (7 instead of 5 resident waves per SIMD).
+template <bool PF_LDS, int COORD_LOAD, int FMT, int UPD, bool GROUPED, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterArgs a) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    float dmax = 0.0f;
+    if (!GROUPED) {
+        for (uint64_t ti = g; ti < a.n_terms; ti += L) {
+            const Anchor an = sample_anchor(c, pf, rng);
+            const Term t = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
+            uint64_t wa, wb;
+            if (ABL == 3 || ABL == 4) {
+                wa = (uint64_t)t.end_a * 0x100000001ull;
+                wb = (uint64_t)t.end_b * 0x100000003ull;
+            } else {
+                wa = load_word<COORD_LOAD>(c.coords, t.end_a);
+                wb = load_word<COORD_LOAD>(c.coords, t.end_b);
+            }
+            float dx, dy;
+            if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
+                dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+                dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+            } else {
+                dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
+                dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
+            }
+            float r_x, r_y, abs_delta;
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            dmax = fmaxf(dmax, abs_delta);
+            if (ABL == 1 || ABL == 4) {
+                dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
+                continue;
+            }
+            if (UPD == kUpdStore && t.end_a == t.end_b) continue;  // the reference's two load/store pairs cancel
+            if (FMT == kFmtQ32) {
+                // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
+                // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum
+                // of all coordinates is conserved exactly.
+                const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                    // partner end first, anchor end second: the order of the grouped path and of the oracle mirror
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_a), (unsigned long long)(0 - delta));
+                } else {
+                    __hip_atomic_store(c.coords + t.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(c.coords + t.end_a, q32_shift(wa, -qx, -qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (UPD == kUpdAtomic) {
+                float* ca = reinterpret_cast<float*>(c.coords + t.end_a);
+                float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
+                unsafeAtomicAdd(cb, r_x);
+                unsafeAtomicAdd(cb + 1, r_y);
+                unsafeAtomicAdd(ca, -r_x);
+                unsafeAtomicAdd(ca + 1, -r_y);
+            } else {
+                const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
+                const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
+                __hip_atomic_store(c.coords + t.end_b, pack_f32(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c.coords + t.end_a, pack_f32(ax, ay), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    const uint64_t m = c.terms_per_anchor;
+    const uint64_t n_groups = GROUPED ? (a.n_terms + m - 1) / m : 0;
+    for (uint64_t grp = g; grp < n_groups; grp += L) {
+        const uint64_t first = grp * m;
+        const uint32_t mt = (uint32_t)(a.n_terms - first < m ? a.n_terms - first : m);
+        const Anchor an = sample_anchor(c, pf, rng);
+        const uint32_t node_a = an.rec.x & ~1u;  // word index of the anchor node's start end
+        // private copy of the anchor node's two ends (loaded on first use) and what this group
+        // moved each of them by; scalars and bit masks, not arrays: a dynamically indexed array
+        // would live in scratch memory
+        uint64_t la0 = 0, la1 = 0, dq0 = 0, dq1 = 0;
+        float dfx0 = 0.0f, dfy0 = 0.0f, dfx1 = 0.0f, dfy1 = 0.0f;
+        uint32_t have = 0, touched = 0;
+        for (uint32_t r = 0; r < mt; ++r) {
+            const Term t = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
+            const uint32_t ea = t.end_a & 1u, bit = 1u << ea;
+            if (!(have & bit)) {
+                const uint64_t w = (ABL == 3 || ABL == 4) ? (uint64_t)t.end_a * 0x100000001ull : load_word<COORD_LOAD>(c.coords, t.end_a);
+                if (ea) la1 = w; else la0 = w;
+                have |= bit;
+            }
+            const uint64_t wa = ea ? la1 : la0;
+            uint64_t wb;
+            if (ABL == 3 || ABL == 4) wb = (uint64_t)t.end_b * 0x100000003ull;
+            else wb = load_word<COORD_LOAD>(c.coords, t.end_b);
+            float dx, dy;
+            if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
+                dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
+                dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+            } else {
+                dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
+                dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
+            }
+            float r_x, r_y, abs_delta;
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            dmax = fmaxf(dmax, abs_delta);
+            if (ABL == 1 || ABL == 4) {
+                dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
+                continue;
+            }
+            // a term on one and the same node end: the reference's two load/store pairs cancel
+            if (UPD == kUpdStore && t.end_a == t.end_b) continue;
+            touched |= bit;
+            uint64_t na;  // the anchor end after this term
+            if (FMT == kFmtQ32) {
+                // stochastic rounding to quanta with 16+16 spare random bits: steps smaller than a
+                // quantum still act in expectation; a moves by -(qx,qy), b by +(qx,qy), so the sum
+                // of all coordinates is conserved exactly.
+                const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                    na = wa - delta;   // what the word will hold once the group's add has landed
+                    if (ea) dq1 += delta; else dq0 += delta;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);
+                } else {
+                    na = q32_shift(wa, -qx, -qy);
+                    __hip_atomic_store(c.coords + t.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                const float ax = __uint_as_float((uint32_t)wa) + (-r_x), ay = __uint_as_float((uint32_t)(wa >> 32)) + (-r_y);
+                na = pack_f32(ax, ay);
+                if (UPD == kUpdAtomic) {
+                    if (ea) { dfx1 += -r_x; dfy1 += -r_y; } else { dfx0 += -r_x; dfy0 += -r_y; }
+                    float* cb = reinterpret_cast<float*>(c.coords + t.end_b);
+                    unsafeAtomicAdd(cb, r_x);
+                    unsafeAtomicAdd(cb + 1, r_y);
+                } else {
+                    const float bx = __uint_as_float((uint32_t)wb) + r_x, by = __uint_as_float((uint32_t)(wb >> 32)) + r_y;
+                    __hip_atomic_store(c.coords + t.end_b, pack_f32(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (ea) la1 = na; else la0 = na;
+        }
+        // the anchor side reaches memory once per touched end
+        if (ABL != 1 && ABL != 4) {
+            if (touched & 1u) {
+                if (UPD == kUpdStore) __hip_atomic_store(c.coords + node_a, la0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (FMT == kFmtQ32) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + node_a), (unsigned long long)(0 - dq0));
+                else {
+                    float* ca = reinterpret_cast<float*>(c.coords + node_a);
+                    unsafeAtomicAdd(ca, dfx0);
+                    unsafeAtomicAdd(ca + 1, dfy0);
+                }
+            }
+            if (touched & 2u) {
+                if (UPD == kUpdStore) __hip_atomic_store(c.coords + node_a + 1, la1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (FMT == kFmtQ32) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + node_a + 1), (unsigned long long)(0 - dq1));
+                else {
+                    float* ca = reinterpret_cast<float*>(c.coords + node_a + 1);
+                    unsafeAtomicAdd(ca, dfx1);
+                    unsafeAtomicAdd(ca + 1, dfy1);
+                }
+            }
+        }
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+    // per-wavefront reduction of the early-stop quantity, one atomic per wave (:341-347)
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
+// sampler-only launch for parity checks: fresh streams, nothing is modified
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cooling, uint64_t seed_base,
+                                                       uint64_t terms_per_stream, uint64_t* out) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    rng.seed(seed_base + g);
+    Anchor an{};
+    for (uint64_t j = 0; j < terms_per_stream; ++j) {
+        if (j % c.terms_per_anchor == 0) an = sample_anchor(c, pf, rng);
+        const Term t = sample_partner(c, an, cooling, rng, GlobalRecs{c.recs});
+        uint64_t* o = out + (j * (uint64_t)c.n_streams + g) * 4;
+        o[0] = an.k;
+        o[1] = t.kb;
+        o[2] = t.end_a & 1u;
+        o[3] = t.end_b & 1u;
+    }
+}
+
+__global__ void seed_streams_kernel(uint64_t* rng, uint32_t n_streams, uint64_t seed_base) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_streams) return;
+    Xoshiro256Plus r;
+    r.seed(seed_base + g);
+    const size_t L = n_streams;
+    rng[g] = r.s0;
+    rng[L + g] = r.s1;
+    rng[2 * L + g] = r.s2;
+    rng[3 * L + g] = r.s3;
+}
+
+// SoA view -> 16-byte step records, on the device (the gather of node_len happens once, here)
+__global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len,
+                                   uint64_t n_steps, uint4* recs) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = step_handle[k];
+        const uint64_t pos = step_pos[k];
+        recs[k] = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
+    }
+}
+
+__device__ __forceinline__ uint32_t quantize(float v, double off, float scale) {
+    double q = rint(((double)v - off) * (double)scale);
+    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
+    return (uint32_t)q;
+}
+__device__ __forceinline__ float dequantize(uint32_t q, double off, float inv_scale) {
+    return (float)(off + (double)q * (double)inv_scale);
+}
+
+// host X[2N],Y[2N] (staged on the device) <-> coordinate words
+template <int FMT>
+__global__ void pack_coords(const float* X, const float* Y, uint64_t n_ends, Xform xf, uint64_t* coords) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo, hi;
+        if (FMT == kFmtQ32) {
+            lo = quantize(X[i], xf.x_off, xf.scale);
+            hi = quantize(Y[i], xf.y_off, xf.scale);
+        } else {
+            lo = __float_as_uint(X[i]);
+            hi = __float_as_uint(Y[i]);
+        }
+        coords[i] = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+}
+template <int FMT>
+__global__ void unpack_coords(const uint64_t* coords, uint64_t n_ends, Xform xf, float* X, float* Y) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = coords[i];
+        if (FMT == kFmtQ32) {
+            X[i] = dequantize((uint32_t)w, xf.x_off, xf.inv_scale);
+            Y[i] = dequantize((uint32_t)(w >> 32), xf.y_off, xf.inv_scale);
+        } else {
+            X[i] = __uint_as_float((uint32_t)w);
+            Y[i] = __uint_as_float((uint32_t)(w >> 32));
+        }
+    }
+}
+
+// Multi-GPU exchange, step 1: buf[2e], buf[2e+1] = what this rank moved node end e by since the
+// last exchange (bp), buf[4N + e] = squared length of that move.  One fused buffer, one all-reduce.
+template <int FMT>
+__global__ void exchange_prepare_kernel(const uint64_t* coords, const uint64_t* base, uint64_t n_ends, Xform xf, float* buf) {
+    float2* S = reinterpret_cast<float2*>(buf);
+    float* Q = buf + 2 * n_ends;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = coords[i], b = base[i];
+        float dx, dy;
+        if (FMT == kFmtQ32) {
+            dx = (float)((int64_t)(uint32_t)c - (int64_t)(uint32_t)b) * xf.inv_scale;
+            dy = (float)((int64_t)(c >> 32) - (int64_t)(b >> 32)) * xf.inv_scale;
+        } else {
+            dx = __uint_as_float((uint32_t)c) - __uint_as_float((uint32_t)b);
+            dy = __uint_as_float((uint32_t)(c >> 32)) - __uint_as_float((uint32_t)(b >> 32));
+        }
+        S[i] = make_float2(dx, dy);
+        Q[i] = dx * dx + dy * dy;
+    }
+}
+
+// step 2, after the all-reduce (SUM) over G ranks: S = sum of the ranks' moves, Q = sum of their
+// squared lengths.  Each node end moves by S * f with f = clamp(Q / |S|^2, 1/G, 1): ranks that
+// pulled the end the same way (coherent moves, |S|^2 = G*Q: every rank already made the full
+// correction) are averaged, f = 1/G; uncorrelated small steps (|S|^2 ~ Q) add up, f = 1.
+template <int FMT>
+__global__ void exchange_apply_kernel(uint64_t* coords, uint64_t* base, uint64_t n_ends, Xform xf, const float* buf, float inv_world) {
+    const float2* S = reinterpret_cast<const float2*>(buf);
+    const float* Q = buf + 2 * n_ends;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float2 d = S[i];
+        const float s2 = d.x * d.x + d.y * d.y;
+        const float f = s2 > 0.0f ? fminf(fmaxf(Q[i] / s2, inv_world), 1.0f) : 1.0f;
+        const uint64_t b = base[i];
+        uint64_t w;
+        if (FMT == kFmtQ32) {
+            const int64_t qx = (int64_t)rintf(d.x * f * xf.scale), qy = (int64_t)rintf(d.y * f * xf.scale);
+            w = (uint64_t)(uint32_t)((int64_t)(uint32_t)b + qx) | ((uint64_t)(uint32_t)((int64_t)(b >> 32) + qy) << 32);
+        } else {
+            w = (uint64_t)__float_as_uint(__uint_as_float((uint32_t)b) + d.x * f) |
+                ((uint64_t)__float_as_uint(__uint_as_float((uint32_t)(b >> 32)) + d.y * f) << 32);
+        }
+        coords[i] = w;
+        base[i] = w;
+    }
+}
+
+}  // namespace pgsgd

@@ -102,8 +102,9 @@ class DistributedLayout:
         if exchanges_per_iteration is None:
             # measured with G virtual ranks on one MI355X (profiles/r01/virtual_ranks_*.jsonl): the per-lane
             # kernel (small graphs) needs 4 exchanges per iteration to keep G = 1 quality, the tile kernel is
-            # insensitive between 1 and 4 and pays ~5 % of kernel time per extra exchange at G = 8
-            exchanges_per_iteration = 1 if self.world == 1 else (2 if getattr(engine, "tiled", False) else 4)
+            # insensitive between 1 and 4 (stress within 5-17 % of G = 1 either way) and every exchange is a
+            # 24 MB all-reduce against ~3 ms of kernels per iteration and rank at G = 8: one per iteration
+            exchanges_per_iteration = 1 if self.world == 1 else (1 if getattr(engine, "tiled", False) else 4)
         self.blocks = max(1, int(exchanges_per_iteration)) if self.world > 1 else 1
         self.etas = path_linear_sgd_layout_schedule(params)
         self.first_cooling = int(math.floor(params.cooling_start * float(params.iter_max)))

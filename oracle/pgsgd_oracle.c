@@ -246,7 +246,7 @@ static inline double update_f64(const orc_graph* g, const orc_term* t, double et
     return fabs(Delta);
 }
 
-/* ---- mirrors of the HIP kernel (odgi_amd/csrc/pgsgd_device.hip: sgd_iteration_kernel) ----------
+/* ---- mirrors of the HIP kernel (odgi_amd/csrc/pgsgd_kernels.hpp: sgd_iteration_kernel) ----------
  * One anchor group = one first step with `mt` partners.  The anchor node's two ends are loaded once,
  * each term's anchor-side displacement is applied to that private copy at once and reaches memory as
  * one update per touched end when the group ends; partner-side updates go out term by term.
@@ -392,7 +392,7 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
     free(zetas);
 }
 
-/* Terms of the tile kernel (odgi_amd/csrc/pgsgd_device.hip: sgd_tile_kernel / tile_trace_kernel): term q of an
+/* Terms of the tile kernel (odgi_amd/csrc/pgsgd_tiles.hpp: sgd_tile_kernel / tile_trace_kernel): term q of an
  * iteration of n_terms terms belongs to the tile whose share [cum*M/S_tot, (cum+n)*M/S_tot) contains q; it has
  * its own generator seeded with seed_base + epoch*0x9e3779b97f4a7c15 + q, draws its first step uniformly in the
  * tile and its partner by the reference rule. */

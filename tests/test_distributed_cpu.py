@@ -50,7 +50,7 @@ class OracleEngine:
     def sync(self):
         return self._dmax
 
-    # the exchange of odgi_amd/csrc/pgsgd_device.hip (exchange_prepare/apply kernels), in numpy
+    # the exchange of odgi_amd/csrc/pgsgd_kernels.hpp (exchange_prepare/apply kernels), in numpy
     def new_exchange_buffer(self):
         return torch.zeros(6 * len(self.coords), dtype=torch.float32)
 

@@ -69,6 +69,36 @@ def test_sampler_other_theta_and_quantisation(oa, orc, graphs, ographs):
         assert np.array_equal(got, want)
 
 
+def test_many_paths_use_the_global_path_table(oa, orc):
+    """More than 4095 paths: the path table no longer fits the LDS staging and is searched in global
+    memory (the PF_LDS = false instances).  Sampler bit-exact, one-stream run bit-exact, layout sane."""
+    rs = np.random.RandomState(11)
+    n_nodes, n_paths = 3000, 5000
+    node_len = rs.randint(1, 40, n_nodes).astype(np.uint32)
+    counts = rs.randint(1, 30, n_paths)           # includes single-step paths
+    first = np.r_[0, np.cumsum(counts)].astype(np.uint64)
+    starts = rs.randint(0, n_nodes - 40, n_paths)
+    handles = np.concatenate([(2 * (s + np.arange(c)) + (rs.rand(c) < 0.1)).astype(np.uint32) for s, c in zip(starts, counts)])
+    g = oa.Graph.from_arrays(node_len, first, handles)
+    og = orc.Graph.from_product(g)
+    p = _params(oa, g, n_streams=192, flags=8)
+    for cooling in (False, True):
+        with oa.LayoutSession(g, p) as s:
+            got = s.trace_terms(cooling, 40)
+        assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p), p.seed, 192, 0, cooling, 40))
+    X0, Y0 = oa.initial_layout(g, "d", seed=2)
+    p1 = _params(oa, g, n_streams=1, iter_max=5, min_term_updates=2500)
+    Xg, Yg, dmax_g, fmt, w0, w1 = _run_session(oa, g, p1, X0, Y0)
+    Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p1), p1.seed, 1, X0, Y0, fmt[1], fmt[2], fmt[3])
+    assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo) and dmax_g == dmax_o
+    X, Y = X0.copy(), Y0.copy()
+    st = oa.path_linear_sgd_layout_gpu(g, _params(oa, g), X, Y)
+    Xc, Yc, _ = orc.layout_hogwild(og, orc.params_from(_params(oa, g)), 4, X0, Y0)
+    s_gpu, s_cpu = orc.path_stress_sampled(og, X, Y, 300_000), orc.path_stress_sampled(og, Xc, Yc, 300_000)
+    print(f"5000 paths: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} streams {st['n_streams']}")
+    assert np.isfinite(X).all() and s_gpu <= 1.3 * s_cpu + 0.05
+
+
 def test_single_step_and_ragged_paths(oa, orc, tmp_path):
     """Edge cases of the sampler: single-step paths are skipped (path_sgd_layout.cpp:189-192),
     two-step paths force the jump direction, an empty path owns no steps."""

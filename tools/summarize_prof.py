@@ -39,7 +39,7 @@ with open(os.path.join(dst, f"rocprof_pmc_{tag}.csv"), "w", newline="") as f:
         for cname, vals in cs.items():
             w.writerow([name, cname, len(vals), sum(v for v, _ in vals) / len(vals), sum(d for _, d in vals) / len(vals)])
 sgd = [k for k in counters if "sgd_iteration_kernel" in k or "sgd_tile_kernel" in k]
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --steps 5 --warmup 1` ({tag}); "
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --cpu-seconds 0` ({tag}); "
                  "profiles/" + os.path.basename(dst) + f"/rocprof_pmc_{tag}.csv"}
 if sgd:
     c = counters[sgd[0]]
