@@ -235,6 +235,18 @@ int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, const double* 
 int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, const double* Y,
                         double* per_node, double* per_bp);
 
+/* ---- 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500) -- */
+/* Same sampler as the layout, one coordinate per node, the reference's 1D rules (adj_theta = 0.001 once
+ * cooling, terms of path distance 0 dropped, iterations 0..iter_max).  X: host fp64 [n_nodes], updated in place. */
+int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p); /* sort_main.cpp:313-320,378-414 */
+int pgsgd_sort_initial(const pgsgd_graph_view* g, double* X);               /* path_sgd.cpp:67-73 */
+int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, pgsgd_stats* stats);
+int pgsgd_sort_order(uint64_t n_nodes, const double* X, uint64_t* order);   /* path_sgd.cpp:641-650 */
+int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uint64_t n_pairs, uint64_t seed, double* stress);
+/* parity hook: out[(j*n_streams+g)*2 + {0,1}] = flat steps a, b of fresh stream g's j-th term */
+int pgsgd_sort_trace_terms(const pgsgd_graph_view* g, const pgsgd_params* p, int cooling, uint64_t terms_per_stream,
+                           uint64_t* out, uint32_t* n_streams);
+
 /* ---- the subcommand: argv as `odgi layout` takes it (layout_main.cpp:18-466) --------------- */
 int pgsgd_main_layout(int argc, char** argv);
 

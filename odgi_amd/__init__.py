@@ -8,6 +8,7 @@ Host-side mirror of the reference interface for this one path:
   LayoutSession              <- one eta step at a time (multi-GPU driver, benchmark)
   Layout                     <- src/algorithms/layout.hpp:24-40 (.lay / TSV)
   main_layout(argv)          <- the subcommand itself
+  path_linear_sgd, path_linear_sgd_order  <- src/algorithms/path_sgd.hpp (the 1D sibling behind `odgi sort -Y`)
 Everything computes through libpgsgd.so (HIP, gfx950); nothing here falls back to the CPU.
 """
 from .graph import Graph
@@ -15,6 +16,9 @@ from .layout import (Layout, LayoutParams, LayoutSession, initial_layout, main_l
                      path_linear_sgd_layout_gpu, path_linear_sgd_layout_schedule, zeta_table,
                      path_stress, path_distance)
 
-__all__ = ["Graph", "Layout", "LayoutParams", "LayoutSession", "initial_layout", "main_layout",
+from .sort import path_linear_sgd, path_linear_sgd_order, sort_params_defaults, sort_stress
+
+__all__ = ["path_linear_sgd", "path_linear_sgd_order", "sort_params_defaults", "sort_stress",
+           "Graph", "Layout", "LayoutParams", "LayoutSession", "initial_layout", "main_layout",
            "path_linear_sgd_layout_gpu", "path_linear_sgd_layout_schedule", "zeta_table",
            "path_stress", "path_distance"]

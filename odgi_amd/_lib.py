@@ -99,6 +99,12 @@ SIGNATURES = [
     ("pgsgd_free", None, [C.c_void_p]),
     ("pgsgd_path_stress", C.c_int, [P(GraphView), P(f64), P(f64), u64, u64, P(f64)]),
     ("pgsgd_path_distance", C.c_int, [P(GraphView), P(f64), P(f64), P(f64), P(f64)]),
+    ("pgsgd_sort_params_defaults", C.c_int, [P(GraphView), P(Params)]),
+    ("pgsgd_sort_initial", C.c_int, [P(GraphView), P(f64)]),
+    ("pgsgd_sort_run", C.c_int, [P(GraphView), P(Params), P(f64), P(Stats)]),
+    ("pgsgd_sort_order", C.c_int, [u64, P(f64), P(u64)]),
+    ("pgsgd_sort_stress", C.c_int, [P(GraphView), P(f64), u64, u64, P(f64)]),
+    ("pgsgd_sort_trace_terms", C.c_int, [P(GraphView), P(Params), C.c_int, u64, P(u64), P(u32)]),
     ("pgsgd_main_layout", C.c_int, [C.c_int, P(C.c_char_p)]),
 ]
 for _name, _res, _args in SIGNATURES:

@@ -397,6 +397,124 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500): the layout's
+// sibling — same first-step/partner sampler, one coordinate per node, no end choice.  Differences:
+// the Zipf draw uses adj_theta = 0.001 once cooling starts while the zeta cache keeps the user's theta
+// (:127-137,195,246); a term of path distance 0 is dropped uncounted (:320-323).
+// Coordinates: one signed 64-bit fixed-point word per node, x = q * inv_scale, moved with one 64-bit
+// integer atomic per node; arithmetic in fp64 like the reference.
+struct SortArgs {
+    long long* X;
+    double scale, inv_scale;
+    ZipfConst zc_cool;  // theta = 0.001
+    uint64_t n_terms;
+    double eta;
+    uint32_t cooling;
+};
+
+struct Term1D {
+    uint64_t ka, kb, pos_a, pos_b;
+    uint32_t node_a, node_b;
+};
+
+template <typename PF>
+__device__ __forceinline__ Term1D sample_term_1d(const DevConst& c, const PF pf, const SortArgs& sa, Xoshiro256Plus& rng) {
+    Term1D t;
+    for (;;) {
+        const Anchor a = sample_anchor(c, pf, rng);
+        uint64_t b_rank;
+        if (sa.cooling || coin(rng)) {                                            // path_sgd.cpp:245
+            const bool back = (a.s_rank > 0 && coin(rng)) || a.s_rank == a.cnt - 1;  // :247
+            const uint64_t room = back ? a.s_rank : a.cnt - a.s_rank - 1;
+            const uint64_t jump = c.space < room ? c.space : room;
+            const double zeta_n = c.zetas[zeta_index(jump, c.space_max, c.space_quant)];
+            const uint64_t z = zipf(rng, sa.cooling ? sa.zc_cool : c.zc, jump, zeta_n);
+            b_rank = back ? a.s_rank - z : a.s_rank + z;
+        } else {
+            b_rank = uniform_below(rng, a.cnt);                                   // :275-277
+        }
+        t.ka = a.k;
+        t.kb = a.pstart + b_rank;
+        const uint4 rb = c.recs[t.kb];
+        t.pos_a = (uint64_t)a.rec.z | ((uint64_t)a.rec.w << 32);
+        t.pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+        t.node_a = a.rec.x >> 1;
+        t.node_b = rb.x >> 1;
+        if (t.pos_a != t.pos_b) return t;                                         // :320-323
+    }
+}
+
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void sort_iteration_kernel(DevConst c, SortArgs sa) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    float dmax = 0.0f;
+    for (uint64_t ti = g; ti < sa.n_terms; ti += L) {
+        const Term1D t = sample_term_1d(c, pf, sa, rng);
+        const long long qa = __hip_atomic_load(sa.X + t.node_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long qb = __hip_atomic_load(sa.X + t.node_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
+        const double term_dist = (double)(uint64_t)(diff < 0 ? -diff : diff);     // :316-318
+        double mu = sa.eta * (1.0 / term_dist);                                   // :328-332
+        if (mu > 1.0) mu = 1.0;
+        double dx = (double)(qa - qb) * sa.inv_scale;
+        if (dx == 0.0) dx = 1e-9;
+        const double mag = fabs(dx);
+        const double Delta = mu * (mag - term_dist) / 2.0;                        // :355
+        const double r_x = (Delta / mag) * dx;
+        const long long dq = __double2ll_rn(r_x * sa.scale);
+        atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_b), (unsigned long long)dq);
+        atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_a), (unsigned long long)(-dq));
+        dmax = fmaxf(dmax, (float)fabs(Delta));
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void sort_trace_kernel(DevConst c, SortArgs sa, uint64_t seed_base, uint64_t terms_per_stream, uint64_t* out) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    rng.seed(seed_base + g);
+    for (uint64_t j = 0; j < terms_per_stream; ++j) {
+        const Term1D t = sample_term_1d(c, pf, sa, rng);
+        uint64_t* o = out + (j * (uint64_t)c.n_streams + g) * 2;
+        o[0] = t.ka;
+        o[1] = t.kb;
+    }
+}
+
+__global__ void sort_pack_kernel(const double* X, uint64_t n, double scale, long long* W) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) W[i] = __double2ll_rn(X[i] * scale);
+}
+__global__ void sort_unpack_kernel(const long long* W, uint64_t n, double inv_scale, double* X) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) X[i] = (double)W[i] * inv_scale;
+}
+
 // sampler-only launch for parity checks: fresh streams, nothing is modified
 template <bool PF_LDS>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DevConst c, uint32_t cooling, uint64_t seed_base,

@@ -919,3 +919,181 @@ int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const
     for (uint64_t i = 0; i < n_ends; ++i) { dx[i] = X[i]; dy[i] = Y[i]; }
     return pgsgd_write_lay(path, n_ends, dx.data(), dy.data());
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// 1D path-guided SGD (`odgi sort -Y`, reference src/algorithms/path_sgd.cpp:12-500): SURVEY 8(f) row 2.
+// Runs the per-lane 1D kernel on a session's step records, path table, zeta cache and streams.
+
+// reference defaults of `odgi sort -Y` (src/subcommand/sort_main.cpp:313-320,378-414)
+extern "C" int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p) {
+    int rc = pgsgd_params_defaults(g, p);
+    if (rc) return rc;
+    uint64_t max_steps = 0, max_bp = 0;
+    for (uint64_t i = 0; i < g->n_paths; ++i) {
+        const uint64_t b = g->path_first[i], e = g->path_first[i + 1];
+        max_steps = std::max(max_steps, e - b);
+        if (e > b) max_bp = std::max(max_bp, g->step_pos[e - 1] + g->node_len[g->step_handle[e - 1] >> 1]);
+    }
+    p->iter_max = 100;                                                    // :313
+    p->min_term_updates = (uint64_t)(1.0 * (double)g->n_steps);           // :383
+    p->eta_max = (double)max_steps * (double)max_steps;                   // :414
+    p->space = max_bp;                                                    // :387 get_max_path_length (nucleotides)
+    p->space_max = 100;                                                   // :388
+    const uint64_t max_dist = std::max<uint64_t>(p->space_max + 1, 100);  // :390-394, MAX_NUMBER_OF_ZIPF_DISTRIBUTIONS = 100
+    if (p->space > p->space_max && max_dist > p->space_max)               // :404-410
+        p->space_quantization_step = std::max<uint64_t>(2, (uint64_t)std::ceil((double)(p->space - p->space_max) / (double)(max_dist - p->space_max)));
+    else
+        p->space_quantization_step = 100;
+    return PGSGD_OK;
+}
+
+static int sort_session(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** s) {
+    pgsgd_params q = *p;
+    q.flags |= PGSGD_FLAG_NO_TILES;  // the 1D path has a per-lane kernel only
+    q.terms_per_anchor = 1;
+    q.snapshot = 0;
+    return pgsgd_session_create(g, &q, s);
+}
+
+static pgsgd::SortArgs sort_args(const pgsgd_session* s, long long* d_x, double scale) {
+    pgsgd::SortArgs sa;
+    sa.X = d_x;
+    sa.scale = scale;
+    sa.inv_scale = 1.0 / scale;
+    sa.zc_cool.init(0.001);  // adj_theta once cooling starts, path_sgd.cpp:195
+    sa.n_terms = 0;
+    sa.eta = 0;
+    sa.cooling = 0;
+    (void)s;
+    return sa;
+}
+
+// X: host fp64 [n_nodes], pre-initialised (the reference starts from the cumulative node length,
+// path_sgd.cpp:67-73), updated in place.  Iterations 0..iter_max (:181), cooling when
+// iteration > floor(cooling_start*iter_max) (:194), stop when max|Delta| <= delta (:183).
+extern "C" int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, pgsgd_stats* stats) {
+    pgsgd::clear_error();
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!g || !p || !X) return PGSGD_E_INVALID;
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    bool multi = false;
+    for (uint64_t i = 0; i < g->n_paths && !multi; ++i) multi = g->path_first[i + 1] - g->path_first[i] > 1;
+    if (!multi) {
+        int dev;
+        return pick_device(p->device, &dev);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    pgsgd_session* s = nullptr;
+    rc = sort_session(g, p, &s);
+    if (rc) return rc;
+    const uint64_t N = g->n_nodes;
+    const double scale = 65536.0;  // quanta per bp: +-1.4e14 bp of range in a signed 64-bit word
+    long long* d_x = nullptr;
+    double* d_f = nullptr;
+    auto cleanup = [&](int code) {
+        if (d_x) (void)hipFree(d_x);
+        if (d_f) (void)hipFree(d_f);
+        pgsgd_session_destroy(s);
+        return code;
+    };
+#define T_TRY(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return cleanup(PGSGD_E_HIP);                                                        \
+        }                                                                                       \
+    } while (0)
+    T_TRY(hipMalloc(&d_x, N * sizeof(long long)));
+    T_TRY(hipMalloc(&d_f, N * sizeof(double)));
+    T_TRY(hipMemcpyAsync(d_f, X, N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    const int sgrid = (int)std::min<uint64_t>((N + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::sort_pack_kernel, dim3(sgrid), dim3(256), 0, s->stream, d_f, N, scale, d_x);
+    T_TRY(hipGetLastError());
+    std::vector<double> etas(p->iter_max + 1);
+    if (pgsgd_schedule(p, etas.data(), etas.size()) < 0) return cleanup(PGSGD_E_INVALID);
+    const uint64_t first_cooling = (uint64_t)std::floor(p->cooling_start * (double)p->iter_max);
+    const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
+    const uint32_t grid = (s->n_streams + block - 1) / block;
+    pgsgd::SortArgs sa = sort_args(s, d_x, scale);
+    hipEvent_t e0, e1;
+    T_TRY(hipEventCreate(&e0));
+    T_TRY(hipEventCreate(&e1));
+    uint64_t iters = 0, terms = 0;
+    double dmax = 0, kernel_ms = 0;
+    uint32_t early = 0;
+    for (uint64_t it = 0; it <= p->iter_max; ++it) {
+        sa.n_terms = p->min_term_updates;
+        sa.eta = etas[it];
+        sa.cooling = it > first_cooling ? 1u : 0u;
+        T_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
+        T_TRY(hipEventRecord(e0, s->stream));
+        if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sort_iteration_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, sa);
+        else hipLaunchKernelGGL((pgsgd::sort_iteration_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, sa);
+        T_TRY(hipGetLastError());
+        T_TRY(hipEventRecord(e1, s->stream));
+        T_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        T_TRY(hipStreamSynchronize(s->stream));
+        float ms = 0, f;
+        T_TRY(hipEventElapsedTime(&ms, e0, e1));
+        kernel_ms += ms;
+        memcpy(&f, s->h_delta_max, sizeof f);
+        dmax = f;
+        ++iters;
+        terms += p->min_term_updates;
+        if (p->progress)
+            fprintf(stderr, "\r[odgi::path_linear_sgd] 1D path-guided SGD: iteration %llu/%llu  eta %.4g  delta_max %.4g   ",
+                    (unsigned long long)(it + 1), (unsigned long long)(p->iter_max + 1), etas[it], dmax);
+        if (it < p->iter_max && dmax <= p->delta) { early = 1; break; }
+    }
+    if (p->progress) fprintf(stderr, "\n");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipLaunchKernelGGL(pgsgd::sort_unpack_kernel, dim3(sgrid), dim3(256), 0, s->stream, d_x, N, 1.0 / scale, d_f);
+    T_TRY(hipGetLastError());
+    T_TRY(hipMemcpyAsync(X, d_f, N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    T_TRY(hipStreamSynchronize(s->stream));
+    if (stats) {
+        stats->iterations = iters;
+        stats->term_updates = terms;
+        stats->last_delta_max = dmax;
+        stats->kernel_ms = kernel_ms;
+        stats->n_streams = s->n_streams;
+        stats->early_stop = early;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return cleanup(PGSGD_OK);
+#undef T_TRY
+}
+
+// parity hook: out[(j*n_streams+g)*2 + {0,1}] = flat steps a, b of stream g's j-th term (fresh streams)
+extern "C" int pgsgd_sort_trace_terms(const pgsgd_graph_view* g, const pgsgd_params* p, int cooling, uint64_t terms_per_stream,
+                                      uint64_t* out, uint32_t* n_streams_out) {
+    pgsgd::clear_error();
+    if (!g || !p || !out) return PGSGD_E_INVALID;
+    pgsgd_session* s = nullptr;
+    int rc = sort_session(g, p, &s);
+    if (rc) return rc;
+    if (n_streams_out) *n_streams_out = s->n_streams;
+    const size_t n = (size_t)terms_per_stream * s->n_streams * 2;
+    uint64_t* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_out, n * sizeof(uint64_t));
+    if (e == hipSuccess) {
+        pgsgd::SortArgs sa = sort_args(s, nullptr, 65536.0);
+        sa.cooling = cooling ? 1u : 0u;
+        const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
+        const uint32_t grid = (s->n_streams + block - 1) / block;
+        const uint64_t seed_base = p->seed + (uint64_t)p->stream_offset;
+        if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sort_trace_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, sa, seed_base, terms_per_stream, d_out);
+        else hipLaunchKernelGGL((pgsgd::sort_trace_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, sa, seed_base, terms_per_stream, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        (void)hipFree(d_out);
+    }
+    pgsgd_session_destroy(s);
+    if (e != hipSuccess) { set_error("1D trace failed: %s", hipGetErrorString(e)); return PGSGD_E_HIP; }
+    return PGSGD_OK;
+}

@@ -89,3 +89,73 @@ extern "C" int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, c
     if (per_bp) *per_bp = bp ? sum2d / (double)bp : 0.0;
     return PGSGD_OK;
 }
+
+
+// ---- 1D (odgi sort -Y) helpers ----------------------------------------------------------------
+// Node order from 1D positions: by position, ties by handle (path_sgd.cpp:641-650; the component
+// key of the reference's comparator reads a vector it has just cleared, :587, so only these two act).
+extern "C" int pgsgd_sort_order(uint64_t n_nodes, const double* X, uint64_t* order) {
+    pgsgd::clear_error();
+    if (!X || !order) return PGSGD_E_INVALID;
+    for (uint64_t i = 0; i < n_nodes; ++i) order[i] = i;
+    std::sort(order, order + n_nodes, [&](uint64_t a, uint64_t b) { return X[a] < X[b] || (X[a] == X[b] && a < b); });
+    return PGSGD_OK;
+}
+
+// reference start: X[rank] = cumulative node length in graph order (path_sgd.cpp:67-73)
+extern "C" int pgsgd_sort_initial(const pgsgd_graph_view* g, double* X) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X) return PGSGD_E_INVALID;
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) { X[i] = (double)len; len += g->node_len[i]; }
+    return PGSGD_OK;
+}
+
+// 1D path stress: mean ((|x_a - x_b| - d)/d)^2 over pairs drawn by the sampler's non-cooling mode (step starts)
+extern "C" int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uint64_t n_pairs, uint64_t seed, double* stress) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X || !stress) return PGSGD_E_INVALID;
+    *stress = 0.0;
+    uint64_t max_steps = 0;
+    for (uint64_t p = 0; p < g->n_paths; ++p) max_steps = std::max(max_steps, g->path_first[p + 1] - g->path_first[p]);
+    if (max_steps < 2) return PGSGD_OK;
+    const uint64_t space = max_steps, space_max = 100, quant = 100;
+    std::vector<double> zetas(pgsgd_zeta_table_size(space, space_max, quant));
+    rc = pgsgd_zeta_table(0.99, space, space_max, quant, zetas.data(), zetas.size());
+    if (rc) return rc;
+    pgsgd::ZipfConst zc;
+    zc.init(0.99);
+    pgsgd::Xoshiro256Plus rng;
+    rng.seed(seed);
+    double acc = 0.0;
+    uint64_t cnt = 0;
+    for (uint64_t n = 0; n < n_pairs; ++n) {
+        const uint64_t k = pgsgd::uniform_below(rng, g->n_steps);
+        const uint64_t p = g->step_path[k];
+        const uint64_t pstart = g->path_first[p], c = g->path_first[p + 1] - pstart;
+        if (c == 1) continue;
+        const uint64_t s_rank = k - pstart;
+        uint64_t b_rank;
+        if (pgsgd::coin(rng)) {
+            const bool back = (s_rank > 0 && pgsgd::coin(rng)) || s_rank == c - 1;
+            const uint64_t room = back ? s_rank : c - s_rank - 1;
+            const uint64_t jump = std::min(space, room);
+            const uint64_t z = pgsgd::zipf(rng, zc, jump, zetas[pgsgd::zeta_index(jump, space_max, quant)]);
+            b_rank = back ? s_rank - z : s_rank + z;
+        } else {
+            b_rank = pgsgd::uniform_below(rng, c);
+        }
+        const uint64_t kb = pstart + b_rank;
+        const double d = std::fabs((double)g->step_pos[k] - (double)g->step_pos[kb]);
+        if (d == 0) continue;
+        const double e = (std::fabs(X[g->step_handle[k] >> 1] - X[g->step_handle[kb] >> 1]) - d) / d;
+        acc += e * e;
+        ++cnt;
+    }
+    *stress = cnt ? acc / (double)cnt : 0.0;
+    return PGSGD_OK;
+}

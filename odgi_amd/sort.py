@@ -1,0 +1,74 @@
+"""1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.hpp / path_sgd.cpp) over the C ABI.
+
+`path_linear_sgd` returns the 1D node positions, `path_linear_sgd_order` the node order derived from
+them, like the reference functions of the same names; the work runs on the GPU (libpgsgd.so)."""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+from .graph import Graph
+from .layout import LayoutParams
+
+_F64P = C.POINTER(C.c_double)
+
+
+def sort_params_defaults(graph: Graph, **overrides) -> LayoutParams:
+    """Defaults of `odgi sort -Y` (src/subcommand/sort_main.cpp:313-320,378-414)."""
+    p = _lib.Params()
+    check(lib.pgsgd_sort_params_defaults(C.byref(graph.view), C.byref(p)), "sort_params_defaults")
+    out = LayoutParams(iter_max=p.iter_max, iter_with_max_learning_rate=p.iter_with_max_learning_rate,
+                       min_term_updates=p.min_term_updates, delta=p.delta, eps=p.eps, eta_max=p.eta_max, theta=p.theta,
+                       space=p.space, space_max=p.space_max, space_quantization_step=p.space_quantization_step,
+                       cooling_start=p.cooling_start, seed=p.seed)
+    return dataclasses.replace(out, **overrides)
+
+
+def sort_initial(graph: Graph):
+    X = np.zeros(graph.n_nodes, dtype=np.float64)
+    check(lib.pgsgd_sort_initial(C.byref(graph.view), X.ctypes.data_as(_F64P)), "sort_initial")
+    return X
+
+
+def path_linear_sgd(graph: Graph, params: LayoutParams, X=None):
+    """1D positions of the nodes (path_sgd.cpp:12-500). Returns (X, stats)."""
+    X = sort_initial(graph) if X is None else np.ascontiguousarray(X, dtype=np.float64).copy()
+    st = _lib.Stats()
+    p = params.to_c()
+    check(lib.pgsgd_sort_run(C.byref(graph.view), C.byref(p), X.ctypes.data_as(_F64P), C.byref(st)), "sort_run")
+    return X, {f: getattr(st, f) for f, _ in _lib.Stats._fields_}
+
+
+def order_from_positions(X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    order = np.zeros(len(X), dtype=np.uint64)
+    check(lib.pgsgd_sort_order(len(X), X.ctypes.data_as(_F64P), order.ctypes.data_as(C.POINTER(C.c_uint64))), "sort_order")
+    return order
+
+
+def path_linear_sgd_order(graph: Graph, params: LayoutParams):
+    """Node ranks in their new order (path_sgd.cpp:503-686, without the graph rewrite)."""
+    X, st = path_linear_sgd(graph, params)
+    return order_from_positions(X), X, st
+
+
+def sort_stress(graph: Graph, X, n_pairs=1_000_000, seed=0x5eed):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    s = C.c_double()
+    check(lib.pgsgd_sort_stress(C.byref(graph.view), X.ctypes.data_as(_F64P), n_pairs, seed, C.byref(s)), "sort_stress")
+    return s.value
+
+
+def trace_terms_1d(graph: Graph, params: LayoutParams, cooling, terms_per_stream):
+    """Parity hook: uint64 [terms_per_stream, n_streams, 2] = (ka, kb) of fresh streams."""
+    if not params.n_streams:
+        raise ValueError("trace_terms_1d needs an explicit n_streams")
+    out = np.zeros((terms_per_stream, params.n_streams, 2), dtype=np.uint64)
+    n = C.c_uint32()
+    p = params.to_c()
+    check(lib.pgsgd_sort_trace_terms(C.byref(graph.view), C.byref(p), 1 if cooling else 0, terms_per_stream,
+                                     out.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n)), "sort_trace_terms")
+    assert n.value == params.n_streams
+    return out

@@ -74,6 +74,14 @@ def _load(name):
                                            C.c_uint32, _F64P, _F64P]
     lib.orc_layout_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, _F64P,
                                        C.POINTER(HogStats)]
+    lib.orc_sort_initial.argtypes = [C.POINTER(OrcGraph), _F64P]
+    lib.orc_sort_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.c_uint64, _U64P]
+    lib.orc_sort_streams.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_double,
+                                     _F64P, _F64P]
+    lib.orc_sort_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, C.POINTER(HogStats)]
+    lib.orc_sort_stress.argtypes = [C.POINTER(OrcGraph), _F64P, C.c_uint64, C.c_uint64]
+    lib.orc_sort_stress.restype = C.c_double
     lib.orc_path_stress_sampled.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P, C.c_uint64, C.c_uint64]
     lib.orc_path_stress_sampled.restype = C.c_double
     lib.orc_path_stress_exhaustive.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P]
@@ -229,3 +237,36 @@ def path_distance(g, X, Y):
     a, b = C.c_double(), C.c_double()
     lib().orc_path_distance(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+# ---- 1D path-guided SGD (odgi sort -Y) ---------------------------------------------------------
+def sort_initial(g):
+    X = np.zeros(g.n_nodes)
+    lib().orc_sort_initial(C.byref(g.view), X.ctypes.data_as(_F64P))
+    return X
+
+
+def sort_trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream):
+    out = np.zeros((terms_per_stream, n_streams, 2), dtype=np.uint64)
+    lib().orc_sort_trace_terms(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, 1 if cooling else 0, terms_per_stream,
+                               out.ctypes.data_as(_U64P))
+    return out
+
+
+def sort_streams(g, p, seed, n_streams, X, quanta_per_bp=65536.0, stream_offset=0):
+    X = _d(X).copy()
+    d = C.c_double()
+    lib().orc_sort_streams(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, quanta_per_bp, X.ctypes.data_as(_F64P), C.byref(d))
+    return X, d.value
+
+
+def sort_hogwild(g, p, nthreads, X, max_seconds=0.0, fast=False):
+    X = _d(X).copy()
+    st = HogStats()
+    lib(fast).orc_sort_hogwild(C.byref(g.view), C.byref(p), nthreads, max_seconds, X.ctypes.data_as(_F64P), C.byref(st))
+    return X, {"terms": st.terms, "iterations": st.iterations, "seconds": st.seconds}
+
+
+def sort_stress(g, X, n_pairs=1_000_000, seed=0x5eed):
+    X = _d(X)
+    return lib().orc_sort_stress(C.byref(g.view), X.ctypes.data_as(_F64P), n_pairs, seed)

@@ -800,3 +800,237 @@ void orc_path_distance(const orc_graph* g, const double* X, const double* Y, dou
     if (per_node) *per_node = nodes ? sum2d / (double)nodes : 0.0;
     if (per_bp) *per_bp = bp ? sum2d / (double)bp : 0.0;
 }
+
+
+/* =========================================================================================== */
+/* 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500): the sibling of
+ * the layout path — same sampler, one coordinate per node, no end choice.  Differences restated here:
+ *   - X[n] starts at the cumulative node length in graph order (:67-73);
+ *   - the Zipf draw uses adj_theta, which the controller sets to 0.001 once cooling starts (:195,246),
+ *     while the zeta cache stays the one of the user's theta (:127-137);
+ *   - a term of path distance 0 is dropped without being counted (:320-323);
+ *   - the controller stops when iteration > iter_max and cools when iteration > first_cooling (:181,194),
+ *     so iter_max + 1 learning rates etas[0..iter_max] are used. */
+static int orc_sample_term_1d(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
+                              uint64_t s[4], orc_term* t) {
+    orc_anchor a;
+    if (!orc_sample_anchor(g, s, &a)) return 0;
+    const double theta = cooling ? 0.001 : p->theta;                   /* adj_theta, :195,246 */
+    const uint64_t s_rank = a.s_rank, cnt = a.cnt;
+    uint64_t b_rank;
+    if (cooling || orc_flip(s)) {                                      /* :245 */
+        if ((s_rank > 0 && orc_flip(s)) || s_rank == cnt - 1) {        /* :247 */
+            const uint64_t jump_space = p->space < s_rank ? p->space : s_rank;
+            uint64_t space = jump_space;
+            if (jump_space > p->space_max) space = p->space_max + (jump_space - p->space_max) / p->space_quantization_step + 1;
+            b_rank = s_rank - orc_zipf(s, jump_space, theta, zetas[space]);
+        } else {
+            const uint64_t rest = cnt - s_rank - 1;
+            const uint64_t jump_space = p->space < rest ? p->space : rest;
+            uint64_t space = jump_space;
+            if (jump_space > p->space_max) space = p->space_max + (jump_space - p->space_max) / p->space_quantization_step + 1;
+            b_rank = s_rank + orc_zipf(s, jump_space, theta, zetas[space]);
+        }
+    } else {
+        b_rank = orc_uniform_u64(s, cnt);                              /* :275-277 */
+    }
+    t->ka = a.k;
+    t->kb = a.pstart + b_rank;
+    t->pos_a = g->step_pos[t->ka];                                     /* :312-313 */
+    t->pos_b = g->step_pos[t->kb];
+    t->off_a = t->off_b = 0;
+    t->dither = 0;
+    return t->pos_a != t->pos_b;                                       /* :320-323 */
+}
+
+static inline double update_1d_f64(const orc_graph* g, const orc_term* t, double eta, double* X) {
+    const double term_dist = fabs((double)t->pos_a - (double)t->pos_b);
+    double mu = eta * (1.0 / term_dist);
+    if (mu > 1) mu = 1;
+    const uint64_t i = g->step_handle[t->ka] >> 1, j = g->step_handle[t->kb] >> 1;
+    double dx = X[i] - X[j];
+    if (dx == 0) dx = 1e-9;
+    const double mag = fabs(dx);
+    const double Delta = mu * (mag - term_dist) / 2;
+    const double r_x = (Delta / mag) * dx;
+    X[i] = X[i] - r_x;
+    X[j] = X[j] + r_x;
+    return fabs(Delta);
+}
+
+void orc_sort_initial(const orc_graph* g, double* X) {                 /* :67-73 */
+    uint64_t len = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) { X[i] = (double)len; len += g->node_len[i]; }
+}
+
+void orc_sort_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
+                          int cooling, uint64_t terms_per_stream, uint64_t* out) {
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    for (uint32_t gi = 0; gi < n_streams; ++gi) {
+        uint64_t s[4];
+        orc_rng_seed(seed + stream_offset + gi, s);
+        for (uint64_t j = 0; j < terms_per_stream; ++j) {
+            orc_term t;
+            while (!orc_sample_term_1d(g, p, zetas, cooling, s, &t)) { }
+            uint64_t* o = out + (j * (uint64_t)n_streams + gi) * 2;
+            o[0] = t.ka; o[1] = t.kb;
+        }
+    }
+    free(zetas);
+}
+
+/* mirror of the device's 1D kernel (odgi_amd/csrc/pgsgd_kernels.hpp: sort_iteration_kernel): one signed
+ * 64-bit fixed-point word per node (x = q / quanta_per_bp), fp64 arithmetic, round-to-nearest steps.
+ * Streams serialised like the 2D mirrors; bit-exact for n_streams == 1. */
+void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
+                      double quanta_per_bp, double* X, double* last_delta_max) {
+    if (last_delta_max) *last_delta_max = 0.0;
+    if (!has_multistep_path(g)) return;
+    stream_run r;
+    stream_run_init(&r, g, p, seed, n_streams, stream_offset);
+    int64_t* W = (int64_t*)malloc(g->n_nodes * sizeof(int64_t));
+    for (uint64_t i = 0; i < g->n_nodes; ++i) W[i] = (int64_t)llrint(X[i] * quanta_per_bp);
+    const double inv = 1.0 / quanta_per_bp;
+    const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    for (uint64_t iter = 0; iter <= p->iter_max; ++iter) {             /* etas[0..iter_max] */
+        const double eta = r.etas[iter];
+        const int cooling = iter > first_cooling;
+        double dmax = 0.0;
+        for (uint64_t t = 0; t < p->min_term_updates; ++t) {
+            uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
+            orc_term term;
+            while (!orc_sample_term_1d(g, p, r.zetas, cooling, s, &term)) { }
+            const double term_dist = fabs((double)term.pos_a - (double)term.pos_b);
+            double mu = eta * (1.0 / term_dist);
+            if (mu > 1) mu = 1;
+            const uint64_t i = g->step_handle[term.ka] >> 1, j = g->step_handle[term.kb] >> 1;
+            double dx = (double)(W[i] - W[j]) * inv;
+            if (dx == 0) dx = 1e-9;
+            const double mag = fabs(dx);
+            const double Delta = mu * (mag - term_dist) / 2;
+            const double r_x = (Delta / mag) * dx;
+            const int64_t dq = (int64_t)llrint(r_x * quanta_per_bp);
+            W[j] += dq;   /* partner first, then the first step: the device's order */
+            W[i] -= dq;
+            if (fabs(Delta) > dmax) dmax = fabs(Delta);
+        }
+        if (last_delta_max) *last_delta_max = dmax;
+        if (iter < p->iter_max && dmax <= p->delta) break;             /* :183 */
+    }
+    for (uint64_t i = 0; i < g->n_nodes; ++i) X[i] = (double)W[i] * inv;
+    free(W);
+    stream_run_free(&r);
+}
+
+/* the reference as it is (Hogwild workers + 1 ms controller), path_sgd.cpp:158-452 */
+typedef struct sort_shared {
+    const orc_graph* g; const orc_params* p; const double* zetas; const double* etas; double* X;
+    uint64_t first_cooling_iteration, term_updates, iteration, total_terms;
+    double eta, Delta_max, max_seconds; int cooling, work_todo; struct timespec t0;
+} sort_shared;
+typedef struct sort_worker { sort_shared* sh; uint64_t tid; } sort_worker;
+
+static void* sort_checker(void* arg) {
+    sort_shared* sh = (sort_shared*)arg;
+    const struct timespec ms = {0, 1000000};
+    while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&sh->term_updates, __ATOMIC_SEQ_CST) > sh->p->min_term_updates) {
+            sh->iteration++;
+            if (sh->iteration > sh->p->iter_max) {                     /* :181 */
+                __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+            } else if (ld_f64(&sh->Delta_max) <= sh->p->delta) {
+                __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+            } else {
+                st_f64(&sh->eta, sh->etas[sh->iteration]);
+                st_f64(&sh->Delta_max, sh->p->delta);
+                if (sh->iteration > sh->first_cooling_iteration) __atomic_store_n(&sh->cooling, 1, __ATOMIC_SEQ_CST);  /* :194 */
+            }
+            __atomic_store_n(&sh->term_updates, (uint64_t)0, __ATOMIC_SEQ_CST);
+        }
+        if (sh->max_seconds > 0 && seconds_since(&sh->t0) > sh->max_seconds) __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
+        nanosleep(&ms, NULL);
+    }
+    return NULL;
+}
+
+static void* sort_work(void* arg) {
+    sort_worker* w = (sort_worker*)arg;
+    sort_shared* sh = w->sh;
+    const orc_graph* g = sh->g;
+    uint64_t s[4];
+    orc_rng_seed(9399220ull + w->tid, s);
+    uint64_t local = 0, total = 0;
+    double* X = sh->X;
+    while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
+        orc_term t;
+        const int cooling = __atomic_load_n(&sh->cooling, __ATOMIC_SEQ_CST);
+        if (!orc_sample_term_1d(g, sh->p, sh->zetas, cooling, s, &t)) continue;
+        const double term_dist = fabs((double)t.pos_a - (double)t.pos_b);
+        double mu = ld_f64(&sh->eta) * (1.0 / term_dist);
+        if (mu > 1) mu = 1;
+        const uint64_t i = g->step_handle[t.ka] >> 1, j = g->step_handle[t.kb] >> 1;
+        double dx = ld_f64(&X[i]) - ld_f64(&X[j]);
+        if (dx == 0) dx = 1e-9;
+        const double mag = fabs(dx);
+        const double Delta = mu * (mag - term_dist) / 2;
+        const double Delta_abs = fabs(Delta);
+        while (Delta_abs > ld_f64(&sh->Delta_max)) st_f64(&sh->Delta_max, Delta_abs);
+        const double r_x = (Delta / mag) * dx;
+        st_f64(&X[i], ld_f64(&X[i]) - r_x);
+        st_f64(&X[j], ld_f64(&X[j]) + r_x);
+        if (++local >= 1000) { __atomic_fetch_add(&sh->term_updates, local, __ATOMIC_SEQ_CST); total += local; local = 0; }
+    }
+    total += local;
+    __atomic_fetch_add(&sh->total_terms, total, __ATOMIC_SEQ_CST);
+    return NULL;
+}
+
+void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, double* X, orc_hogwild_stats* st) {
+    if (st) { st->terms = 0; st->iterations = 0; st->seconds = 0; }
+    if (!has_multistep_path(g) || nthreads == 0) return;
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    double* etas = (double*)malloc((p->iter_max + 1) * sizeof(double));
+    orc_schedule(p, etas);
+    sort_shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.g = g; sh.p = p; sh.zetas = zetas; sh.etas = etas; sh.X = X;
+    sh.first_cooling_iteration = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    sh.eta = etas[0]; sh.work_todo = 1; sh.max_seconds = max_seconds;
+    clock_gettime(CLOCK_MONOTONIC, &sh.t0);
+    pthread_t checker;
+    pthread_t* th = (pthread_t*)malloc(nthreads * sizeof(pthread_t));
+    sort_worker* ws = (sort_worker*)malloc(nthreads * sizeof(sort_worker));
+    pthread_create(&checker, NULL, sort_checker, &sh);
+    for (uint32_t t = 0; t < nthreads; ++t) { ws[t].sh = &sh; ws[t].tid = t; pthread_create(&th[t], NULL, sort_work, &ws[t]); }
+    for (uint32_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    const double secs = seconds_since(&sh.t0);
+    pthread_join(checker, NULL);
+    if (st) { st->terms = sh.total_terms; st->iterations = sh.iteration; st->seconds = secs; }
+    free(th); free(ws); free(zetas); free(etas);
+}
+
+/* 1D path stress: mean ((|x_a - x_b| - d)/d)^2 over pairs drawn by the sampler's non-cooling mode */
+double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, uint64_t seed) {
+    if (!has_multistep_path(g)) return 0.0;
+    uint64_t max_steps = 0;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) { const uint64_t c = g->path_first[pi + 1] - g->path_first[pi]; if (c > max_steps) max_steps = c; }
+    orc_params p; memset(&p, 0, sizeof p);
+    p.theta = 0.99; p.space = max_steps; p.space_max = 100; p.space_quantization_step = 100;
+    double* zetas = (double*)malloc(orc_zeta_size(p.space, p.space_max, p.space_quantization_step) * sizeof(double));
+    orc_zetas(p.theta, p.space, p.space_max, p.space_quantization_step, zetas);
+    uint64_t s[4]; orc_rng_seed(seed, s);
+    double acc = 0.0; uint64_t cnt = 0;
+    for (uint64_t n = 0; n < n_pairs; ++n) {
+        orc_term t;
+        if (!orc_sample_term_1d(g, &p, zetas, 0, s, &t)) continue;
+        const double d = fabs((double)t.pos_a - (double)t.pos_b);
+        const double e = (fabs(X[g->step_handle[t.ka] >> 1] - X[g->step_handle[t.kb] >> 1]) - d) / d;
+        acc += e * e; cnt++;
+    }
+    free(zetas);
+    return cnt ? acc / (double)cnt : 0.0;
+}

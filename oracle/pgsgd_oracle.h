@@ -112,6 +112,15 @@ double orc_path_stress_exhaustive(const orc_graph* g, const double* X, const dou
 /* odgi stats -s, 2D branch (stats_main.cpp:667-716) */
 void orc_path_distance(const orc_graph* g, const double* X, const double* Y, double* per_node, double* per_bp);
 
+/* ---- 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500) ---- */
+void orc_sort_initial(const orc_graph* g, double* X /* [n_nodes] */);
+void orc_sort_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
+                          int cooling, uint64_t terms_per_stream, uint64_t* out /* [terms][streams][2] = ka, kb */);
+void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
+                      double quanta_per_bp, double* X, double* last_delta_max);
+void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, double* X, orc_hogwild_stats* st);
+double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,101 @@
+"""1D path-guided SGD (`odgi sort -Y`): oracle sanity on the CPU, GPU parity through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _shuffled_linear_graph(oa, n_nodes=4000, n_paths=6, seed=3):
+    """A linear pangenome whose node ranks are a random permutation of their true order: the 1D SGD
+    has to recover the order from the paths."""
+    rs = np.random.RandomState(seed)
+    true_order = rs.permutation(n_nodes)          # true position -> node rank
+    node_len = rs.randint(1, 20, n_nodes).astype(np.uint32)
+    handles, first = [], [0]
+    for _ in range(n_paths):
+        keep = rs.rand(n_nodes) > 0.05            # each path skips 5 % of the nodes
+        h = (2 * true_order[keep]).astype(np.uint32)
+        handles.append(h)
+        first.append(first[-1] + len(h))
+    g = oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
+    return g, true_order
+
+
+def _order_quality(order, true_order):
+    """Spearman-like: |correlation| between recovered position and true position of every node."""
+    n = len(order)
+    pos = np.empty(n)
+    pos[np.asarray(order, dtype=np.int64)] = np.arange(n)     # node rank -> recovered position
+    true_pos = np.empty(n)
+    true_pos[true_order] = np.arange(n)                        # node rank -> true position
+    return abs(np.corrcoef(pos, true_pos)[0, 1])
+
+
+def test_sort_defaults_follow_sort_main(oa, graphs):
+    from odgi_amd.sort import sort_params_defaults
+    g = graphs("DRB1-3123")
+    p = sort_params_defaults(g)
+    # sort_main.cpp:313-320,383-414: 100 iterations, 1*S terms, space = longest path in bp, one quantised bucket
+    path_bp = max(int(g.step_pos[e - 1]) + int(g.node_len[g.step_handle[e - 1] >> 1]) for e in g.path_first[1:].astype(np.int64))
+    assert (p.iter_max, p.min_term_updates, p.eta_max, p.space, p.space_max) == (100, 35059, 3100.0 ** 2, path_bp, 100)
+    assert p.space_quantization_step == path_bp - 100
+
+
+def test_oracle_1d_recovers_a_shuffled_order(oa, orc):
+    from odgi_amd.sort import sort_params_defaults
+    g, true_order = _shuffled_linear_graph(oa)
+    og = orc.Graph.from_product(g)
+    p = sort_params_defaults(g, iter_max=30, min_term_updates=10 * g.n_steps)
+    X0 = orc.sort_initial(og)
+    assert orc.sort_stress(og, X0, 200000) > 100
+    X, st = orc.sort_hogwild(og, orc.params_from(p), 4, X0)
+    assert st["iterations"] == 31                                     # iterations 0..iter_max (path_sgd.cpp:181)
+    assert orc.sort_stress(og, X, 200000) < 1.0
+    assert _order_quality(np.argsort(X, kind="stable"), true_order) > 0.99
+    Xs, _ = orc.sort_streams(og, orc.params_from(p), 9399220, 16, X0)
+    assert _order_quality(np.argsort(Xs, kind="stable"), true_order) > 0.99
+
+
+@pytest.mark.gpu
+def test_1d_sampler_streams_bit_exact(oa, orc, graphs, ographs):
+    from odgi_amd.sort import sort_params_defaults, trace_terms_1d
+    for name in ("DRB1-3123", "chr6.C4"):
+        g, og = graphs(name), ographs(name)
+        p = sort_params_defaults(g, n_streams=256, stream_offset=3, device=0)
+        for cooling in (False, True):                                 # cooling switches the Zipf theta to 0.001
+            got = trace_terms_1d(g, p, cooling, 24)
+            want = orc.sort_trace_terms(og, orc.params_from(p), p.seed, 256, 3, cooling, 24)
+            assert np.array_equal(got, want)
+            ka, kb = got[..., 0].astype(np.int64), got[..., 1].astype(np.int64)
+            assert np.all(g.step_pos[ka] != g.step_pos[kb])           # distance-0 terms are dropped (path_sgd.cpp:320)
+
+
+@pytest.mark.gpu
+def test_1d_one_stream_run_bit_exact(oa, orc, graphs, ographs):
+    from odgi_amd.sort import path_linear_sgd, sort_params_defaults
+    g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
+    p = sort_params_defaults(g, n_streams=1, iter_max=8, min_term_updates=2000, device=0)
+    Xg, st = path_linear_sgd(g, p)
+    Xo, dmax = orc.sort_streams(og, orc.params_from(p), p.seed, 1, orc.sort_initial(og))
+    assert st["iterations"] == 9 and st["term_updates"] == 9 * 2000
+    assert np.array_equal(Xg, Xo)
+    assert st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_1d_layout_and_order_match_oracle(oa, orc):
+    from odgi_amd.sort import path_linear_sgd_order, sort_params_defaults, sort_stress
+    g, true_order = _shuffled_linear_graph(oa, n_nodes=20000, n_paths=8)
+    og = orc.Graph.from_product(g)
+    p = sort_params_defaults(g, iter_max=30, min_term_updates=10 * g.n_steps, device=0)
+    order, X, st = path_linear_sgd_order(g, p)
+    Xo, _ = orc.sort_hogwild(og, orc.params_from(p), 4, orc.sort_initial(og))
+    s_gpu, s_cpu = orc.sort_stress(og, X, 500000), orc.sort_stress(og, Xo, 500000)
+    q_gpu, q_cpu = _order_quality(order, true_order), _order_quality(np.argsort(Xo, kind="stable"), true_order)
+    print(f"1D: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f}; order quality gpu {q_gpu:.5f} cpu {q_cpu:.5f}; streams {st['n_streams']}")
+    assert st["iterations"] == 31 and np.isfinite(X).all()
+    assert s_gpu <= 1.25 * s_cpu + 0.02 and q_gpu > 0.99 and q_gpu >= q_cpu - 0.005
+    assert sort_stress(g, X, 500000, seed=0x5eed) == pytest.approx(s_gpu, rel=1e-12)   # product and oracle evaluators agree
+    assert sorted(order.tolist()) == list(range(g.n_nodes))
