@@ -75,6 +75,10 @@ typedef struct pgsgd_graph_view {
                                            /* it: first steps stratified by tile, node windows in LDS   */
 #define PGSGD_FLAG_NO_FAR_CAP        0x10u /* tile kernel: do not cap the learning rate of terms whose   */
                                            /* partner lies outside the staged window (debug / A-B)      */
+#define PGSGD_FLAG_ONE_SIDED_FAR     0x20u /* tile kernel, experiment (not the reference's update rule): */
+                                           /* a term whose partner lies outside the staged window moves */
+                                           /* only its first end, by twice the step; no far write;      */
+                                           /* ignored on graphs with window-less tiles                  */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

@@ -48,6 +48,7 @@ FLAG_FP32_ATOMICS = 0x2
 FLAG_HOGWILD_STORES = 0x4
 FLAG_NO_TILES = 0x8
 FLAG_NO_FAR_CAP = 0x10
+FLAG_ONE_SIDED_FAR = 0x20
 DEFAULT_SEED = 9399220
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)

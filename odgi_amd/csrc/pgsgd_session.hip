@@ -68,6 +68,7 @@ struct pgsgd_session {
     uint64_t tile_steps_total = 0;
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
     size_t tile_lds = 0;
+    int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_grid = 0;
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
@@ -151,6 +152,11 @@ struct HostTiles {
     std::vector<pgsgd::WorkItem> items[2];
     uint64_t steps_total = 0, n_nonlocal = 0;
 };
+
+typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::IterArgs);
+static tile_kernel_t tile_kernel(int far) {
+    return far == pgsgd::kFarExclusive ? pgsgd::sgd_tile_kernel<1, pgsgd::kFarExclusive> : pgsgd::sgd_tile_kernel<1, pgsgd::kFarTwoSided>;
+}
 
 static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
     struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
@@ -369,11 +375,20 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
         s->tile_lds = (size_t)8 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
         int bpc = 0;
-        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sgd_tile_kernel<1>, (int)s->tile_block, s->tile_lds));
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
         const uint64_t lanes = (uint64_t)prop.multiProcessorCount * bpc * s->tile_block;
         if (cap >= lanes && g->n_nodes >= 8ull * s->region) {
             HostTiles ht = build_tiles(g, s->region, s->tile_steps);
+            if ((p->flags & PGSGD_FLAG_ONE_SIDED_FAR) && !ht.n_nonlocal) {
+                // experiment: nobody but its owner writes a window, so no copy of the staged state, half
+                // the LDS, more resident workgroups (never more lanes than the hot-node cap).  Ignored on
+                // graphs with window-less tiles, whose terms write into other workgroups' windows.
+                s->tile_far = pgsgd::kFarExclusive;
+                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
+                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(s->tile_far), (int)s->tile_block, s->tile_lds));
+                bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / ((uint64_t)prop.multiProcessorCount * s->tile_block)));
+            }
             s->tiled = true;
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
             s->n_streams = s->tile_grid * s->tile_block;
@@ -713,7 +728,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_mu_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) ? 1.0f : s->far_mu_cap[colour];
             ta.far_count = s->d_far + colour;
             HIP_TRY(hipEventRecord(ev.first, s->stream));
-            hipLaunchKernelGGL(pgsgd::sgd_tile_kernel<1>, dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
+            hipLaunchKernelGGL(tile_kernel(s->tile_far), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ev.second, s->stream));
             s->pending_events.push_back(ev);

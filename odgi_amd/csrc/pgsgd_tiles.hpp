@@ -71,12 +71,22 @@ __device__ __forceinline__ uint64_t mul_div(uint64_t a, uint64_t b, uint64_t c) 
     return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) / (unsigned __int128)c);
 }
 
-template <int COORD_LOAD>
+// FAR selects what a term whose partner lies outside the window does:
+//   kFarTwoSided   the reference's update: both ends move by -/+ delta (the partner through a global atomic);
+//   kFarExclusive  experiment (PGSGD_FLAG_ONE_SIDED_FAR, graphs without window-less tiles only): only the
+//                  first end moves, by -2 delta.  The pair is drawn from either side with equal
+//                  probability, so every end still receives the same expected displacement per
+//                  iteration, but nobody except its owner writes a window during a launch: no copy of
+//                  the staged state is kept and the window goes back with plain stores.  Measured
+//                  (profiles/r01/one_sided_far_experiment.jsonl): +21 % terms/s, stress +1..9 %.
+constexpr int kFarTwoSided = 0, kFarExclusive = 2;
+
+template <int COORD_LOAD, int FAR>
 __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileArgs ta, IterArgs a) {
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                   // [4R] window words
-    uint64_t* orig = lds + 4 * (size_t)ta.region;          // [4R] as staged
-    uint4* trec = reinterpret_cast<uint4*>(lds + 8 * (size_t)ta.region);  // [T] tile records
+    uint64_t* orig = lds + 4 * (size_t)ta.region;          // [4R] as staged (not with kFarExclusive)
+    uint4* trec = reinterpret_cast<uint4*>(lds + (FAR == kFarExclusive ? 4 : 8) * (size_t)ta.region);  // [T] tile records
     __shared__ uint32_t s_item;
     float dmax = 0.0f;
     uint32_t n_far = 0;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x) {
                 const uint64_t w = wbase + i < n_ends ? load_word<COORD_LOAD>(c.coords, (uint32_t)(wbase + i)) : 0;
                 win[i] = w;
-                orig[i] = w;
+                if (FAR != kFarExclusive) orig[i] = w;
             }
         }
         for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
@@ -138,8 +148,13 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 // at mu = 1/h, h = far pulls per node end per launch as counted in the previous launch:
                 // together they still amount to one projection.  Inactive once eta/d < 1/h.
                 float r_x, r_y, abs_delta;
-                term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, in_b ? 1.0f : ta.far_mu_cap);
-                n_far += in_b ? 0u : 1u;
+                const bool one_sided = FAR == kFarExclusive && !in_b;
+                term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : ta.far_mu_cap);
+                if (one_sided) {
+                    r_x *= 2.0f;
+                    r_y *= 2.0f;
+                }
+                n_far += (in_b || one_sided) ? 0u : 1u;
                 dmax = fmaxf(dmax, abs_delta);
                 const float ux = (float)(dither & 0xffffu) * (1.0f / 65536.0f);
                 const float uy = (float)(dither >> 16) * (1.0f / 65536.0f);
@@ -150,16 +165,20 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
                 const unsigned long long delta = (unsigned long long)((uint64_t)qx + ((uint64_t)qy << 32));
                 if (in_b) atomicAdd(reinterpret_cast<unsigned long long*>(win + lb), delta);
-                else atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_b), delta);
+                else if (!one_sided) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_b), delta);
                 if (in_a) atomicAdd(reinterpret_cast<unsigned long long*>(win + la), 0ull - delta);
                 else atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_a), 0ull - delta);
             }
         }
         __syncthreads();
-        if (wi.local) {  // what this workgroup moved, added to whatever others added meanwhile
+        if (wi.local) {
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x) {
-                const uint64_t d = win[i] - orig[i];
-                if (d != 0 && wbase + i < n_ends) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + wbase + i), (unsigned long long)d);
+                if (FAR == kFarExclusive) {  // sole writer of these words since they were staged
+                    if (wbase + i < n_ends) __hip_atomic_store(c.coords + wbase + i, win[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {  // what this workgroup moved, added to whatever others added meanwhile
+                    const uint64_t d = win[i] - orig[i];
+                    if (d != 0 && wbase + i < n_ends) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + wbase + i), (unsigned long long)d);
+                }
             }
         }
         __syncthreads();  // s_item and the window are reused
