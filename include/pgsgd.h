@@ -172,11 +172,15 @@ int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
-/* Multi-GPU sharding of the tile kernel: this device processes work items (node regions with all
- * their tiles) rank, rank+world, ... and every iteration call takes the FULL term count of the
- * block, of which only the owned tiles' share is applied.  Returns 1 when the session is tiled (the
- * shard is in effect), 0 when it runs the per-lane kernel (shard the term count instead), < 0 on error. */
-int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world);
+/* Multi-GPU sharding of the tile kernel.  Every iteration call then takes the FULL term count of the
+ * block, of which only the owned tiles' share is applied.
+ *   by_region = 0: this device runs tiles rank, rank+world, ... (every work item on every device, each
+ *                  visited tile with its whole share of terms: no short term loops);
+ *   by_region = 1: this device runs work items (node regions with all their tiles) rank, rank+world, ...
+ *                  (disjoint windows across devices; needs >= ~1000 regions per device and launch).
+ * Returns 1 when the session is tiled (the shard is in effect), 0 when it runs the per-lane kernel
+ * (shard the term count instead), < 0 on error. */
+int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region);
 /* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);

@@ -55,7 +55,8 @@ struct pgsgd_session {
     // region-exclusive tiles
     bool tiled = false;
     uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
-    uint32_t shard_rank = 0, shard_world = 1;
+    uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
+    uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
     unsigned long long* d_far = nullptr;  // [2] far-partner updates of the last launch of each colour
     unsigned long long* h_far = nullptr;  // pinned copy
@@ -151,6 +152,18 @@ struct HostTiles {
     std::vector<pgsgd::Tile> tiles;
     std::vector<pgsgd::WorkItem> items[2];
     uint64_t steps_total = 0, n_nonlocal = 0;
+};
+
+// PGSGD_TIMING=1: wall-clock of the set-up phases on stderr (where the time of a run goes besides the kernels)
+struct PhaseTimer {
+    const bool on = getenv("PGSGD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pgsgd timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
 };
 
 typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::IterArgs);
@@ -279,6 +292,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     rc = pick_device(p->device, &dev);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(dev));
+    PhaseTimer timer;
     auto s = new pgsgd_session();
     s->device = dev;
     s->params = *p;
@@ -321,6 +335,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             s->max_node_steps = std::max(s->max_node_steps, v);
         }
     }
+    timer.lap("hottest node (host)");
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
         return code;
@@ -357,6 +372,15 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     // fewer lanes than the GPU holds; everything else runs the per-lane kernel
     if (!(p->flags & (PGSGD_FLAG_NO_TILES | PGSGD_FLAG_COORD_LOAD_PLAIN | PGSGD_FLAG_ABLATE(15))) && s->fmt == pgsgd::kFmtQ32 &&
         s->upd == pgsgd::kUpdAtomic && !p->n_streams && p->terms_per_anchor <= 1) {
+        // Region size: a launch has N / 2R work items (one colour) and a workgroup takes one at a time, so
+        // R = 512 fills the ~1000 workgroup slots of the chip only from ~1e6 nodes; below that R = 256 doubles
+        // the work items at the same 256 lanes per workgroup (one lane per 4 window ends instead of 8;
+        // measured at 300k nodes: 1.97e10 vs 1.33e10 terms/s, stress 0.156 vs 0.155, and no gain at 1e6 nodes,
+        // profiles/r01/tiles_region_256_vs_512.jsonl).  R = 128 with 256 lanes diverges.
+        if (g->n_nodes / (2ull * 512) < (uint64_t)(0.9 * 4 * prop.multiProcessorCount)) {
+            s->region = 256;
+            s->tile_steps = 224;
+        }
         if (const char* e = getenv("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
             const long r = atol(e);
             if (r >= 32 && r <= 2048 && (r & (r - 1)) == 0) {
@@ -377,9 +401,13 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         int bpc = 0;
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
-        const uint64_t lanes = (uint64_t)prop.multiProcessorCount * bpc * s->tile_block;
-        if (cap >= lanes && g->n_nodes >= 8ull * s->region) {
+        // the hottest node must leave room for at least four workgroups per CU (the occupancy the kernel
+        // was validated at); between that and full residency the grid is cut to the hot-node cap
+        const uint64_t cu_lanes = (uint64_t)prop.multiProcessorCount * s->tile_block;
+        if (cap >= 4 * cu_lanes && g->n_nodes >= 8ull * s->region) {
+            bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / cu_lanes));
             HostTiles ht = build_tiles(g, s->region, s->tile_steps);
+            timer.lap("tile table (host)");
             if ((p->flags & PGSGD_FLAG_ONE_SIDED_FAR) && !ht.n_nonlocal) {
                 // experiment: nobody but its owner writes a window, so no copy of the staged state, half
                 // the LDS, more resident workgroups (never more lanes than the hot-node cap).  Ignored on
@@ -387,7 +415,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 s->tile_far = pgsgd::kFarExclusive;
                 s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
                 S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(s->tile_far), (int)s->tile_block, s->tile_lds));
-                bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / ((uint64_t)prop.multiProcessorCount * s->tile_block)));
+                bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / cu_lanes));
             }
             s->tiled = true;
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
@@ -412,6 +440,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         }
     }
 
+    timer.lap("stream, occupancy, tile upload");
     // step records: upload the SoA arrays, pack on the device, drop the staging copies
     {
         uint32_t *d_handle = nullptr, *d_len = nullptr;
@@ -431,6 +460,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         (void)hipFree(d_pos);
         (void)hipFree(d_len);
     }
+    timer.lap("step records (upload + pack)");
     S_TRY(hipMalloc(&s->d_path_first, (g->n_paths + 1) * sizeof(uint64_t)));
     S_TRY(hipMemcpy(s->d_path_first, g->path_first, (g->n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     {
@@ -474,6 +504,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.zc.init(p->theta);
     c.xf.x_off = c.xf.y_off = 0.0;
     c.xf.scale = c.xf.inv_scale = 1.0f;
+    timer.lap("tables, streams");
     *out = s;
     return PGSGD_OK;
 #undef S_TRY
@@ -646,11 +677,13 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     return (int64_t)cnt;
 }
 
-extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world) {
+extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region) {
     pgsgd::clear_error();
     if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
-    s->shard_rank = rank;
-    s->shard_world = world;
+    s->shard_rank = by_region ? rank : 0;
+    s->shard_world = by_region ? world : 1;
+    s->tshard_rank = by_region ? 0 : rank;
+    s->tshard_world = by_region ? 1 : world;
     return s->tiled ? 1 : 0;
 }
 
@@ -695,13 +728,15 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         if (s->tile_epoch == 1 && part == 0) {
             // nothing was counted yet: assume three quarters of the partners of this call's terms are far,
             // half of them in each colour's launch
-            const double h = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)(2 * s->n_nodes);
+            const double h = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
             s->far_mu_cap[0] = s->far_mu_cap[1] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
         }
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
-        const uint32_t n_sub = n_parts * s->tile_substeps;
-        for (uint32_t sub = part * s->tile_substeps; sub < (part + 1) * s->tile_substeps; ++sub)
+        // tile subsets: (part, window refresh, tile shard of this device) -> tiles with index = sub (mod n_sub)
+        const uint32_t n_sub = n_parts * s->tile_substeps * s->tshard_world;
+        for (uint32_t ps = part * s->tile_substeps; ps < (part + 1) * s->tile_substeps; ++ps)
         for (int colour = 0; colour < 2; ++colour) {
+            const uint32_t sub = ps * s->tshard_world + s->tshard_rank;
             if (!s->n_items[colour]) continue;
             HIP_TRY(hipMemsetAsync(s->d_queue + colour, 0, sizeof(uint32_t), s->stream));
             HIP_TRY(hipMemsetAsync(s->d_far + colour, 0, sizeof(unsigned long long), s->stream));
@@ -876,12 +911,15 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
         return pick_device(p->device, &dev);
     }
     const auto t0 = std::chrono::steady_clock::now();
+    PhaseTimer timer;
     pgsgd_session* s = nullptr;
     rc = pgsgd_session_create(g, p, &s);
     if (rc) return rc;
+    timer.lap("session create (total)");
     std::vector<double> etas(p->iter_max + 1);
     if (pgsgd_schedule(p, etas.data(), etas.size()) < 0) { pgsgd_session_destroy(s); return PGSGD_E_INVALID; }
     rc = pgsgd_session_upload_coords(s, X, Y);
+    timer.lap("coordinates upload");
     const uint64_t first_cooling = (uint64_t)std::floor(p->cooling_start * (double)p->iter_max);  // :39
     uint64_t iters = 0, terms = 0;
     double dmax = 0;
@@ -915,7 +953,9 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
         }
     }
     if (p->progress) fprintf(stderr, "\n");
+    timer.lap("iterations");
     if (rc == PGSGD_OK) rc = pgsgd_session_download_coords(s, X, Y);
+    timer.lap("coordinates download");
     if (stats) {
         stats->iterations = iters;
         stats->term_updates = terms;
@@ -926,6 +966,7 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     pgsgd_session_destroy(s);
+    timer.lap("session destroy");
     return rc;
 }
 

@@ -3,9 +3,9 @@
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  Every rank holds the
 whole lowered graph and a full copy of the coordinates.  In each iteration (learning-rate step)
 rank r applies 1/G of the iteration's terms with its own sampler streams (disjoint stream ids across
-ranks), in `exchanges_per_iteration` parts (per-lane kernel: slices of the terms; tile kernel: every
-B-th tile with its whole share).  After each part the ranks exchange what they changed since the
-previous exchange:
+ranks), in `exchanges_per_iteration` parts (per-lane kernel: slices of 1/G of the terms; tile kernel:
+the tiles with index = part*G + r (mod B*G), each with its whole share of the iteration's terms).
+After each part the ranks exchange what they changed since the previous exchange:
 
     begin : buf[0..4N) = coords - base ; buf[4N..6N) = |delta of each node end|^2      (HIP kernel)
     all-reduce(SUM) of the one fused 6N-float buffer over the G ranks                    (RCCL)
@@ -65,10 +65,11 @@ class HipEngine:
     def sync(self):
         return self.session.sync()
 
-    def set_shard(self, rank, world):
-        """True when the engine shards by node region (tile kernel): iteration() then takes the full
-        term count of a block; False when the caller must shard the term count (per-lane kernel)."""
-        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world))
+    def set_shard(self, rank, world, by_region=False):
+        """True when the engine shards by tile (or by node region) itself (tile kernel): iteration()
+        then takes the full term count of a block; False when the caller must shard the term count
+        (per-lane kernel)."""
+        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), 1 if by_region else 0)
         if rc < 0:
             check(rc, "set_shard")
         return rc == 1
@@ -92,7 +93,7 @@ class HipEngine:
 class DistributedLayout:
     """Drives one engine per rank through the schedule with the exchange between blocks."""
 
-    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None, region_shard=False):
+    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None, region_shard=False, tile_shard=True):
         self.params = params
         self.engine = engine
         self.group = group
@@ -111,27 +112,29 @@ class DistributedLayout:
         self.iterations_done = 0
         self.stopped_early = False
         self._buf = None
-        # Every rank applies 1/G of each iteration's terms.  With the tile kernel, part b of an iteration runs
-        # every B-th tile with its whole (1/G) share, so the cost of an iteration does not grow with the
-        # number of exchanges.  region_shard=True instead gives each rank every G-th node region with all
-        # its tiles (disjoint private windows; pays off only when there are >= ~1000 regions per rank and
-        # launch, i.e. N >~ 1e6 * G nodes: fewer leave most of the GPU idle).
-        self.region_sharded = False
+        # Every rank applies 1/G of each iteration's terms.  Per-lane kernel: 1/G of the term count, in B
+        # slices.  Tile kernel: part b of an iteration runs the tiles with index = b*G + rank (mod B*G), each
+        # with its whole share of the iteration's terms, so a visited tile always has a full term loop and
+        # the cost of an iteration grows neither with the number of exchanges nor with G.
+        # region_shard=True instead gives each rank every G-th node region with all its tiles (disjoint
+        # private windows; pays off only when there are >= ~1000 regions per rank and launch, i.e.
+        # N >~ 1e6 * G nodes: fewer leave most of the GPU idle).
+        self.engine_sharded = False
         if self.world > 1:
             self._buf = engine.new_exchange_buffer()
             engine.exchange_mark()
-            if region_shard and hasattr(engine, "set_shard"):
-                self.region_sharded = bool(engine.set_shard(self.rank, self.world))
+            if hasattr(engine, "set_shard") and (region_shard or (tile_shard and getattr(engine, "tiled", False))):
+                self.engine_sharded = bool(engine.set_shard(self.rank, self.world, by_region=bool(region_shard)))
 
     def _iteration_terms(self):
-        """Term count this rank passes for one iteration: everything when it shards by region (only the
-        owned tiles' share is applied), 1/G of it otherwise."""
+        """Term count this rank passes for one iteration: everything when the engine shards by tile or
+        region (only the owned tiles' share is applied), 1/G of it otherwise."""
         M = self.params.min_term_updates
-        return M if self.region_sharded else shard_terms(M, self.world, self.rank)
+        return M if self.engine_sharded else shard_terms(M, self.world, self.rank)
 
     def my_terms(self):
-        """Terms this rank applies per iteration (for a region-sharded engine: its expected share)."""
-        if self.region_sharded:
+        """Terms this rank applies per iteration (for an engine that shards itself: its expected share)."""
+        if self.engine_sharded:
             return self.params.min_term_updates // self.world
         return shard_terms(self.params.min_term_updates, self.world, self.rank)
 

@@ -476,3 +476,44 @@ def test_tiled_kernel_with_tandem_repeats(oa):
     print(f"tandem repeats: tiled={info['tiled']} stress tiled {res['tiled']:.4f} per-lane {res['per_lane']:.4f}")
     assert info["tiled"]
     assert res["tiled"] <= 1.3 * res["per_lane"] + 0.05
+
+
+def test_tile_sharded_virtual_ranks(oa):
+    """Multi-GPU path of the tile kernel on one GPU: two sessions play ranks 0 and 1 (tiles rank, rank+2, ...
+    of every work item, each with its whole share of the iteration's terms), merged after every iteration
+    by the exchange kernels, the all-reduce replaced by a sum on the device.  Both ranks must end with the
+    same coordinates, and the stress must stay within 25 % (+0.02) of the one-rank run's."""
+    import torch
+    from odgi_amd.distributed import HipEngine
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    X0, Y0 = oa.initial_layout(g, "d", seed=7)
+    p = _params(oa, g, min_term_updates=3 * g.n_steps)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    res = {}
+    for G in (1, 2):
+        engines = [HipEngine(g, _params(oa, g, min_term_updates=3 * g.n_steps, stream_offset=r * (1 << 20)), X0, Y0) for r in range(G)]
+        for r, e in enumerate(engines):
+            e.exchange_mark()
+            assert e.tiled and e.set_shard(r, G, by_region=False)
+        bufs = [e.new_exchange_buffer() for e in engines]
+        for it in range(p.iter_max):
+            for e in engines:
+                e.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, 0, 1)
+            if G > 1:
+                for e, b in zip(engines, bufs):
+                    e.exchange_begin(b)
+                torch.cuda.synchronize()
+                total = torch.stack(bufs).sum(0)
+                for e in engines:
+                    e.exchange_end(total, G)
+            for e in engines:
+                e.sync()
+        out = [e.result() for e in engines]
+        for e in engines:
+            e.close()
+        if G > 1:
+            assert np.abs(out[0][0] - out[1][0]).max() < 1.0 and np.abs(out[0][1] - out[1][1]).max() < 1.0
+        assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+        res[G] = oa.path_stress(g, out[0][0], out[0][1], 1_000_000, seed=1)
+    print(f"tile-sharded virtual ranks: stress G=1 {res[1]:.4f} G=2 {res[2]:.4f}")
+    assert res[2] <= 1.25 * res[1] + 0.02

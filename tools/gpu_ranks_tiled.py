@@ -8,14 +8,22 @@ import odgi_amd as oa
 from odgi_amd.distributed import HipEngine, shard_terms, split_blocks
 g = oa.Graph.synthetic(1_000_000, 50, seed=42)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
-for G, blocks_list in ((1, (1,)), (8, (1, 2, 4)), (4, (1, 2)), (2, (1, 2))):
-    for blocks in blocks_list:
+# argv[1]: "terms" (every rank runs every tile with 1/G of its terms) or "tiles" (default: every rank
+# runs every G-th tile with its whole share)
+# argv[2]: comma-separated G:exchanges list (default 1:1,8:1,8:2,4:1,2:1); argv[3]: replicates (initial layout / sampler seeds)
+mode = sys.argv[1] if len(sys.argv) > 1 else "tiles"
+cfgs = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "1:1,8:1,8:2,4:1,2:1").split(",")]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+for rep in range(reps):
+    X0, Y0 = oa.initial_layout(g, "d", seed=42 + rep)
+    for G, blocks in cfgs:
         p = oa.LayoutParams.defaults(g, device=0)
         etas = oa.path_linear_sgd_layout_schedule(p)
         engines = []
         for r in range(G):
-            pr = oa.LayoutParams.defaults(g, device=0, stream_offset=r * (1 << 20))
-            e = HipEngine(g, pr, X0, Y0); e.exchange_mark(); sharded = False; engines.append(e)
+            pr = oa.LayoutParams.defaults(g, device=0, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep)
+            e = HipEngine(g, pr, X0, Y0); e.exchange_mark(); engines.append(e)
+            sharded = mode == "tiles" and e.set_shard(r, G, by_region=False)
         bufs = [e.new_exchange_buffer() for e in engines]
         kms = 0.0
         for it in range(p.iter_max):
@@ -31,7 +39,7 @@ for G, blocks_list in ((1, (1,)), (8, (1, 2, 4)), (4, (1, 2)), (2, (1, 2))):
                 for e in engines: e.sync()
         ms, n = engines[0].session.kernel_time()
         X, Y = engines[0].result()
-        print(json.dumps(dict(exp="ranks_tiled", G=G, exchanges_per_iteration=blocks, stress=oa.path_stress(g, X, Y, 2_000_000, seed=1),
+        print(json.dumps(dict(exp="ranks_tiled", shard=mode, rep=rep, G=G, exchanges_per_iteration=blocks, stress=oa.path_stress(g, X, Y, 2_000_000, seed=1),
                               path_distance=oa.path_distance(g, X, Y)[0], rank0_kernel_ms=ms, rank0_launches=n,
                               rank0_terms_per_s=1e3 * p.min_term_updates * p.iter_max / G / ms)), flush=True)
         for e in engines: e.close()
