@@ -209,6 +209,11 @@ int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t terms_per_
 /* ---- graph input: GFA v1 -> lowered view (gfa_to_handle.cpp:27-217 + xp.cpp:49-175) -------- */
 typedef struct pgsgd_graph pgsgd_graph; /* owns its arrays */
 int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph** out);
+/* odgi's native graph file (.og, what graph_t::serialize writes: odgi.cpp:1632-1685, node.cpp:422-435)
+ * -> lowered view; path "-" reads standard input.  The graph must be optimized (ids 1..N). */
+int pgsgd_graph_from_og(const char* path, int n_threads, pgsgd_graph** out);
+/* The reference's input dispatch (utils.cpp:110-134): names ending in "gfa" are GFA, the rest .og. */
+int pgsgd_graph_load(const char* path, int n_threads, pgsgd_graph** out);
 /* Seeded synthetic "linearised pangenome" (BASELINE.json configs 4/5). */
 int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_t seed, pgsgd_graph** out);
 void pgsgd_graph_free(pgsgd_graph* g);

@@ -50,6 +50,8 @@ FLAG_NO_TILES = 0x8
 FLAG_NO_FAR_CAP = 0x10
 FLAG_ONE_SIDED_FAR = 0x20
 DEFAULT_SEED = 9399220
+# error codes of include/pgsgd.h
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/pgsgd.h declares: (name, restype, argtypes)
 SIGNATURES = [
@@ -84,6 +86,8 @@ SIGNATURES = [
     ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
+    ("pgsgd_graph_from_og", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
+    ("pgsgd_graph_load", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_synthetic", C.c_int, [u64, u64, u64, P(C.c_void_p)]),
     ("pgsgd_graph_free", None, [C.c_void_p]),
     ("pgsgd_graph_get_view", C.c_int, [C.c_void_p, P(GraphView)]),

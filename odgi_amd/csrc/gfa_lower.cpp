@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <thread>
+#include <tuple>
 
 #include "pgsgd_internal.hpp"
 
@@ -135,6 +136,29 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         const uint64_t rb = (fe[3] > f[3] && f[3][0] == '-') ? 1 : 0;
         g->edges.push_back(2 * (a - 1) + ra);
         g->edges.push_back(2 * (b - 1) + rb);
+    }
+    // graph_t::create_edge ignores an edge that exists (odgi.cpp:611-631), and a -> b is the same edge as
+    // flip(b) -> flip(a): keep the first occurrence of each, in file order
+    {
+        const uint64_t E = g->edges.size() / 2;
+        struct Key { uint64_t a, b, idx; };
+        std::vector<Key> keys(E);
+        for (uint64_t i = 0; i < E; ++i) {
+            const uint64_t a = g->edges[2 * i], b = g->edges[2 * i + 1];
+            const bool swap = std::make_pair(b ^ 1, a ^ 1) < std::make_pair(a, b);
+            keys[i] = {swap ? (b ^ 1) : a, swap ? (a ^ 1) : b, i};
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return std::tie(x.a, x.b, x.idx) < std::tie(y.a, y.b, y.idx); });
+        std::vector<uint64_t> keep;
+        for (uint64_t i = 0; i < E; ++i)
+            if (i == 0 || keys[i].a != keys[i - 1].a || keys[i].b != keys[i - 1].b) keep.push_back(keys[i].idx);
+        if (keep.size() != E) {
+            std::sort(keep.begin(), keep.end());
+            std::vector<uint64_t> uniq;
+            uniq.reserve(2 * keep.size());
+            for (uint64_t i : keep) { uniq.push_back(g->edges[2 * i]); uniq.push_back(g->edges[2 * i + 1]); }
+            g->edges.swap(uniq);
+        }
     }
     // paths: parsed in parallel, numbered in file order
     const uint64_t P = p_lines.size();

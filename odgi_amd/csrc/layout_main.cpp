@@ -120,11 +120,6 @@ bool to_u64(const std::string& s, uint64_t* u) {
     return e && *e == 0;
 }
 
-bool ends_with(const std::string& s, const char* suf) {
-    const size_t n = strlen(suf);
-    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
-}
-
 }  // namespace
 
 extern "C" int pgsgd_main_layout(int argc, char** argv) {
@@ -159,16 +154,13 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     if (a.has("threads") && !to_u64(a.get("threads"), &num_threads)) return bad("threads");
     if (num_threads == 0) num_threads = 1;
     if (a.has("path-index")) {
-        fprintf(stderr, "[odgi::layout] error: -X/--path-index is not supported by this build; the path index is lowered from the GFA input.\n");
+        fprintf(stderr, "[odgi::layout] error: -X/--path-index is not supported by this build; the path index is lowered from the graph input.\n");
         return 1;
     }
+    // utils.cpp:110-134: names ending in "gfa" are built from GFA, anything else (and "-" = stdin) is .og
     const std::string infile = a.get("idx");
-    if (infile == "-" || !(ends_with(infile, "gfa") || ends_with(infile, "GFA"))) {
-        fprintf(stderr, "[odgi::layout] error: this build reads GFAv1 input (a file name ending in 'gfa'); ODGI .og / GFAz input is not supported.\n");
-        return 1;
-    }
     pgsgd_graph* graph = nullptr;
-    int rc = pgsgd_graph_from_gfa(infile.c_str(), (int)num_threads, &graph);
+    int rc = pgsgd_graph_load(infile.c_str(), (int)num_threads, &graph);
     if (rc == PGSGD_E_NOTOPTIMIZED) {
         fprintf(stderr, "[odgi::layout] error: the graph is not optimized. Please run 'odgi sort' using -O, --optimize.\n");
         return 1;

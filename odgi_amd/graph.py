@@ -14,7 +14,8 @@ def _ptr(a, ctype):
 class Graph:
     """Flat path-step index: node_len[N], path_first[P+1], step_path/step_handle/step_pos[S].
 
-    Build with Graph.from_gfa (reference: gfa_to_handle + XP::from_handle_graph), Graph.synthetic
+    Build with Graph.from_gfa / Graph.from_og / Graph.load (reference: gfa_to_handle or
+    graph_t::deserialize, + XP::from_handle_graph), Graph.synthetic
     (BASELINE configs 4/5) or Graph.from_arrays (any caller that already walked its own graph_t).
     """
 
@@ -31,6 +32,24 @@ class Graph:
         g = cls()
         h = C.c_void_p()
         check(lib.pgsgd_graph_from_gfa(str(path).encode(), int(threads), C.byref(h)), f"from_gfa({path})")
+        g._adopt(h)
+        return g
+
+    @classmethod
+    def from_og(cls, path, threads=1):
+        """odgi's native graph file (graph_t::serialize, src/odgi.cpp:1632-1685); must be optimized."""
+        g = cls()
+        h = C.c_void_p()
+        check(lib.pgsgd_graph_from_og(str(path).encode(), int(threads), C.byref(h)), f"from_og({path})")
+        g._adopt(h)
+        return g
+
+    @classmethod
+    def load(cls, path, threads=1):
+        """The reference's input dispatch (src/utils.cpp:110-134): *gfa -> GFA v1, anything else -> .og."""
+        g = cls()
+        h = C.c_void_p()
+        check(lib.pgsgd_graph_load(str(path).encode(), int(threads), C.byref(h)), f"load({path})")
         g._adopt(h)
         return g
 

@@ -77,13 +77,18 @@ def ographs(graphs, orc):
 def parse_gfa_py(path):
     """Independent (pure Python) lowering of a GFA, used to cross-check the C++ loader."""
     node_len, paths, edges = {}, [], []
+    seen_edges = set()
     with open(path) as f:
         for line in f:
             t = line.rstrip("\n").split("\t")
             if t[0] == "S":
                 node_len[int(t[1])] = len(t[2])
             elif t[0] == "L":
-                edges.append((2 * (int(t[1]) - 1) + (t[2] == "-"), 2 * (int(t[3]) - 1) + (t[4] == "-")))
+                a, b = 2 * (int(t[1]) - 1) + (t[2] == "-"), 2 * (int(t[3]) - 1) + (t[4] == "-")
+                key = min((a, b), (b ^ 1, a ^ 1))   # a -> b is the same edge as flip(b) -> flip(a) (odgi.cpp:611-631)
+                if key not in seen_edges:
+                    seen_edges.add(key)
+                    edges.append((a, b))
             elif t[0] == "P":
                 steps = [(int(s[:-1]), s[-1] == "-") for s in t[2].split(",") if s and s != "*"]
                 paths.append((t[1], steps))

@@ -82,3 +82,69 @@ def zipf(g, n, theta, zeta_n):
         return 2
     v = 1.0 + n * fast_precise_pow(eta * u - eta + 1.0, alpha)
     return max(1, min(n, int(v)))
+
+
+def decode_og(path):
+    """Independent pure-Python reading of an odgi .og file (graph_t::serialize, src/odgi.cpp:1632-1685;
+    node_t::serialize, src/node.cpp:422-435; packed vector layout read off the fixture).  Returns
+    dict(header, node_len, node_seq, edges [(from_handle, to_handle)], paths [(name, [handles])])."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == bytes([0x76, 0x80, 0xBD, 0xBA])
+    off = 4
+
+    def rq():
+        nonlocal off
+        v = struct.unpack_from("<Q", b, off)[0]
+        off += 8
+        return v
+
+    def rvec():
+        nonlocal off
+        ws = rq()
+        words = struct.unpack_from("<%dQ" % ws, b, off)
+        off += 8 * ws
+        mask, size = rq(), rq()
+        bits, per_word = b[off], b[off + 1]
+        off += 2
+        return [(words[i // per_word] >> ((i % per_word) * bits)) & mask for i in range(size)]
+
+    header = [rq() for _ in range(7)]
+    n_nodes, n_paths = header[2], header[4]
+    nodes = []
+    for _ in range(n_nodes):
+        sl = rq()
+        seq = b[off:off + sl]
+        off += sl
+        nid = rq()
+        nodes.append((nid, seq, rvec(), rvec(), rvec()))
+    metas = []
+    for _ in range(n_paths):
+        length, first = rq(), (rq(), rq())
+        rq(), rq()
+        k = rq()
+        metas.append((length, first, b[off:off + k].decode()))
+        off += k
+    assert off == len(b), "trailing bytes"
+    edges = []
+    for i, (nid, _, ev, _, _) in enumerate(nodes):
+        for e in range(0, len(ev), 2):
+            other, t = ev[e], ev[e + 1]
+            if not t & 4:
+                edges.append((2 * i + ((t >> 1) & 1), 2 * (other - 1) + (t & 1)))
+    paths = []
+    for j, (length, (h, rank), name) in enumerate(metas):
+        node, handles = h >> 1, []
+        for s in range(length):
+            nid, _, _, dec, pv = nodes[node]
+            rec = pv[6 * rank:6 * rank + 6]
+            assert rec[0] == j + 1
+            handles.append(2 * node + (rec[1] & 1))
+            if (rec[1] >> 2) & 1:
+                break
+            d = dec[rec[4]]
+            nxt = nid if d == 0 else (nid + (d >> 1) if d & 1 else nid - (d >> 1))
+            node, rank = nxt - 1, rec[5]
+        assert len(handles) == length
+        paths.append((name, handles))
+    return dict(header=header, node_len=[len(n[1]) for n in nodes], node_seq=[n[1] for n in nodes], edges=edges, paths=paths)

@@ -517,3 +517,19 @@ def test_tile_sharded_virtual_ranks(oa):
         res[G] = oa.path_stress(g, out[0][0], out[0][1], 1_000_000, seed=1)
     print(f"tile-sharded virtual ranks: stress G=1 {res[1]:.4f} G=2 {res[2]:.4f}")
     assert res[2] <= 1.25 * res[1] + 0.02
+
+
+def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
+    """`odgi layout -i graph.og` (the reference's primary input form): the reference's own fixture
+    test/DRB1-3123_sorted.og through the CLI; the layout of this graph must meet the bar of the one layout
+    the reference ships for it (exhaustive path stress 0.0871 on the unsorted copy of the same graph)."""
+    og_file = os.path.join(GOLDEN, "DRB1-3123_sorted.og")
+    lay = tmp_path / "o.lay"
+    rc = oa.main_layout(["-i", og_file, "-o", str(lay), "-t", "2", "--gpu", "--seed", "5"])
+    assert rc == 0
+    g = oa.Graph.from_og(og_file)
+    L = oa.Layout.load(lay)
+    assert L.size() == 2 * g.n_nodes == 2 * 3214
+    s = orc.path_stress_exhaustive(orc.Graph.from_product(g), L.X, L.Y)
+    print("DRB1-3123_sorted.og exhaustive stress", s)
+    assert s <= 0.0871 * 1.25
