@@ -264,6 +264,9 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
                 fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
                 const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
                 if (UPD == kUpdAtomic) {
+                    // a step that rounds to no quantum adds zero: nothing to send (most far-apart terms of the
+                    // late iterations, where eta / d^2 is tiny)
+                    if ((qx | qy) == 0) continue;
                     const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
                     // partner end first, anchor end second: the order of the grouped path and of the oracle mirror
                     atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + t.end_b), (unsigned long long)delta);

@@ -154,7 +154,6 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     r_x *= 2.0f;
                     r_y *= 2.0f;
                 }
-                n_far += (in_b || one_sided) ? 0u : 1u;
                 dmax = fmaxf(dmax, abs_delta);
                 const float ux = (float)(dither & 0xffffu) * (1.0f / 65536.0f);
                 const float uy = (float)(dither >> 16) * (1.0f / 65536.0f);
@@ -163,6 +162,10 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
                 fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
                 const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                // a step that rounds to no quantum adds zero: nothing to send, in particular no global atomic
+                // for a far partner (most far terms of the late iterations, where eta / d^2 is tiny)
+                if ((qx | qy) == 0) continue;
+                n_far += (in_b || one_sided) ? 0u : 1u;
                 const unsigned long long delta = (unsigned long long)((uint64_t)qx + ((uint64_t)qy << 32));
                 if (in_b) atomicAdd(reinterpret_cast<unsigned long long*>(win + lb), delta);
                 else if (!one_sided) atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + end_b), delta);
