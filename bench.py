@@ -7,7 +7,8 @@ reference defaults (iter_max 30, 10*S terms per iteration, theta 0.99, cooling f
 The first half of the schedule draws half of the partners uniformly over the path (more far
 partners, slower), the cooling half draws all of them by Zipf; the default window times both.
 A "step" is one SGD iteration (one learning-rate step): 10*S node-pair updates, sharded 1/G per
-GPU, followed by the coordinate-delta all-reduce when G > 1 (strong scaling: total terms fixed).
+GPU (tile kernel: every G-th tile with its whole share of terms), followed by the coordinate-delta
+all-reduce when G > 1 (strong scaling: total terms fixed).
 
   python bench.py --gpus 1 --steps 28 --warmup 2        # = the reference's whole 30-iteration schedule
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
@@ -132,7 +133,8 @@ def main():
                                f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
                                f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
                    "streams_per_gpu": int(p.n_streams), "kernel_launches_per_step": launches / args.steps,
-                   "parallelism": f"term-sharded x{world}, graph replicated, {drv.blocks} delta all-reduce(s) per eta step"},
+                   "parallelism": f"{'tile' if drv.engine_sharded else 'term'}-sharded x{world}, graph replicated, "
+                                  f"{drv.blocks} delta all-reduce(s) per eta step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "pgsgd::sgd_tile_kernel" if eng.session.tile_info()["tiled"] else "pgsgd::sgd_iteration_kernel",
