@@ -199,6 +199,11 @@ int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_float
  * a, flat step b, end offset a, end offset b}; returns the number of terms. */
 int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0, uint64_t* cum, uint32_t* n, uint32_t* path,
                                  uint64_t capacity, uint64_t* steps_total);
+/* Parity hook: the work items of the tile kernel in launch order; item i runs tiles [tile_begin[i], tile_end[i])
+ * of the tile table on the node window starting at rank win0[i] (local[i] = 0: no window, every end in global
+ * memory); the first *n_first items belong to the launch of the even regions.  Returns the item count. */
+int64_t pgsgd_session_tile_items(const pgsgd_session* s, uint32_t* tile_begin, uint32_t* tile_end, uint32_t* win0,
+                                 uint32_t* local, uint64_t capacity, uint64_t* n_first);
 int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t tile, int cooling, uint64_t epoch, uint64_t n_terms,
                                        uint64_t* out, uint64_t capacity_terms);
 /* Parity hook: run the sampler only and write, for stream g and its j-th term (j < terms_per_stream),

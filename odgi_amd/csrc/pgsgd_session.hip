@@ -62,6 +62,7 @@ struct pgsgd_session {
     unsigned long long* h_far = nullptr;  // pinned copy
     float far_mu_cap[2] = {1.0f, 1.0f};   // per colour, from the previous launch of that colour
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
+    std::vector<pgsgd::WorkItem> h_items; // host copy of the work items, colour 0 first (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
@@ -404,9 +405,18 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // the hottest node must leave room for at least four workgroups per CU (the occupancy the kernel
         // was validated at); between that and full residency the grid is cut to the hot-node cap
         const uint64_t cu_lanes = (uint64_t)prop.multiProcessorCount * s->tile_block;
-        if (cap >= 4 * cu_lanes && g->n_nodes >= 8ull * s->region) {
-            bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / cu_lanes));
+        // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
+        // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
+        // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
+        const bool force = getenv("PGSGD_TILE_FORCE") != nullptr;
+        if ((force || cap >= 4 * cu_lanes) && g->n_nodes >= 8ull * s->region) {
+            bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
             HostTiles ht = build_tiles(g, s->region, s->tile_steps);
+            if (const char* e = getenv("PGSGD_TILE_LANES")) {
+                const long l = atol(e);
+                if (l >= 1)
+                    for (pgsgd::Tile& t : ht.tiles) t.lanes = std::min<uint32_t>(t.lanes, (uint32_t)l);
+            }
             timer.lap("tile table (host)");
             if ((p->flags & PGSGD_FLAG_ONE_SIDED_FAR) && !ht.n_nonlocal) {
                 // experiment: nobody but its owner writes a window, so no copy of the staged state, half
@@ -419,6 +429,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             }
             s->tiled = true;
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
+            if (const char* e = getenv("PGSGD_TILE_GRID")) {
+                const long gr = atol(e);
+                if (gr >= 1 && gr <= (long)s->tile_grid) s->tile_grid = (uint32_t)gr;
+            }
             s->n_streams = s->tile_grid * s->tile_block;
             s->tile_steps_total = ht.steps_total;
             s->n_tiles = ht.tiles.size();
@@ -428,6 +442,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             s->n_items[1] = (uint32_t)ht.items[1].size();
             std::vector<pgsgd::WorkItem> all(ht.items[0]);
             all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
+            s->h_items = all;
             S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
             S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
             S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
@@ -646,6 +661,21 @@ extern "C" int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0
         if (cum) cum[i] = s->h_tiles[i].cum;
         if (n) n[i] = s->h_tiles[i].n;
         if (path) path[i] = s->h_tiles[i].path;
+    }
+    return (int64_t)cnt;
+}
+
+// work items in launch order (the first *n_first belong to the launch of the even regions, the rest to the odd ones)
+extern "C" int64_t pgsgd_session_tile_items(const pgsgd_session* s, uint32_t* tile_begin, uint32_t* tile_end, uint32_t* win0, uint32_t* local,
+                                            uint64_t capacity, uint64_t* n_first) {
+    if (!s) return PGSGD_E_INVALID;
+    if (n_first) *n_first = s->n_items[0];
+    const uint64_t cnt = s->h_items.size();
+    for (uint64_t i = 0; i < cnt && i < capacity; ++i) {
+        if (tile_begin) tile_begin[i] = s->h_items[i].tile_begin;
+        if (tile_end) tile_end[i] = s->h_items[i].tile_end;
+        if (win0) win0[i] = s->h_items[i].win0;
+        if (local) local[i] = s->h_items[i].local;
     }
     return (int64_t)cnt;
 }

@@ -180,6 +180,16 @@ class LayoutSession:
                                      path.ctypes.data_as(u32p), cnt, C.byref(tot))
         return dict(t0=t0, cum=cum, n=n, path=path, steps_total=tot.value)
 
+
+    def tile_items(self):
+        """Work items in launch order: dict of arrays tile_begin, tile_end, win0, local, and n_first (items of the
+        first launch, the even regions)."""
+        cnt = lib.pgsgd_session_tile_items(self._h, None, None, None, None, 0, None)
+        arrs = [np.zeros(cnt, dtype=np.uint32) for _ in range(4)]
+        nf = C.c_uint64()
+        u32p = C.POINTER(C.c_uint32)
+        lib.pgsgd_session_tile_items(self._h, *[a.ctypes.data_as(u32p) for a in arrs], cnt, C.byref(nf))
+        return dict(tile_begin=arrs[0], tile_end=arrs[1], win0=arrs[2], local=arrs[3], n_first=nf.value)
     def trace_tile_terms(self, tile, cooling, epoch, n_terms, capacity=1 << 16):
         """Replay of the terms one tile draws in iteration `epoch`: uint64 [terms, 4] = (ka, kb, off_a, off_b)."""
         out = np.zeros((capacity, 4), dtype=np.uint64)

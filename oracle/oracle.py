@@ -39,6 +39,7 @@ class HogStats(C.Structure):
 _F64P = C.POINTER(C.c_double)
 _F32P = C.POINTER(C.c_float)
 _U64P = C.POINTER(C.c_uint64)
+_U32P = C.POINTER(C.c_uint32)
 
 
 def _load(name):
@@ -66,6 +67,11 @@ def _load(name):
     lib.orc_tile_terms.restype = C.c_uint64
     lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, _F32P, _F32P, _F64P]
+    lib.orc_tile_layout_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64,
+                                        C.c_uint64, _U64P, _U64P, _U32P, _U32P, C.c_uint64, C.c_uint64, C.c_uint64,
+                                        _U32P, _U32P, _U32P, _U32P, C.c_uint32, C.c_double, C.c_double, C.c_double,
+                                        _F32P, _F32P, C.POINTER(C.c_double), _U64P, C.POINTER(C.c_uint64)]
+    lib.orc_tile_layout_q32.restype = None
     lib.orc_layout_streams_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double, _F32P, _F32P, _F64P, _U64P]
     lib.orc_layout_streams_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
@@ -190,6 +196,25 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
                                  x_off, y_off, quanta_per_bp,
                                  X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P), C.byref(d), ck.ctypes.data_as(_U64P))
     return X, Y, d.value, ck
+
+
+def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, quanta_per_bp):
+    """Sequential mirror of the tile kernel (one workgroup, one lane per tile).  `tiles` / `items` are the dicts of
+    LayoutSession.tile_table() / tile_items().  Returns X, Y (fp32), last delta_max, checksums[4], far terms."""
+    X = np.ascontiguousarray(X, dtype=np.float32).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
+    d, far = C.c_double(), C.c_uint64()
+    ck = np.zeros(4, dtype=np.uint64)
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
+    u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+    t0, cum, tn, tp = u64(tiles["t0"]), u64(tiles["cum"]), u32(tiles["n"]), u32(tiles["path"])
+    tb, te, w0, lo = u32(items["tile_begin"]), u32(items["tile_end"]), u32(items["win0"]), u32(items["local"])
+    lib().orc_tile_layout_q32(C.byref(g.view), C.byref(p), seed_base, len(t0), t0.ctypes.data_as(_U64P), cum.ctypes.data_as(_U64P),
+                              tn.ctypes.data_as(_U32P), tp.ctypes.data_as(_U32P), int(tiles["steps_total"]), len(tb), int(items["n_first"]),
+                              tb.ctypes.data_as(_U32P), te.ctypes.data_as(_U32P), w0.ctypes.data_as(_U32P), lo.ctypes.data_as(_U32P),
+                              int(region), x_off, y_off, quanta_per_bp, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P),
+                              C.byref(d), ck.ctypes.data_as(_U64P), C.byref(far))
+    return X, Y, d.value, ck, far.value
 
 
 def layout_streams_f64(g, p, seed, n_streams, X, Y, stream_offset=0):

@@ -1034,3 +1034,141 @@ double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, ui
     free(zetas);
     return cnt ? acc / (double)cnt : 0.0;
 }
+
+/* ---- mirror of the region-exclusive tile kernel (odgi_amd/csrc/pgsgd_tiles.hpp: sgd_tile_kernel) run by ONE
+ * workgroup with ONE lane per tile (PGSGD_TILE_GRID=1, PGSGD_TILE_LANES=1): a sequential program.
+ * Per iteration two launches (even regions, odd regions); a launch takes its work items in order; an item
+ * stages its window of 4R coordinate words (private copy `win`, and `orig` as staged), runs its tiles' terms in
+ * term order — ends inside the window read and move the private copy, ends outside read and move the global
+ * words, a term with a partner outside the window is limited to mu <= far_mu_cap, a step that rounds to no
+ * quantum sends nothing — and adds win - orig back.  far_mu_cap of a launch is 1 / (far pulls per node end)
+ * counted in the previous launch of the same parity (first iteration: 0.75 * 0.5 * n_terms / 2N assumed).
+ * The tile table and the work items are the product's (pgsgd_session_tile_table / _tile_items); the test
+ * checks them separately as an exact partition of steps and terms. */
+static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy, float mu_cap,
+                                            float* r_x, float* r_y) {
+    const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
+    float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > mu_cap) mu = mu_cap;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    const float r = Delta / mag;
+    *r_x = r * dx;
+    *r_y = r * dy;
+    return fabsf(Delta);
+}
+
+void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
+                         uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
+                         uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
+                         double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
+                         double* last_delta_max, uint64_t* checksum, uint64_t* far_terms) {
+    (void)n_tiles;
+    if (last_delta_max) *last_delta_max = 0.0;
+    const uint64_t n_ends = 2 * g->n_nodes;
+    const float scale = (float)quanta_per_bp, inv_scale = (float)(1.0 / quanta_per_bp);
+    uint64_t* W = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
+    for (uint64_t i = 0; i < n_ends; ++i)
+        W[i] = (uint64_t)q32_quantize(X[i], x_off, scale) | ((uint64_t)q32_quantize(Y[i], y_off, scale) << 32);
+    if (checksum) {
+        checksum[0] = checksum[1] = 0;
+        for (uint64_t i = 0; i < n_ends; ++i) { checksum[0] += (uint32_t)W[i]; checksum[1] += W[i] >> 32; }
+    }
+    const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
+    double* zetas = (double*)malloc(nz * sizeof(double));
+    orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
+    double* etas = (double*)malloc((p->iter_max + 1) * sizeof(double));
+    orc_schedule(p, etas);
+    const uint32_t win_words = 4 * region;
+    uint64_t* win = (uint64_t*)malloc(win_words * sizeof(uint64_t));
+    uint64_t* orig = (uint64_t*)malloc(win_words * sizeof(uint64_t));
+    const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
+    const uint64_t n_terms = p->min_term_updates;
+    float far_cap[2];
+    {
+        const double h = 0.75 * 0.5 * (double)n_terms / (double)n_ends;
+        far_cap[0] = far_cap[1] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
+    }
+    uint64_t far_total = 0;
+    for (uint64_t iter = 0; iter < p->iter_max; ++iter) {
+        const float eta = (float)etas[iter];
+        const int cooling = iter >= first_cooling;
+        const uint64_t epoch = iter + 1;
+        float dmax = 0.0f;
+        uint64_t far_count[2] = {0, 0};
+        for (int colour = 0; colour < 2; ++colour) {
+            const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
+            for (uint64_t it = ib; it < ie; ++it) {
+                const uint64_t wbase = 2 * (uint64_t)win0[it];
+                if (local[it])
+                    for (uint32_t i = 0; i < win_words; ++i) win[i] = orig[i] = wbase + i < n_ends ? W[wbase + i] : 0;
+                for (uint32_t ti = tile_begin[it]; ti < tile_end[it]; ++ti) {
+                    const uint64_t term_begin = (uint64_t)(((unsigned __int128)cum[ti] * n_terms) / steps_total);
+                    const uint64_t term_end = (uint64_t)(((unsigned __int128)(cum[ti] + tn[ti]) * n_terms) / steps_total);
+                    for (uint64_t q = term_begin; q < term_end; ++q) {
+                        uint64_t s[4];
+                        orc_rng_seed(seed_base + epoch * 0x9e3779b97f4a7c15ull + q, s);
+                        orc_anchor an;
+                        an.pstart = g->path_first[tpath[ti]];
+                        an.cnt = g->path_first[tpath[ti] + 1] - an.pstart;
+                        an.k = t0[ti] + orc_uniform_u64(s, tn[ti]);
+                        an.s_rank = an.k - an.pstart;
+                        orc_term t;
+                        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+                        const uint64_t ea = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
+                        const uint64_t eb = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
+                        const int in_a = local[it] && ea >= wbase && ea - wbase < win_words;
+                        const int in_b = local[it] && eb >= wbase && eb - wbase < win_words;
+                        uint64_t* pa = in_a ? &win[ea - wbase] : &W[ea];
+                        uint64_t* pb = in_b ? &win[eb - wbase] : &W[eb];
+                        const uint64_t wa = *pa, wb = *pb;
+                        const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
+                        const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
+                        float r_x, r_y;
+                        const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, in_b ? 1.0f : far_cap[colour], &r_x, &r_y);
+                        if (da > dmax) dmax = da;
+                        const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
+                        const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                        float fx = r_x * scale;
+                        float fy = r_y * scale;
+                        fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                        fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                        const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                        if ((qx | qy) == 0) continue;
+                        if (!in_b) far_count[colour]++;
+                        const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                        *pb += delta;
+                        *pa -= delta;
+                    }
+                }
+                if (local[it])
+                    for (uint32_t i = 0; i < win_words; ++i)
+                        if (wbase + i < n_ends) W[wbase + i] += win[i] - orig[i];
+            }
+        }
+        for (int colour = 0; colour < 2; ++colour) {
+            const double h = (double)far_count[colour] / (double)n_ends;
+            far_cap[colour] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
+            far_total += far_count[colour];
+        }
+        if (last_delta_max) *last_delta_max = dmax;
+        if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;
+    }
+    if (far_terms) *far_terms = far_total;
+    if (checksum) {
+        checksum[2] = checksum[3] = 0;
+        for (uint64_t i = 0; i < n_ends; ++i) { checksum[2] += (uint32_t)W[i]; checksum[3] += W[i] >> 32; }
+    }
+    for (uint64_t i = 0; i < n_ends; ++i) {
+        X[i] = (float)(x_off + (double)(uint32_t)W[i] * (double)inv_scale);
+        Y[i] = (float)(y_off + (double)(uint32_t)(W[i] >> 32) * (double)inv_scale);
+    }
+    free(W); free(zetas); free(etas); free(win); free(orig);
+}

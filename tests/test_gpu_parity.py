@@ -533,3 +533,41 @@ def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
     s = orc.path_stress_exhaustive(orc.Graph.from_product(g), L.X, L.Y)
     print("DRB1-3123_sorted.og exhaustive stress", s)
     assert s <= 0.0871 * 1.25
+
+
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123"])
+def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
+    """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
+    order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
+    staging, private-copy reads, the far-partner learning-rate cap and its pull counts, steps that round to
+    no quantum, the flush.  `synthetic` is a sorted graph (every tile has a window), DRB1-3123 has stretches
+    whose tiles do not fit a window (every end in global memory)."""
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
+    monkeypatch.setenv("PGSGD_TILE_REGION", "64")
+    monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")
+    monkeypatch.setenv("PGSGD_TILE_GRID", "1")
+    monkeypatch.setenv("PGSGD_TILE_LANES", "1")
+    g = oa.Graph.synthetic(3000, 4, seed=3) if graph_name == "synthetic" else graphs("DRB1-3123")
+    og = orc.Graph.from_product(g)
+    X0, Y0 = oa.initial_layout(g, "d", seed=5)
+    p = _params(oa, g, iter_max=6, min_term_updates=2 * g.n_steps)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
+        assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64
+        assert (info["n_nonlocal_tiles"] == 0) == (graph_name == "synthetic")
+        assert len(items["local"]) == info["n_work_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
+        s.upload(X0, Y0)
+        fixed, x_off, y_off, q = s.coord_format()
+        w0 = s.download_words()
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            dmax_g = s.sync()
+        Xg, Yg = s.download()
+        w1 = s.download_words()
+    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
+    assert far > 0 and not np.array_equal(w0, w1)
+    assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
+    assert dmax_g == dmax_o
+    sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
+    assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1])) == (int(ck[2]), int(ck[3]))
