@@ -571,3 +571,51 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     assert dmax_g == dmax_o
     sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
     assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1])) == (int(ck[2]), int(ck[3]))
+
+
+def test_exchange_kernels_match_the_merge_rule_word_for_word(oa, graphs):
+    """Multi-GPU merge on one GPU with three virtual ranks: after exchange_begin every rank's buffer holds
+    (its move, |move|^2) per node end in bp; after the sum and exchange_end every rank's words must be
+    base + rint(S * clamp(Q / |S|^2, 1/G, 1) * quanta per bp), computed here in numpy float32."""
+    import torch
+    from odgi_amd.distributed import HipEngine
+    g = graphs("LPA")
+    G = 3
+    X0, Y0 = oa.initial_layout(g, "d", seed=9)
+    engines = [HipEngine(g, _params(oa, g, n_streams=512, stream_offset=r * 4096), X0, Y0) for r in range(G)]
+    for e in engines:
+        e.exchange_mark()
+    base = engines[0].session.download_words()
+    fixed, x_off, y_off, q = engines[0].session.coord_format()
+    assert fixed
+    for e in engines:
+        e.iteration(3.0e5, False, 40_000)
+    bufs = [e.new_exchange_buffer() for e in engines]
+    moved = [e.session.download_words() for e in engines]
+    for e, b in zip(engines, bufs):
+        e.exchange_begin(b)
+    torch.cuda.synchronize()
+    n_ends = 2 * g.n_nodes
+    lo = np.uint64(0xffffffff)
+    inv = np.float32(1.0 / q)
+    for r in range(G):   # what a rank reports: its own move since the mark, in bp (float32), and the squared length
+        dx = ((moved[r] & lo).astype(np.int64) - (base & lo).astype(np.int64)).astype(np.float32) * inv
+        dy = ((moved[r] >> np.uint64(32)).astype(np.int64) - (base >> np.uint64(32)).astype(np.int64)).astype(np.float32) * inv
+        b = bufs[r].cpu().numpy()
+        assert np.array_equal(b[:2 * n_ends].reshape(-1, 2), np.stack([dx, dy], axis=1))
+        assert np.array_equal(b[2 * n_ends:], dx * dx + dy * dy)
+    total = torch.stack(bufs).sum(0)
+    t = total.cpu().numpy()
+    S, Q = t[:2 * n_ends].reshape(-1, 2), t[2 * n_ends:]
+    s2 = S[:, 0] * S[:, 0] + S[:, 1] * S[:, 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = np.where(s2 > 0, np.minimum(np.maximum(Q / s2, np.float32(1.0 / G)), np.float32(1.0)), np.float32(1.0)).astype(np.float32)
+    qx = np.rint(S[:, 0] * f * np.float32(q)).astype(np.int64)
+    qy = np.rint(S[:, 1] * f * np.float32(q)).astype(np.int64)
+    want = (((base & lo).astype(np.int64) + qx).astype(np.uint64) & lo) | ((((base >> np.uint64(32)).astype(np.int64) + qy).astype(np.uint64) & lo) << np.uint64(32))
+    assert (s2 > 0).sum() > 1000 and (f < 1).sum() > 100   # both regimes of the rule occur
+    for e in engines:
+        e.exchange_end(total, G)
+        e.sync()
+        assert np.array_equal(e.session.download_words(), want)
+        e.close()
