@@ -254,7 +254,8 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
     };
     for (int colour = 0; colour < 2; ++colour) {
         // big work items first: the persistent workgroups pull from a queue
-        std::sort(groups[colour].begin(), groups[colour].end(), [](const Group& a, const Group& b) { return a.steps > b.steps; });
+        std::sort(groups[colour].begin(), groups[colour].end(),
+                  [](const Group& a, const Group& b) { return a.steps != b.steps ? a.steps > b.steps : a.r0 < b.r0; });  // a total order
         for (const Group& gr : groups[colour]) {
             pgsgd::WorkItem wi;
             wi.tile_begin = (uint32_t)ht.tiles.size();

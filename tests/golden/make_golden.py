@@ -6,7 +6,7 @@ layout path, so these vectors are the oracle's own output, committed so that (a)
 to the oracle is caught and (b) the GPU sampler can be checked on a box without re-deriving them.
 Contents: learning-rate schedules and zeta tables for the three fixture graphs'
 default parameters, and the first 1000 sampled terms (ka, kb, off_a, off_b) of stream seed 9399220
-on DRB1-3123 in non-cooling and cooling mode.
+on DRB1-3123 in non-cooling and cooling mode; final words of the tile-kernel mirror on DRB1-3123.
 Usage:  python tests/golden/make_golden.py
 """
 import os
@@ -36,5 +36,13 @@ for name in ("DRB1-3123", "LPA", "chr6.C4"):
         out["terms/DRB1-3123/warm"] = orc.trace_terms(g, p, 9399220, 1, 0, False, 1000)[:, 0, :]
         out["terms/DRB1-3123/cooling"] = orc.trace_terms(g, p, 9399220, 1, 0, True, 1000)[:, 0, :]
 out["zetas/theta0.5_space2932"] = orc.zetas(0.5, 2932, 1000, 100)
+
+# The sequential mirror of the tile kernel (one workgroup, one lane per tile) on DRB1-3123, whose unsorted
+# stretches give window-less tiles: tile table from the Python restatement (tests/pyref.py), region 64,
+# 6 iterations of 2*S terms, frame 16 quanta per bp.  The GPU test checks the kernel against the same
+# mirror with the product's own tile table and frame; this pins the mirror itself.
+import pyref  # noqa: E402
+from test_oracle_pins import tile_mirror_case  # noqa: E402
+out.update({f"tile_mirror/{k}": v for k, v in tile_mirror_case(orc, pyref).items()})
 np.savez_compressed(os.path.join(GOLDEN, "golden_vectors.npz"), **out)
 print("wrote", len(out), "arrays")

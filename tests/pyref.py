@@ -148,3 +148,60 @@ def decode_og(path):
         assert len(handles) == length
         paths.append((name, handles))
     return dict(header=header, node_len=[len(n[1]) for n in nodes], node_seq=[n[1] for n in nodes], edges=edges, paths=paths)
+
+
+def build_tiles_py(path_first, step_handle, R, T):
+    """Independent restatement of the tile table of the region-exclusive tile kernel: paths cut
+    into tiles of T steps (single-step paths have none); a tile whose node ranks fit the window
+    [r0*R, (r0+2)*R), r0 = rmin // R, joins work item r0; the launch of the even regions takes its items by
+    decreasing step count (ties: smaller region first), then every window-less tile as an item of its own;
+    the launch of the odd regions follows.  Returns (tiles dict, items dict) shaped like
+    LayoutSession.tile_table() / tile_items()."""
+    import numpy as np
+    pf = np.asarray(path_first, dtype=np.int64)
+    ranks = np.asarray(step_handle, dtype=np.int64) >> 1
+    raw = []
+    for p in range(len(pf) - 1):
+        b, cnt = int(pf[p]), int(pf[p + 1] - pf[p])
+        if cnt <= 1:
+            continue
+        for o in range(0, cnt, T):
+            n = min(T, cnt - o)
+            r = ranks[b + o:b + o + n]
+            raw.append((b + o, n, p, int(r.min()), int(r.max())))
+    groups, nonlocal_ = ({}, {}), []
+    for i, (t0, n, p, rmin, rmax) in enumerate(raw):
+        r0 = rmin // R
+        if rmax < (r0 + 2) * R:
+            groups[r0 & 1].setdefault(r0, []).append(i)
+        else:
+            nonlocal_.append(i)
+    tiles = dict(t0=[], cum=[], n=[], path=[])
+    items = dict(tile_begin=[], tile_end=[], win0=[], local=[])
+    total = 0
+
+    def emit(i):
+        nonlocal total
+        t0, n, p, _, _ = raw[i]
+        tiles["t0"].append(t0); tiles["cum"].append(total); tiles["n"].append(n); tiles["path"].append(p)
+        total += n
+
+    n_first = 0
+    for colour in (0, 1):
+        order = sorted(groups[colour].items(), key=lambda kv: (-sum(raw[i][1] for i in kv[1]), kv[0]))
+        for r0, members in order:
+            items["tile_begin"].append(len(tiles["t0"]))
+            for i in members:
+                emit(i)
+            items["tile_end"].append(len(tiles["t0"])); items["win0"].append(r0 * R); items["local"].append(1)
+        if colour == 0:
+            for i in nonlocal_:
+                items["tile_begin"].append(len(tiles["t0"]))
+                emit(i)
+                items["tile_end"].append(len(tiles["t0"])); items["win0"].append(0); items["local"].append(0)
+            n_first = len(items["local"])
+    tiles = {k: np.array(v, dtype=np.uint64 if k in ("t0", "cum") else np.uint32) for k, v in tiles.items()}
+    tiles["steps_total"] = total
+    items = {k: np.array(v, dtype=np.uint32) for k, v in items.items()}
+    items["n_first"] = n_first
+    return tiles, items

@@ -557,6 +557,14 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64
         assert (info["n_nonlocal_tiles"] == 0) == (graph_name == "synthetic")
         assert len(items["local"]) == info["n_work_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
+        # the product's tile table and work items are exactly the independent restatement's (tests/pyref.py)
+        import pyref
+        tiles_py, items_py = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56)
+        for k in ("t0", "cum", "n", "path"):
+            assert np.array_equal(tiles[k], tiles_py[k]), k
+        for k in ("tile_begin", "tile_end", "win0", "local"):
+            assert np.array_equal(items[k], items_py[k]), k
+        assert tiles["steps_total"] == tiles_py["steps_total"] and items["n_first"] == items_py["n_first"]
         s.upload(X0, Y0)
         fixed, x_off, y_off, q = s.coord_format()
         w0 = s.download_words()

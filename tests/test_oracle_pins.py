@@ -191,3 +191,36 @@ def test_oracle_hogwild_reaches_reference_quality(oa, orc, graphs, ographs):
     assert orc.path_stress_exhaustive(og, X, Y) < 0.0871 * 1.25
     Xf, Yf, dmax = orc.layout_streams_f32(og, orc.params_from(p), 9399220, 64, X0, Y0)
     assert orc.path_stress_exhaustive(og, Xf, Yf) < 0.0871 * 1.25 and dmax > 0
+
+
+def tile_mirror_case(orc, pyref):
+    """The committed tile-mirror case (also called by tests/golden/make_golden.py): DRB1-3123, region 64,
+    6 iterations of 2*S terms, deterministic initial layout (X = cumulative bp at node ends, Y = a fixed
+    pattern), frame 16 quanta per bp around it.  Returns the final coordinates and bookkeeping."""
+    from conftest import parse_gfa_py
+    d = parse_gfa_py(os.path.join(GOLDEN, "DRB1-3123.gfa"))
+    g = orc.Graph(d["node_len"], d["path_first"], d["step_path"], d["step_handle"], d["step_pos"])
+    counts = np.diff(d["path_first"].astype(np.int64))
+    max_steps = int(counts.max())
+    p = orc.params(iter_max=6, iter_with_max_learning_rate=0, min_term_updates=2 * g.n_steps, delta=0.0, eps=0.01,
+                   eta_max=float(max_steps) ** 2, theta=0.99, space=max_steps, space_max=1000, space_quantization_step=100,
+                   cooling_start=0.5)
+    tiles, items = pyref.build_tiles_py(d["path_first"], d["step_handle"], 64, 56)
+    ends = np.cumsum(np.repeat(d["node_len"].astype(np.float64), 2) * np.tile([0.0, 1.0], g.n_nodes))
+    X0 = ends.astype(np.float32)
+    Y0 = (((np.arange(2 * g.n_nodes) * 2654435761) % 1000) / 10.0 - 50.0).astype(np.float32)
+    X, Y, dmax, ck, far = orc.tile_layout_q32(g, p, 9399220, tiles, items, 64, X0, Y0, -float(1 << 27), -float(1 << 27), 16.0)
+    return dict(X=X, Y=Y, dmax=np.array([dmax]), checksum=ck, far=np.array([far], dtype=np.uint64),
+                n_tiles=np.array([len(tiles["t0"])]), n_items=np.array([len(items["local"])]),
+                n_windowless=np.array([int((items["local"] == 0).sum())]))
+
+
+def test_tile_mirror_golden_regression(orc):
+    """The oracle's mirror of the tile kernel against its committed output (the GPU test compares the kernel
+    with the same mirror), and the invariants of a run: coordinate sums conserved, some far partners."""
+    gv = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
+    got = tile_mirror_case(orc, pyref)
+    for k, v in got.items():
+        assert np.array_equal(v, gv[f"tile_mirror/{k}"]), k
+    ck = got["checksum"]
+    assert (ck[0], ck[1]) == (ck[2], ck[3]) and got["far"][0] > 0 and got["n_windowless"][0] > 0
