@@ -7,7 +7,8 @@
 // reference's CUDA host code does (src/cuda/layout.cu:325-410) — and calls pgsgd_layout_run.
 //
 // Header-only and duck-typed: libhandlegraph is not needed to compile it.  `Graph` must offer the
-// PathHandleGraph calls used below; handles must be odgi's packed integers (2*rank + is_reverse,
+// PathHandleGraph calls used below (get_node_count, get_length, for_each_handle, for_each_path_handle,
+// get_step_count, for_each_step_in_path, get_handle_of_step); handles must be odgi's packed integers (2*rank + is_reverse,
 // handlegraph::number_bool_packing, pinned in-tree by src/algorithms/layout.cpp:76-79) reachable
 // through an ADL `as_integer(handle)`.  `PathIndex` (xp::XP) is accepted for signature
 // compatibility and not read: like the reference's CUDA route, the GPU path builds its own index.
@@ -18,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgsgd.h"
@@ -42,27 +44,40 @@ struct lowered_graph {
     }
 };
 
-template <class Graph>
-lowered_graph lower_graph(const Graph& graph) {
+// Paths are independent, so they are walked on `n_threads` host threads (the reference's CUDA route does
+// the same walk under OpenMP, src/cuda/layout.cu:371-410); the graph is only read.
+template <class PathHandle, class Graph>
+lowered_graph lower_graph(const Graph& graph, uint64_t n_threads = 1) {
     lowered_graph lg;
     lg.node_len.assign(graph.get_node_count(), 0);
     graph.for_each_handle([&](const auto& h) {
         lg.node_len[as_integer(h) >> 1] = (uint32_t)graph.get_length(h);  // src/odgi.cpp:65-71
     });
-    lg.path_first.push_back(0);
-    graph.for_each_path_handle([&](const auto& path) {  // path ids in creation order (odgi.cpp:261-270)
-        uint64_t pos = 0;
-        const uint32_t pid = (uint32_t)(lg.path_first.size() - 1);
-        graph.for_each_step_in_path(path, [&](const auto& step) {
-            const auto h = graph.get_handle_of_step(step);
-            const uint64_t hi = as_integer(h);
-            lg.step_path.push_back(pid);
-            lg.step_handle.push_back((uint32_t)hi);
-            lg.step_pos.push_back(pos);  // xp.cpp:607-617
-            pos += lg.node_len[hi >> 1];
-        });
-        lg.path_first.push_back(lg.step_handle.size());
-    });
+    std::vector<PathHandle> paths;  // path ids in creation order (odgi.cpp:261-270)
+    graph.for_each_path_handle([&](const PathHandle& path) { paths.push_back(path); });
+    lg.path_first.assign(paths.size() + 1, 0);
+    for (size_t p = 0; p < paths.size(); ++p) lg.path_first[p + 1] = lg.path_first[p] + graph.get_step_count(paths[p]);
+    lg.step_path.resize(lg.path_first.back());
+    lg.step_handle.resize(lg.path_first.back());
+    lg.step_pos.resize(lg.path_first.back());
+    std::atomic<size_t> next{0};
+    auto walk = [&]() {
+        for (size_t p = next.fetch_add(1); p < paths.size(); p = next.fetch_add(1)) {
+            uint64_t pos = 0, k = lg.path_first[p];
+            graph.for_each_step_in_path(paths[p], [&](const auto& step) {
+                const uint64_t hi = as_integer(graph.get_handle_of_step(step));
+                lg.step_path[k] = (uint32_t)p;
+                lg.step_handle[k] = (uint32_t)hi;
+                lg.step_pos[k] = pos;  // xp.cpp:607-617
+                pos += lg.node_len[hi >> 1];
+                ++k;
+            });
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint64_t t = 1; t < n_threads && t < paths.size(); ++t) th.emplace_back(walk);
+    walk();
+    for (auto& t : th) t.join();
     return lg;
 }
 
@@ -80,10 +95,10 @@ void path_linear_sgd_layout_gpu(const Graph& graph, const PathIndex& /*path_inde
                                 const uint64_t& iter_with_max_learning_rate, const uint64_t& min_term_updates,
                                 const double& delta, const double& eps, const double& eta_max, const double& theta,
                                 const uint64_t& space, const uint64_t& space_max, const uint64_t& space_quantization_step,
-                                const double& cooling_start, const uint64_t& /*nthreads*/, const bool& progress,
+                                const double& cooling_start, const uint64_t& nthreads, const bool& progress,
                                 const bool& snapshot, const std::string& snapshot_prefix,
                                 std::vector<std::atomic<double>>& X, std::vector<std::atomic<double>>& Y) {
-    const pgsgd::lowered_graph lg = pgsgd::lower_graph(graph);
+    const pgsgd::lowered_graph lg = pgsgd::lower_graph<PathHandle>(graph, nthreads);
     const pgsgd_graph_view view = lg.view();
     pgsgd_params p;
     if (pgsgd_params_defaults(&view, &p) != PGSGD_OK) {

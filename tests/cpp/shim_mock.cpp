@@ -29,6 +29,7 @@ struct graph_t {
         for (uint64_t r = 0; r < paths[p.v - 1].size(); ++r) f(step_handle_t{p.v, r});
     }
     handle_t get_handle_of_step(const step_handle_t& s) const { return paths[s.path - 1][s.rank]; }
+    uint64_t get_step_count(const path_handle_t& p) const { return paths[p.v - 1].size(); }
 };
 struct xp_t {};
 }  // namespace mock
@@ -47,7 +48,7 @@ int main() {
         p5m.push_back({2 * (b + 0)}); p5m.push_back({2 * (b + 3)}); p5m.push_back({2 * (b + 2) + 1});  // 1+,4+,3-
     }
     g.paths = {p5, p5m};
-    const pgsgd::lowered_graph lg = pgsgd::lower_graph(g);
+    const pgsgd::lowered_graph lg = pgsgd::lower_graph<mock::path_handle_t>(g, 2);
     std::printf("N=%zu S=%zu P=%zu pos=%llu,%llu,%llu handle_last=%u\n", lg.node_len.size(), lg.step_handle.size(), lg.path_first.size() - 1,
                 (unsigned long long)lg.step_pos[0], (unsigned long long)lg.step_pos[1], (unsigned long long)lg.step_pos[2], lg.step_handle[3 * copies + 2]);
     if (lg.step_pos[1] != 4 || lg.step_pos[2] != 6 || lg.step_handle[3 * copies + 2] != 5) return 2;
@@ -63,7 +64,7 @@ int main() {
     pgsgd_session_destroy(probe);
     std::vector<mock::path_handle_t> use;
     odgi::algorithms::path_linear_sgd_layout_gpu(g, mock::xp_t{}, use, p.iter_max, (uint64_t)0, p.min_term_updates, p.delta, p.eps, p.eta_max,
-                                                 p.theta, p.space, p.space_max, p.space_quantization_step, p.cooling_start, (uint64_t)1, false,
+                                                 p.theta, p.space, p.space_max, p.space_quantization_step, p.cooling_start, (uint64_t)2, false,
                                                  false, std::string(), X, Y);
     double before = 0, after = 0;
     std::vector<double> X1(X0.size()), Y1(Y0.size());
