@@ -259,6 +259,10 @@ int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, const double
 int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p); /* sort_main.cpp:313-320,378-414 */
 int pgsgd_sort_initial(const pgsgd_graph_view* g, double* X);               /* path_sgd.cpp:67-73 */
 int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, pgsgd_stats* stats);
+/* the same with target sorting (path_sgd.cpp:289-301,392-397): target_nodes[n_nodes] != 0 marks nodes that keep
+ * their position; a term between two of them is counted and does nothing.  NULL = no target nodes. */
+int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_params* p, const uint8_t* target_nodes, double* X,
+                           pgsgd_stats* stats);
 int pgsgd_sort_order(uint64_t n_nodes, const double* X, uint64_t* order);   /* path_sgd.cpp:641-650 */
 int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uint64_t n_pairs, uint64_t seed, double* stress);
 /* parity hook: out[(j*n_streams+g)*2 + {0,1}] = flat steps a, b of fresh stream g's j-th term */

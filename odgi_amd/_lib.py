@@ -108,6 +108,7 @@ SIGNATURES = [
     ("pgsgd_sort_params_defaults", C.c_int, [P(GraphView), P(Params)]),
     ("pgsgd_sort_initial", C.c_int, [P(GraphView), P(f64)]),
     ("pgsgd_sort_run", C.c_int, [P(GraphView), P(Params), P(f64), P(Stats)]),
+    ("pgsgd_sort_run_targets", C.c_int, [P(GraphView), P(Params), P(C.c_uint8), P(f64), P(Stats)]),
     ("pgsgd_sort_order", C.c_int, [u64, P(f64), P(u64)]),
     ("pgsgd_sort_stress", C.c_int, [P(GraphView), P(f64), u64, u64, P(f64)]),
     ("pgsgd_sort_trace_terms", C.c_int, [P(GraphView), P(Params), C.c_int, u64, P(u64), P(u32)]),

@@ -404,11 +404,13 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
 // 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500): the layout's
 // sibling — same first-step/partner sampler, one coordinate per node, no end choice.  Differences:
 // the Zipf draw uses adj_theta = 0.001 once cooling starts while the zeta cache keeps the user's theta
-// (:127-137,195,246); a term of path distance 0 is dropped uncounted (:320-323).
+// (:127-137,195,246); a term of path distance 0 is dropped uncounted (:320-323); with target sorting a frozen
+// node does not move, and a term between two frozen nodes is counted but does nothing (:289-301).
 // Coordinates: one signed 64-bit fixed-point word per node, x = q * inv_scale, moved with one 64-bit
 // integer atomic per node; arithmetic in fp64 like the reference.
 struct SortArgs {
     long long* X;
+    const uint8_t* frozen;  // [n_nodes] target nodes of `odgi sort -Y --target-paths`, or null
     double scale, inv_scale;
     ZipfConst zc_cool;  // theta = 0.001
     uint64_t n_terms;
@@ -419,6 +421,7 @@ struct SortArgs {
 struct Term1D {
     uint64_t ka, kb, pos_a, pos_b;
     uint32_t node_a, node_b;
+    bool move_a, move_b;
 };
 
 template <typename PF>
@@ -444,6 +447,9 @@ __device__ __forceinline__ Term1D sample_term_1d(const DevConst& c, const PF pf,
         t.pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
         t.node_a = a.rec.x >> 1;
         t.node_b = rb.x >> 1;
+        t.move_a = !(sa.frozen && sa.frozen[t.node_a]);                           // :289-296
+        t.move_b = !(sa.frozen && sa.frozen[t.node_b]);
+        if (!t.move_a && !t.move_b) return t;                                     // counted, nothing to move (:297-301)
         if (t.pos_a != t.pos_b) return t;                                         // :320-323
     }
 }
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(kBlock) void sort_iteration_kernel(DevConst c, Sort
     float dmax = 0.0f;
     for (uint64_t ti = g; ti < sa.n_terms; ti += L) {
         const Term1D t = sample_term_1d(c, pf, sa, rng);
+        if (!t.move_a && !t.move_b) continue;
         const long long qa = __hip_atomic_load(sa.X + t.node_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long qb = __hip_atomic_load(sa.X + t.node_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(kBlock) void sort_iteration_kernel(DevConst c, Sort
         const double Delta = mu * (mag - term_dist) / 2.0;                        // :355
         const double r_x = (Delta / mag) * dx;
         const long long dq = __double2ll_rn(r_x * sa.scale);
-        atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_b), (unsigned long long)dq);
-        atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_a), (unsigned long long)(-dq));
+        if (t.move_b) atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_b), (unsigned long long)dq);
+        if (t.move_a) atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_a), (unsigned long long)(-dq));
         dmax = fmaxf(dmax, (float)fabs(Delta));
     }
     c.rng[g] = rng.s0;

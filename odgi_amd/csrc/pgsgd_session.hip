@@ -1046,6 +1046,7 @@ static int sort_session(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_
 static pgsgd::SortArgs sort_args(const pgsgd_session* s, long long* d_x, double scale) {
     pgsgd::SortArgs sa;
     sa.X = d_x;
+    sa.frozen = nullptr;
     sa.scale = scale;
     sa.inv_scale = 1.0 / scale;
     sa.zc_cool.init(0.001);  // adj_theta once cooling starts, path_sgd.cpp:195
@@ -1060,6 +1061,11 @@ static pgsgd::SortArgs sort_args(const pgsgd_session* s, long long* d_x, double 
 // path_sgd.cpp:67-73), updated in place.  Iterations 0..iter_max (:181), cooling when
 // iteration > floor(cooling_start*iter_max) (:194), stop when max|Delta| <= delta (:183).
 extern "C" int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, pgsgd_stats* stats) {
+    return pgsgd_sort_run_targets(g, p, nullptr, X, stats);
+}
+
+extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_params* p, const uint8_t* target_nodes, double* X,
+                                      pgsgd_stats* stats) {
     pgsgd::clear_error();
     if (stats) memset(stats, 0, sizeof *stats);
     if (!g || !p || !X) return PGSGD_E_INVALID;
@@ -1079,9 +1085,11 @@ extern "C" int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, 
     const double scale = 65536.0;  // quanta per bp: +-1.4e14 bp of range in a signed 64-bit word
     long long* d_x = nullptr;
     double* d_f = nullptr;
+    uint8_t* d_frozen = nullptr;
     auto cleanup = [&](int code) {
         if (d_x) (void)hipFree(d_x);
         if (d_f) (void)hipFree(d_f);
+        if (d_frozen) (void)hipFree(d_frozen);
         pgsgd_session_destroy(s);
         return code;
     };
@@ -1105,6 +1113,11 @@ extern "C" int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, 
     const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
     const uint32_t grid = (s->n_streams + block - 1) / block;
     pgsgd::SortArgs sa = sort_args(s, d_x, scale);
+    if (target_nodes) {
+        T_TRY(hipMalloc(&d_frozen, N));
+        T_TRY(hipMemcpyAsync(d_frozen, target_nodes, N, hipMemcpyHostToDevice, s->stream));
+        sa.frozen = d_frozen;
+    }
     hipEvent_t e0, e1;
     T_TRY(hipEventCreate(&e0));
     T_TRY(hipEventCreate(&e1));

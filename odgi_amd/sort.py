@@ -32,12 +32,20 @@ def sort_initial(graph: Graph):
     return X
 
 
-def path_linear_sgd(graph: Graph, params: LayoutParams, X=None):
-    """1D positions of the nodes (path_sgd.cpp:12-500). Returns (X, stats)."""
+def path_linear_sgd(graph: Graph, params: LayoutParams, X=None, target_nodes=None):
+    """1D positions of the nodes (path_sgd.cpp:12-500). Returns (X, stats).  `target_nodes` (bool per node,
+    the reference's target sorting): nodes that keep their position."""
     X = sort_initial(graph) if X is None else np.ascontiguousarray(X, dtype=np.float64).copy()
     st = _lib.Stats()
     p = params.to_c()
-    check(lib.pgsgd_sort_run(C.byref(graph.view), C.byref(p), X.ctypes.data_as(_F64P), C.byref(st)), "sort_run")
+    if target_nodes is None:
+        tp = None
+    else:
+        tn = np.ascontiguousarray(target_nodes, dtype=np.uint8)
+        if len(tn) != graph.n_nodes:
+            raise ValueError("target_nodes needs one entry per node")
+        tp = tn.ctypes.data_as(C.POINTER(C.c_uint8))
+    check(lib.pgsgd_sort_run_targets(C.byref(graph.view), C.byref(p), tp, X.ctypes.data_as(_F64P), C.byref(st)), "sort_run")
     return X, {f: getattr(st, f) for f, _ in _lib.Stats._fields_}
 
 

@@ -40,6 +40,7 @@ _F64P = C.POINTER(C.c_double)
 _F32P = C.POINTER(C.c_float)
 _U64P = C.POINTER(C.c_uint64)
 _U32P = C.POINTER(C.c_uint32)
+_U8P = C.POINTER(C.c_uint8)
 
 
 def _load(name):
@@ -84,8 +85,8 @@ def _load(name):
     lib.orc_sort_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
                                          C.c_uint64, _U64P]
     lib.orc_sort_streams.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_double,
-                                     _F64P, _F64P]
-    lib.orc_sort_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, C.POINTER(HogStats)]
+                                     _U8P, _F64P, _F64P]
+    lib.orc_sort_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _U8P, _F64P, C.POINTER(HogStats)]
     lib.orc_sort_stress.argtypes = [C.POINTER(OrcGraph), _F64P, C.c_uint64, C.c_uint64]
     lib.orc_sort_stress.restype = C.c_double
     lib.orc_path_stress_sampled.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P, C.c_uint64, C.c_uint64]
@@ -278,17 +279,21 @@ def sort_trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_st
     return out
 
 
-def sort_streams(g, p, seed, n_streams, X, quanta_per_bp=65536.0, stream_offset=0):
+def sort_streams(g, p, seed, n_streams, X, quanta_per_bp=65536.0, stream_offset=0, frozen=None):
     X = _d(X).copy()
     d = C.c_double()
-    lib().orc_sort_streams(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, quanta_per_bp, X.ctypes.data_as(_F64P), C.byref(d))
+    fz = None if frozen is None else np.ascontiguousarray(frozen, dtype=np.uint8)
+    lib().orc_sort_streams(C.byref(g.view), C.byref(p), seed, n_streams, stream_offset, quanta_per_bp,
+                           None if fz is None else fz.ctypes.data_as(_U8P), X.ctypes.data_as(_F64P), C.byref(d))
     return X, d.value
 
 
-def sort_hogwild(g, p, nthreads, X, max_seconds=0.0, fast=False):
+def sort_hogwild(g, p, nthreads, X, max_seconds=0.0, fast=False, frozen=None):
     X = _d(X).copy()
     st = HogStats()
-    lib(fast).orc_sort_hogwild(C.byref(g.view), C.byref(p), nthreads, max_seconds, X.ctypes.data_as(_F64P), C.byref(st))
+    fz = None if frozen is None else np.ascontiguousarray(frozen, dtype=np.uint8)
+    lib(fast).orc_sort_hogwild(C.byref(g.view), C.byref(p), nthreads, max_seconds, None if fz is None else fz.ctypes.data_as(_U8P),
+                               X.ctypes.data_as(_F64P), C.byref(st))
     return X, {"terms": st.terms, "iterations": st.iterations, "seconds": st.seconds}
 
 

@@ -885,7 +885,7 @@ void orc_sort_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed
  * 64-bit fixed-point word per node (x = q / quanta_per_bp), fp64 arithmetic, round-to-nearest steps.
  * Streams serialised like the 2D mirrors; bit-exact for n_streams == 1. */
 void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
-                      double quanta_per_bp, double* X, double* last_delta_max) {
+                      double quanta_per_bp, const uint8_t* frozen, double* X, double* last_delta_max) {
     if (last_delta_max) *last_delta_max = 0.0;
     if (!has_multistep_path(g)) return;
     stream_run r;
@@ -901,7 +901,16 @@ void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, ui
         for (uint64_t t = 0; t < p->min_term_updates; ++t) {
             uint64_t* s = r.states + 4 * (size_t)(t % n_streams);
             orc_term term;
-            while (!orc_sample_term_1d(g, p, r.zetas, cooling, s, &term)) { }
+            int move_i = 1, move_j = 1;
+            for (;;) {   /* target nodes are looked at before the distance (:289-301 then :320-323) */
+                const int distinct = orc_sample_term_1d(g, p, r.zetas, cooling, s, &term);
+                if (frozen) {
+                    move_i = !frozen[g->step_handle[term.ka] >> 1];
+                    move_j = !frozen[g->step_handle[term.kb] >> 1];
+                }
+                if ((!move_i && !move_j) || distinct) break;
+            }
+            if (!move_i && !move_j) continue;   /* counted, nothing to move */
             const double term_dist = fabs((double)term.pos_a - (double)term.pos_b);
             double mu = eta * (1.0 / term_dist);
             if (mu > 1) mu = 1;
@@ -912,8 +921,8 @@ void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, ui
             const double Delta = mu * (mag - term_dist) / 2;
             const double r_x = (Delta / mag) * dx;
             const int64_t dq = (int64_t)llrint(r_x * quanta_per_bp);
-            W[j] += dq;   /* partner first, then the first step: the device's order */
-            W[i] -= dq;
+            if (move_j) W[j] += dq;   /* partner first, then the first step: the device's order */
+            if (move_i) W[i] -= dq;
             if (fabs(Delta) > dmax) dmax = fabs(Delta);
         }
         if (last_delta_max) *last_delta_max = dmax;
@@ -926,7 +935,7 @@ void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, ui
 
 /* the reference as it is (Hogwild workers + 1 ms controller), path_sgd.cpp:158-452 */
 typedef struct sort_shared {
-    const orc_graph* g; const orc_params* p; const double* zetas; const double* etas; double* X;
+    const orc_graph* g; const orc_params* p; const double* zetas; const double* etas; double* X; const uint8_t* frozen;
     uint64_t first_cooling_iteration, term_updates, iteration, total_terms;
     double eta, Delta_max, max_seconds; int cooling, work_todo; struct timespec t0;
 } sort_shared;
@@ -966,11 +975,17 @@ static void* sort_work(void* arg) {
     while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
         orc_term t;
         const int cooling = __atomic_load_n(&sh->cooling, __ATOMIC_SEQ_CST);
-        if (!orc_sample_term_1d(g, sh->p, sh->zetas, cooling, s, &t)) continue;
+        const int distinct = orc_sample_term_1d(g, sh->p, sh->zetas, cooling, s, &t);
+        const uint64_t i = g->step_handle[t.ka] >> 1, j = g->step_handle[t.kb] >> 1;
+        const int move_i = !(sh->frozen && sh->frozen[i]), move_j = !(sh->frozen && sh->frozen[j]);   /* :289-296 */
+        if (!move_i && !move_j) {                                                                   /* :297-301 */
+            if (++local >= 1000) { __atomic_fetch_add(&sh->term_updates, local, __ATOMIC_SEQ_CST); total += local; local = 0; }
+            continue;
+        }
+        if (!distinct) continue;                                                                    /* :320-323 */
         const double term_dist = fabs((double)t.pos_a - (double)t.pos_b);
         double mu = ld_f64(&sh->eta) * (1.0 / term_dist);
         if (mu > 1) mu = 1;
-        const uint64_t i = g->step_handle[t.ka] >> 1, j = g->step_handle[t.kb] >> 1;
         double dx = ld_f64(&X[i]) - ld_f64(&X[j]);
         if (dx == 0) dx = 1e-9;
         const double mag = fabs(dx);
@@ -978,8 +993,8 @@ static void* sort_work(void* arg) {
         const double Delta_abs = fabs(Delta);
         while (Delta_abs > ld_f64(&sh->Delta_max)) st_f64(&sh->Delta_max, Delta_abs);
         const double r_x = (Delta / mag) * dx;
-        st_f64(&X[i], ld_f64(&X[i]) - r_x);
-        st_f64(&X[j], ld_f64(&X[j]) + r_x);
+        if (move_i) st_f64(&X[i], ld_f64(&X[i]) - r_x);                                            /* :392-397 */
+        if (move_j) st_f64(&X[j], ld_f64(&X[j]) + r_x);
         if (++local >= 1000) { __atomic_fetch_add(&sh->term_updates, local, __ATOMIC_SEQ_CST); total += local; local = 0; }
     }
     total += local;
@@ -987,7 +1002,8 @@ static void* sort_work(void* arg) {
     return NULL;
 }
 
-void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, double* X, orc_hogwild_stats* st) {
+void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, const uint8_t* frozen, double* X,
+                      orc_hogwild_stats* st) {
     if (st) { st->terms = 0; st->iterations = 0; st->seconds = 0; }
     if (!has_multistep_path(g) || nthreads == 0) return;
     const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
@@ -997,7 +1013,7 @@ void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads
     orc_schedule(p, etas);
     sort_shared sh;
     memset(&sh, 0, sizeof sh);
-    sh.g = g; sh.p = p; sh.zetas = zetas; sh.etas = etas; sh.X = X;
+    sh.g = g; sh.p = p; sh.zetas = zetas; sh.etas = etas; sh.X = X; sh.frozen = frozen;
     sh.first_cooling_iteration = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
     sh.eta = etas[0]; sh.work_todo = 1; sh.max_seconds = max_seconds;
     clock_gettime(CLOCK_MONOTONIC, &sh.t0);

@@ -124,8 +124,8 @@ void orc_sort_initial(const orc_graph* g, double* X /* [n_nodes] */);
 void orc_sort_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
                           int cooling, uint64_t terms_per_stream, uint64_t* out /* [terms][streams][2] = ka, kb */);
 void orc_sort_streams(const orc_graph* g, const orc_params* p, uint64_t seed, uint32_t n_streams, uint32_t stream_offset,
-                      double quanta_per_bp, double* X, double* last_delta_max);
-void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, double* X, orc_hogwild_stats* st);
+                      double quanta_per_bp, const uint8_t* frozen, double* X, double* last_delta_max);
+void orc_sort_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds, const uint8_t* frozen, double* X, orc_hogwild_stats* st);
 double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, uint64_t seed);
 
 #ifdef __cplusplus

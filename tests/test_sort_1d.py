@@ -99,3 +99,39 @@ def test_1d_layout_and_order_match_oracle(oa, orc):
     assert s_gpu <= 1.25 * s_cpu + 0.02 and q_gpu > 0.99 and q_gpu >= q_cpu - 0.005
     assert sort_stress(g, X, 500000, seed=0x5eed) == pytest.approx(s_gpu, rel=1e-12)   # product and oracle evaluators agree
     assert sorted(order.tolist()) == list(range(g.n_nodes))
+
+
+def test_oracle_1d_target_nodes_stay_put(oa, orc):
+    """Target sorting (path_sgd.cpp:289-301,392-397): frozen nodes keep their position exactly, the rest is
+    still laid out around them."""
+    from odgi_amd.sort import sort_params_defaults
+    g, true_order = _shuffled_linear_graph(oa, n_nodes=2000, n_paths=4)
+    og = orc.Graph.from_product(g)
+    p = sort_params_defaults(g, iter_max=20, min_term_updates=5 * g.n_steps)
+    X0 = orc.sort_initial(og)
+    frozen = np.zeros(g.n_nodes, dtype=np.uint8)
+    frozen[::7] = 1
+    X, st = orc.sort_hogwild(og, orc.params_from(p), 4, X0, frozen=frozen)
+    assert np.array_equal(X[frozen == 1], X0[frozen == 1]) and not np.array_equal(X[frozen == 0], X0[frozen == 0])
+    Xs, _ = orc.sort_streams(og, orc.params_from(p), 9399220, 8, X0, frozen=frozen)
+    assert np.array_equal(Xs[frozen == 1], X0[frozen == 1])
+    Xa, _ = orc.sort_streams(og, orc.params_from(p), 9399220, 8, X0, frozen=np.ones(g.n_nodes, dtype=np.uint8))
+    assert np.array_equal(Xa, X0)      # every term is counted and does nothing: the run still ends
+
+
+@pytest.mark.gpu
+def test_1d_target_nodes_bit_exact_and_frozen(oa, orc, graphs, ographs):
+    from odgi_amd.sort import path_linear_sgd, sort_params_defaults
+    g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
+    frozen = np.zeros(g.n_nodes, dtype=np.uint8)
+    frozen[np.random.RandomState(4).rand(g.n_nodes) < 0.3] = 1
+    p = sort_params_defaults(g, n_streams=1, iter_max=8, min_term_updates=2000, device=0)
+    Xg, st = path_linear_sgd(g, p, target_nodes=frozen)
+    X0 = orc.sort_initial(og)
+    Xo, dmax = orc.sort_streams(og, orc.params_from(p), p.seed, 1, X0, frozen=frozen)
+    assert np.array_equal(Xg, Xo) and st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
+    assert np.array_equal(Xg[frozen == 1], X0[frozen == 1]) and not np.array_equal(Xg, X0)
+    # full-width run: frozen nodes still exactly in place
+    p = sort_params_defaults(g, device=0)
+    Xf, _ = path_linear_sgd(g, p, target_nodes=frozen)
+    assert np.array_equal(Xf[frozen == 1], X0[frozen == 1])
