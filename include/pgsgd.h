@@ -264,6 +264,12 @@ int pgsgd_sort_run(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, 
 int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_params* p, const uint8_t* target_nodes, double* X,
                            pgsgd_stats* stats);
 int pgsgd_sort_order(uint64_t n_nodes, const double* X, uint64_t* order);   /* path_sgd.cpp:641-650 */
+/* weakly connected components ranked by the average id of their nodes (path_sgd.cpp:552-587) */
+int pgsgd_sort_component_ranks(uint64_t n_nodes, const uint64_t* edges, uint64_t n_edges, uint32_t* comp_rank_of_node);
+/* node ranks by (component rank, position, handle) (path_sgd.cpp:641-650); comp_rank_of_node may be NULL */
+int pgsgd_sort_order_components(uint64_t n_nodes, const double* X, const uint32_t* comp_rank_of_node, uint64_t* order);
+/* `odgi sort --path-sgd-layout` (path_sgd.cpp:651-672): .lay with X = (pos, pos + node length) per node of `order`, Y = 0 */
+int pgsgd_sort_write_lay(const pgsgd_graph_view* g, const double* X, const uint64_t* order, const char* path);
 int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uint64_t n_pairs, uint64_t seed, double* stress);
 /* parity hook: out[(j*n_streams+g)*2 + {0,1}] = flat steps a, b of fresh stream g's j-th term */
 int pgsgd_sort_trace_terms(const pgsgd_graph_view* g, const pgsgd_params* p, int cooling, uint64_t terms_per_stream,

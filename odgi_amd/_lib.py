@@ -110,6 +110,9 @@ SIGNATURES = [
     ("pgsgd_sort_run", C.c_int, [P(GraphView), P(Params), P(f64), P(Stats)]),
     ("pgsgd_sort_run_targets", C.c_int, [P(GraphView), P(Params), P(C.c_uint8), P(f64), P(Stats)]),
     ("pgsgd_sort_order", C.c_int, [u64, P(f64), P(u64)]),
+    ("pgsgd_sort_component_ranks", C.c_int, [u64, P(u64), u64, P(u32)]),
+    ("pgsgd_sort_order_components", C.c_int, [u64, P(f64), P(u32), P(u64)]),
+    ("pgsgd_sort_write_lay", C.c_int, [P(GraphView), P(f64), P(u64), C.c_char_p]),
     ("pgsgd_sort_stress", C.c_int, [P(GraphView), P(f64), u64, u64, P(f64)]),
     ("pgsgd_sort_trace_terms", C.c_int, [P(GraphView), P(Params), C.c_int, u64, P(u64), P(u32)]),
     ("pgsgd_main_layout", C.c_int, [C.c_int, P(C.c_char_p)]),

@@ -102,6 +102,55 @@ extern "C" int pgsgd_sort_order(uint64_t n_nodes, const double* X, uint64_t* ord
     return PGSGD_OK;
 }
 
+// path_sgd.cpp:552-587: weakly connected components, ranked by the average id of their nodes (ties: discovery order)
+extern "C" int pgsgd_sort_component_ranks(uint64_t n_nodes, const uint64_t* edges, uint64_t n_edges, uint32_t* comp_rank_of_node) {
+    pgsgd::clear_error();
+    if (!comp_rank_of_node || (n_edges && !edges)) return PGSGD_E_INVALID;
+    const int64_t n_comp = pgsgd_weak_components(n_nodes, edges, n_edges, comp_rank_of_node);
+    if (n_comp < 0) return (int)n_comp;
+    std::vector<uint64_t> id_sum((size_t)n_comp, 0), size((size_t)n_comp, 0);
+    for (uint64_t i = 0; i < n_nodes; ++i) { id_sum[comp_rank_of_node[i]] += i + 1; size[comp_rank_of_node[i]]++; }
+    std::vector<std::pair<double, uint64_t>> by_avg;
+    for (int64_t c = 0; c < n_comp; ++c) by_avg.emplace_back((double)id_sum[c] / (double)size[c], (uint64_t)c);
+    std::sort(by_avg.begin(), by_avg.end());
+    std::vector<uint32_t> rank((size_t)n_comp);
+    for (size_t r = 0; r < by_avg.size(); ++r) rank[by_avg[r].second] = (uint32_t)r;
+    for (uint64_t i = 0; i < n_nodes; ++i) comp_rank_of_node[i] = rank[comp_rank_of_node[i]];
+    return PGSGD_OK;
+}
+
+// path_sgd.cpp:641-650: by component, then position, then handle.  (The reference's comparator lets the handle
+// tie-break apply across components when two positions are exactly equal; positions of distinct nodes differ,
+// so the strict lexicographic order is used.  Its component key reads a vector it cleared at :587, whose
+// storage still holds the values.)
+extern "C" int pgsgd_sort_order_components(uint64_t n_nodes, const double* X, const uint32_t* comp_rank_of_node, uint64_t* order) {
+    pgsgd::clear_error();
+    if (!X || !order) return PGSGD_E_INVALID;
+    if (!comp_rank_of_node) return pgsgd_sort_order(n_nodes, X, order);
+    for (uint64_t i = 0; i < n_nodes; ++i) order[i] = i;
+    std::sort(order, order + n_nodes, [&](uint64_t a, uint64_t b) {
+        if (comp_rank_of_node[a] != comp_rank_of_node[b]) return comp_rank_of_node[a] < comp_rank_of_node[b];
+        return X[a] < X[b] || (X[a] == X[b] && a < b);
+    });
+    return PGSGD_OK;
+}
+
+// path_sgd.cpp:651-672 (`odgi sort --path-sgd-layout`): the sorted nodes' 1D layout as a .lay file:
+// X = (position, position + node length) of each node in `order`, Y = 0.
+extern "C" int pgsgd_sort_write_lay(const pgsgd_graph_view* g, const double* X, const uint64_t* order, const char* path) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X || !order || !path) return PGSGD_E_INVALID;
+    std::vector<double> sx(2 * g->n_nodes), sy(2 * g->n_nodes, 0.0);
+    for (uint64_t i = 0; i < g->n_nodes; ++i) {
+        if (order[i] >= g->n_nodes) { pgsgd::set_error("order names a node outside the graph"); return PGSGD_E_INVALID; }
+        sx[2 * i] = X[order[i]];
+        sx[2 * i + 1] = X[order[i]] + (double)g->node_len[order[i]];
+    }
+    return pgsgd_write_lay(path, 2 * g->n_nodes, sx.data(), sy.data());
+}
+
 // reference start: X[rank] = cumulative node length in graph order (path_sgd.cpp:67-73)
 extern "C" int pgsgd_sort_initial(const pgsgd_graph_view* g, double* X) {
     pgsgd::clear_error();

@@ -49,17 +49,35 @@ def path_linear_sgd(graph: Graph, params: LayoutParams, X=None, target_nodes=Non
     return X, {f: getattr(st, f) for f, _ in _lib.Stats._fields_}
 
 
-def order_from_positions(X):
+def component_ranks(graph: Graph):
+    """Weakly connected components of the graph ranked by the average id of their nodes (path_sgd.cpp:552-587)."""
+    edges = np.ascontiguousarray(graph.edges, dtype=np.uint64).reshape(-1)
+    out = np.zeros(graph.n_nodes, dtype=np.uint32)
+    check(lib.pgsgd_sort_component_ranks(graph.n_nodes, edges.ctypes.data_as(C.POINTER(C.c_uint64)), len(edges) // 2,
+                                         out.ctypes.data_as(C.POINTER(C.c_uint32))), "sort_component_ranks")
+    return out
+
+
+def order_from_positions(X, comp_ranks=None):
+    """Node ranks by (component rank, position, handle) (path_sgd.cpp:641-650)."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     order = np.zeros(len(X), dtype=np.uint64)
-    check(lib.pgsgd_sort_order(len(X), X.ctypes.data_as(_F64P), order.ctypes.data_as(C.POINTER(C.c_uint64))), "sort_order")
+    cr = None if comp_ranks is None else np.ascontiguousarray(comp_ranks, dtype=np.uint32)
+    check(lib.pgsgd_sort_order_components(len(X), X.ctypes.data_as(_F64P), None if cr is None else cr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          order.ctypes.data_as(C.POINTER(C.c_uint64))), "sort_order")
     return order
 
 
-def path_linear_sgd_order(graph: Graph, params: LayoutParams):
-    """Node ranks in their new order (path_sgd.cpp:503-686, without the graph rewrite)."""
-    X, st = path_linear_sgd(graph, params)
-    return order_from_positions(X), X, st
+def path_linear_sgd_order(graph: Graph, params: LayoutParams, target_nodes=None, layout_out=None):
+    """Node ranks in their new order (path_sgd.cpp:503-686, without the graph rewrite): by weak component
+    (ranked by average node id), then position, then handle.  `layout_out`: also write the sorted nodes' 1D
+    layout as a .lay file (`odgi sort --path-sgd-layout`, :651-672).  Returns (order, X, stats)."""
+    X, st = path_linear_sgd(graph, params, target_nodes=target_nodes)
+    order = order_from_positions(X, component_ranks(graph) if len(graph.edges) else None)
+    if layout_out is not None:
+        check(lib.pgsgd_sort_write_lay(C.byref(graph.view), X.ctypes.data_as(_F64P), order.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       str(layout_out).encode()), "sort_write_lay")
+    return order, X, st
 
 
 def sort_stress(graph: Graph, X, n_pairs=1_000_000, seed=0x5eed):

@@ -236,3 +236,27 @@ def test_reference_signature_shim_compiles_and_lowers(tmp_path):
     r = subprocess.run([str(_build_shim_mock(tmp_path))], capture_output=True, text=True)
     assert "pos=0,4,6 handle_last=5" in r.stdout
     assert r.returncode == (0 if torch.cuda.is_available() else 3), r.stdout + r.stderr
+
+
+def test_sort_order_by_component_then_position_and_1d_lay(oa, tmp_path):
+    """path_linear_sgd_order's ordering rule (path_sgd.cpp:552-587,641-650): components ranked by the average id
+    of their nodes, inside a component by position, ties by handle; and the 1D .lay of `--path-sgd-layout`."""
+    from odgi_amd import sort as osort
+    # two components: nodes {0, 3, 4} (ids 1,4,5: average 3.33) and {1, 2} (ids 2,3: average 2.5) -> {1,2} first
+    edges = np.array([[0, 6], [6, 8], [2, 4]], dtype=np.uint64)            # handles 2*rank
+    g = oa.Graph.from_arrays(np.array([5, 1, 2, 3, 4], dtype=np.uint32), np.array([0, 3, 5], dtype=np.uint64),
+                             np.array([0, 6, 8, 2, 4], dtype=np.uint32), edges=edges)
+    cr = osort.component_ranks(g)
+    assert cr.tolist() == [1, 0, 0, 1, 1]
+    X = np.array([7.0, 9.0, 9.0, 1.0, 7.0])
+    assert osort.order_from_positions(X).tolist() == [3, 0, 4, 1, 2]          # position, then handle
+    order = osort.order_from_positions(X, cr)
+    assert order.tolist() == [1, 2, 3, 0, 4]                                  # component {1,2}, then 1.0 < 7.0 (rank 0 before 4)
+    from odgi_amd._lib import lib, check
+    import ctypes as C
+    f = tmp_path / "sorted.lay"
+    check(lib.pgsgd_sort_write_lay(C.byref(g.view), X.ctypes.data_as(C.POINTER(C.c_double)), order.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                   str(f).encode()), "write")
+    L = oa.Layout.load(f)
+    want_x = np.array([9.0, 10.0, 9.0, 11.0, 1.0, 4.0, 7.0, 12.0, 7.0, 11.0])   # (pos, pos + node length) in the new order
+    assert np.array_equal(L.X, want_x) and np.array_equal(L.Y, np.zeros(10))
