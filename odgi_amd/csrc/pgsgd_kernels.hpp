@@ -486,9 +486,10 @@ __global__ __launch_bounds__(kBlock) void sort_iteration_kernel(DevConst c, Sort
         const double Delta = mu * (mag - term_dist) / 2.0;                        // :355
         const double r_x = (Delta / mag) * dx;
         const long long dq = __double2ll_rn(r_x * sa.scale);
+        dmax = fmaxf(dmax, (float)fabs(Delta));
+        if (dq == 0) continue;  // a step below half a quantum adds zero: nothing to send
         if (t.move_b) atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_b), (unsigned long long)dq);
         if (t.move_a) atomicAdd(reinterpret_cast<unsigned long long*>(sa.X + t.node_a), (unsigned long long)(-dq));
-        dmax = fmaxf(dmax, (float)fabs(Delta));
     }
     c.rng[g] = rng.s0;
     c.rng[L + g] = rng.s1;
