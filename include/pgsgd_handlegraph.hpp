@@ -136,5 +136,50 @@ void path_linear_sgd_layout_gpu(const Graph& graph, const PathIndex& /*path_inde
     }
 }
 
+// The 1D sibling with the reference's parameter list (src/algorithms/path_sgd.hpp:38-55, `odgi sort -Y`):
+// returns the nodes' 1D positions.  `target_nodes` (optional, the reference passes it to
+// path_linear_sgd_order: path_sgd.hpp:63-86) freezes the marked nodes.  Snapshots of intermediate
+// positions (temp files upstream) are not produced.
+template <class Graph, class PathIndex, class PathHandle>
+std::vector<double> path_linear_sgd_gpu(const Graph& graph, const PathIndex& /*path_index*/,
+                                        const std::vector<PathHandle>& /*path_sgd_use_paths*/, const uint64_t& iter_max,
+                                        const uint64_t& iter_with_max_learning_rate, const uint64_t& min_term_updates,
+                                        const double& delta, const double& eps, const double& eta_max, const double& theta,
+                                        const uint64_t& space, const uint64_t& space_max, const uint64_t& space_quantization_step,
+                                        const double& cooling_start, const uint64_t& nthreads, const bool& progress,
+                                        const bool& /*snapshot*/, std::vector<std::string>& /*snapshots*/,
+                                        const std::vector<bool>* target_nodes = nullptr) {
+    const pgsgd::lowered_graph lg = pgsgd::lower_graph<PathHandle>(graph, nthreads);
+    const pgsgd_graph_view view = lg.view();
+    pgsgd_params p;
+    if (pgsgd_sort_params_defaults(&view, &p) != PGSGD_OK) {
+        std::fprintf(stderr, "[odgi::path_linear_sgd_gpu] error: %s\n", pgsgd_last_error());
+        std::exit(1);
+    }
+    p.iter_max = iter_max;
+    p.iter_with_max_learning_rate = iter_with_max_learning_rate;
+    p.min_term_updates = min_term_updates;
+    p.delta = delta;
+    p.eps = eps;
+    p.eta_max = eta_max;
+    p.theta = theta;
+    p.space = space;
+    p.space_max = space_max;
+    p.space_quantization_step = space_quantization_step;
+    p.cooling_start = cooling_start;
+    p.progress = progress ? 1 : 0;
+    std::vector<double> X(view.n_nodes);
+    pgsgd_sort_initial(&view, X.data());  // path_sgd.cpp:67-73
+    std::vector<uint8_t> frozen;
+    if (target_nodes) frozen.assign(target_nodes->begin(), target_nodes->end());
+    pgsgd_stats st;
+    const int rc = pgsgd_sort_run_targets(&view, &p, target_nodes ? frozen.data() : nullptr, X.data(), &st);
+    if (rc != PGSGD_OK) {
+        std::fprintf(stderr, "[odgi::path_linear_sgd_gpu] error: %s: %s\n", pgsgd_strerror(rc), pgsgd_last_error());
+        std::exit(1);
+    }
+    return X;
+}
+
 }  // namespace algorithms
 }  // namespace odgi

@@ -72,5 +72,24 @@ int main() {
     pgsgd_path_stress(&view, X0.data(), Y0.data(), 100000, 1, &before);
     pgsgd_path_stress(&view, X1.data(), Y1.data(), 100000, 1, &after);
     std::printf("stress %.4f -> %.4f\n", before, after);
-    return after < before ? 0 : 4;
+    if (!(after < before)) return 4;
+    // the 1D sibling: frozen nodes stay where the initial order put them, the others move
+    std::vector<bool> targets(g.len.size(), false);
+    for (size_t i = 0; i < targets.size(); i += 5) targets[i] = true;
+    std::vector<std::string> snapshots;
+    pgsgd_params sp;
+    pgsgd_sort_params_defaults(&view, &sp);
+    const std::vector<double> X1d = odgi::algorithms::path_linear_sgd_gpu(g, mock::xp_t{}, use, sp.iter_max, (uint64_t)0, sp.min_term_updates, sp.delta,
+                                                                          sp.eps, sp.eta_max, sp.theta, sp.space, sp.space_max,
+                                                                          sp.space_quantization_step, sp.cooling_start, (uint64_t)2, false, false,
+                                                                          snapshots, &targets);
+    std::vector<double> Xi(g.len.size());
+    pgsgd_sort_initial(&view, Xi.data());
+    size_t moved = 0;
+    for (size_t i = 0; i < Xi.size(); ++i) {
+        if (targets[i] && X1d[i] != Xi[i]) return 5;
+        moved += X1d[i] != Xi[i];
+    }
+    std::printf("1D: %zu of %zu nodes moved\n", moved, Xi.size());
+    return moved > 0 ? 0 : 6;
 }
