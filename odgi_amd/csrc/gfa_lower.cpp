@@ -51,6 +51,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     pgsgd::clear_error();
     if (!path || !out) return PGSGD_E_INVALID;
     *out = nullptr;
+    pgsgd::PhaseTimer timer;
     std::ifstream in(path, std::ios::binary | std::ios::ate);
     if (!in) { set_error("cannot open '%s'", path); return PGSGD_E_IO; }
     const std::streamoff size = in.tellg();
@@ -62,6 +63,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     if (size > 0 && !in.read(&buf[0], size)) { set_error("cannot read '%s'", path); return PGSGD_E_IO; }
     in.close();
 
+    timer.lap("gfa: read file");
     std::vector<Line> s_lines, l_lines, p_lines;
     {
         const char* p = buf.data();
@@ -80,6 +82,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         }
     }
     if (s_lines.empty()) { set_error("'%s' has no S lines", path); return PGSGD_E_FORMAT; }
+    timer.lap("gfa: split lines");
 
     auto g = new pgsgd_graph();
     const uint64_t N = s_lines.size();
@@ -113,6 +116,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         delete g;
         return PGSGD_E_NOTOPTIMIZED;
     }
+    timer.lap("gfa: S lines");
     // edges (only needed for the weakly-connected-component post step)
     g->edges.reserve(l_lines.size() * 2);
     for (const Line& ln : l_lines) {
@@ -137,6 +141,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         g->edges.push_back(2 * (a - 1) + ra);
         g->edges.push_back(2 * (b - 1) + rb);
     }
+    timer.lap("gfa: L lines");
     // graph_t::create_edge ignores an edge that exists (odgi.cpp:611-631), and a -> b is the same edge as
     // flip(b) -> flip(a): keep the first occurrence of each, in file order
     {
@@ -160,6 +165,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
             g->edges.swap(uniq);
         }
     }
+    timer.lap("gfa: distinct edges");
     // paths: parsed in parallel, numbered in file order
     const uint64_t P = p_lines.size();
     std::vector<ParsedPath> parsed(P);
@@ -208,6 +214,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         worker();
         for (auto& t : th) t.join();
     }
+    timer.lap("gfa: P lines (threads)");
     for (uint64_t i = 0; i < P; ++i)
         if (parsed[i].err) {
             set_error("%s", parsed[i].msg.c_str());
@@ -244,6 +251,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         filler();
         for (auto& t : th) t.join();
     }
+    timer.lap("gfa: step index (threads)");
     *out = g;
     return PGSGD_OK;
 }

@@ -1,8 +1,10 @@
 // pgsgd_internal.hpp — types shared by the host translation units of libpgsgd.
 #pragma once
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -13,6 +15,19 @@ namespace pgsgd {
 // thread-local error text behind pgsgd_last_error()
 void set_error(const char* fmt, ...);
 void clear_error();
+
+// PGSGD_TIMING=1: wall-clock of the set-up phases on stderr (where the time of a run goes besides the kernels)
+struct PhaseTimer {
+    const bool on = getenv("PGSGD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pgsgd timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 
 }  // namespace pgsgd
 

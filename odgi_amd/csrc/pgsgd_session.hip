@@ -155,18 +155,6 @@ struct HostTiles {
     uint64_t steps_total = 0, n_nonlocal = 0;
 };
 
-// PGSGD_TIMING=1: wall-clock of the set-up phases on stderr (where the time of a run goes besides the kernels)
-struct PhaseTimer {
-    const bool on = getenv("PGSGD_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[pgsgd timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
-
 typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::IterArgs);
 static tile_kernel_t tile_kernel(int far) {
     return far == pgsgd::kFarExclusive ? pgsgd::sgd_tile_kernel<1, pgsgd::kFarExclusive> : pgsgd::sgd_tile_kernel<1, pgsgd::kFarTwoSided>;
@@ -294,7 +282,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     rc = pick_device(p->device, &dev);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(dev));
-    PhaseTimer timer;
+    pgsgd::PhaseTimer timer;
     auto s = new pgsgd_session();
     s->device = dev;
     s->params = *p;
@@ -942,7 +930,7 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
         return pick_device(p->device, &dev);
     }
     const auto t0 = std::chrono::steady_clock::now();
-    PhaseTimer timer;
+    pgsgd::PhaseTimer timer;
     pgsgd_session* s = nullptr;
     rc = pgsgd_session_create(g, p, &s);
     if (rc) return rc;
