@@ -181,7 +181,9 @@ uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
  * Returns 1 when the session is tiled (the shard is in effect), 0 when it runs the per-lane kernel
  * (shard the term count instead), < 0 on error. */
 int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region);
-/* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel */
+/* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel, 2 (known
+ * after pgsgd_session_upload_coords) when the initial layout has no global structure — long-range stress above
+ * 0.1 — and the iterations before cooling therefore run the per-lane kernel, the cooling ones the tile kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
 /* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.

@@ -54,6 +54,11 @@ struct pgsgd_session {
     pgsgd::DevConst dc{};
     // region-exclusive tiles
     bool tiled = false;
+    bool warm_per_lane = false;           // tiled session whose initial layout has no global structure: the
+                                          // iterations before cooling run the per-lane kernel (set at upload)
+    uint32_t tile_lanes = 0;              // lanes of a tile-kernel launch (n_streams stays the per-lane count)
+    struct CheckPair { uint32_t end_a, end_b; float d; };
+    std::vector<CheckPair> check_pairs;   // long-range step pairs for the initial-layout check
     uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
@@ -267,6 +272,45 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
     return ht;
 }
 
+// Long-range step pairs for the initial-layout check of a tiled session: first step uniform over all steps,
+// partner uniform over the same path (the pairs the non-cooling phase draws half of the time).  The tile kernel
+// moves a node end over long distances only twice per iteration (the capped far pulls of the two launches), which
+// is enough to refine a layout whose global structure is there — `-N d` on a sorted graph — and too little to
+// form it: from `-N g`, `-N r`, `-N h` or on a graph sorted only in blocks the tiled layouts end 6-40 % worse
+// (profiles/r01/init_modes_tile_vs_per_lane.jsonl, shuffled_graphs.jsonl).  So upload measures the stress of
+// the initial layout on these pairs, and when it is not small the iterations before cooling — where long
+// moves happen (mu = 1 for every distance) — run the per-lane kernel.
+static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
+    pgsgd::Xoshiro256Plus rng;
+    rng.seed(0x5eedc0de);
+    s->check_pairs.clear();
+    for (int tries = 0; tries < 65536 && s->check_pairs.size() < 16384; ++tries) {
+        const uint64_t ka = pgsgd::uniform_below(rng, g->n_steps);
+        const uint32_t path = g->step_path[ka];
+        const uint64_t b = g->path_first[path], cnt = g->path_first[path + 1] - b;
+        if (cnt < 2) continue;
+        const uint64_t kb = b + pgsgd::uniform_below(rng, cnt);
+        const uint64_t pa = g->step_pos[ka], pb = g->step_pos[kb];
+        if (pa == pb) continue;
+        pgsgd_session::CheckPair cp;
+        cp.end_a = g->step_handle[ka];  // the end a step starts at: 2 * rank + is_reverse
+        cp.end_b = g->step_handle[kb];
+        cp.d = (float)(pa > pb ? pa - pb : pb - pa);
+        s->check_pairs.push_back(cp);
+    }
+}
+
+static double check_pairs_stress(const pgsgd_session* s, const float* X, const float* Y) {
+    if (s->check_pairs.empty()) return 0.0;
+    double sum = 0;
+    for (const auto& cp : s->check_pairs) {
+        const double dx = (double)X[cp.end_a] - (double)X[cp.end_b], dy = (double)Y[cp.end_a] - (double)Y[cp.end_b];
+        const double e = (std::sqrt(dx * dx + dy * dy) - (double)cp.d) / (double)cp.d;
+        sum += e * e;
+    }
+    return sum / (double)s->check_pairs.size();
+}
+
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
     pgsgd::clear_error();
     if (!out || !p) return PGSGD_E_INVALID;
@@ -416,31 +460,38 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(s->tile_far), (int)s->tile_block, s->tile_lds));
                 bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / cu_lanes));
             }
-            s->tiled = true;
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
             if (const char* e = getenv("PGSGD_TILE_GRID")) {
                 const long gr = atol(e);
                 if (gr >= 1 && gr <= (long)s->tile_grid) s->tile_grid = (uint32_t)gr;
             }
-            s->n_streams = s->tile_grid * s->tile_block;
-            s->tile_steps_total = ht.steps_total;
-            s->n_tiles = ht.tiles.size();
-            s->h_tiles = ht.tiles;
-            s->n_nonlocal_tiles = ht.n_nonlocal;
-            s->n_items[0] = (uint32_t)ht.items[0].size();
-            s->n_items[1] = (uint32_t)ht.items[1].size();
-            std::vector<pgsgd::WorkItem> all(ht.items[0]);
-            all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
-            s->h_items = all;
-            S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
-            S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
-            S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
-            S_TRY(hipMalloc(&s->d_far, 2 * sizeof(unsigned long long)));
-            S_TRY(hipMemset(s->d_far, 0, 2 * sizeof(unsigned long long)));
-            S_TRY(hipHostMalloc(&s->h_far, 2 * sizeof(unsigned long long)));
-            s->h_far[0] = s->h_far[1] = 0;
-            S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
-            S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
+            s->tile_lanes = s->tile_grid * s->tile_block;
+            // A graph whose node ranks do not follow its paths has tiles without a window; all their ends live in
+            // global memory and all their terms count as far (learning rate capped).  A few are fine (measured:
+            // 10 % in relabelled stretches, same stress); when they are many the cap throttles the whole layout
+            // (a randomly numbered graph ends at stress 3e4, profiles/r01/shuffled_graphs.jsonl): per-lane kernel.
+            s->tiled = force || 10 * ht.n_nonlocal <= ht.tiles.size();
+            if (s->tiled) {
+                sample_check_pairs(s, g);
+                s->tile_steps_total = ht.steps_total;
+                s->n_tiles = ht.tiles.size();
+                s->h_tiles = ht.tiles;
+                s->n_nonlocal_tiles = ht.n_nonlocal;
+                s->n_items[0] = (uint32_t)ht.items[0].size();
+                s->n_items[1] = (uint32_t)ht.items[1].size();
+                std::vector<pgsgd::WorkItem> all(ht.items[0]);
+                all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
+                s->h_items = all;
+                S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
+                S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
+                S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
+                S_TRY(hipMalloc(&s->d_far, 2 * sizeof(unsigned long long)));
+                S_TRY(hipMemset(s->d_far, 0, 2 * sizeof(unsigned long long)));
+                S_TRY(hipHostMalloc(&s->h_far, 2 * sizeof(unsigned long long)));
+                s->h_far[0] = s->h_far[1] = 0;
+                S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
+                S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
+            }
         }
     }
 
@@ -563,6 +614,14 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     HIP_TRY(hipSetDevice(s->device));
     const uint64_t n_ends = 2 * s->n_nodes;
     if (s->fmt == pgsgd::kFmtQ32) choose_xform(s, X, Y);
+    if (s->tiled && !getenv("PGSGD_TILE_FORCE")) {
+        // 0.1 = long-range distances off by a third on average; `-N d` on a sorted graph measures ~0.01
+        const double st = check_pairs_stress(s, X, Y);
+        s->warm_per_lane = !(st <= 0.1);
+        if (s->params.progress)
+            fprintf(stderr, "[odgi::path_linear_sgd_layout] long-range stress of the initial layout %.4g: %s\n", st,
+                    s->warm_per_lane ? "per-lane kernel until cooling, tile kernel after" : "tile kernel");
+    }
     float *dX = nullptr, *dY = nullptr;
     HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
     HIP_TRY(hipMalloc(&dY, n_ends * sizeof(float)));
@@ -637,7 +696,8 @@ extern "C" int pgsgd_session_set_stream(pgsgd_session* s, void* hip_stream) {
     return PGSGD_OK;
 }
 
-extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return s ? s->n_streams : 0; }
+// lanes of the kernel that runs the cooling half: the tile kernel's resident lanes, or the per-lane streams
+extern "C" uint32_t pgsgd_session_n_streams(const pgsgd_session* s) { return !s ? 0 : s->tiled ? s->tile_lanes : s->n_streams; }
 
 // parity hooks for the tile kernel
 extern "C" int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0, uint64_t* cum, uint32_t* n, uint32_t* path, uint64_t capacity,
@@ -714,7 +774,7 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
     if (n_work_items) *n_work_items = (uint64_t)s->n_items[0] + s->n_items[1];
     if (region_nodes) *region_nodes = s->region;
     if (tile_steps) *tile_steps = s->tile_steps;
-    return s->tiled ? 1 : 0;
+    return s->tiled ? (s->warm_per_lane ? 2 : 1) : 0;
 }
 
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
@@ -727,9 +787,17 @@ extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling
 extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint64_t n_terms, uint32_t part, uint32_t n_parts) {
     pgsgd::clear_error();
     if (!s || n_parts == 0 || part >= n_parts) return PGSGD_E_INVALID;
-    if (!s->tiled && n_parts > 1) {
-        const uint64_t base = n_terms / n_parts, rem = n_terms % n_parts;
-        n_terms = base + (part < rem ? 1 : 0);
+    // a tiled session whose initial layout had no global structure runs the per-lane kernel until cooling
+    const bool use_tiles = s->tiled && !(s->warm_per_lane && !cooling);
+    if (!use_tiles) {
+        if (s->tiled && s->tshard_world > 1) {  // the caller passed the whole iteration: this device's share
+            const uint64_t base = n_terms / s->tshard_world, rem = n_terms % s->tshard_world;
+            n_terms = base + (s->tshard_rank < rem ? 1 : 0);
+        }
+        if (n_parts > 1) {
+            const uint64_t base = n_terms / n_parts, rem = n_terms % n_parts;
+            n_terms = base + (part < rem ? 1 : 0);
+        }
     }
     HIP_TRY(hipSetDevice(s->device));
     if (s->pending_events.size() >= 64) {  // bound the event pool
@@ -737,7 +805,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         int rc = collect_events(s);
         if (rc) return rc;
     }
-    if (s->tiled) {
+    if (use_tiles) {
         pgsgd::IterArgs a;
         a.n_terms = n_terms;
         a.eta = (float)eta;
@@ -979,7 +1047,7 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
         stats->iterations = iters;
         stats->term_updates = terms;
         stats->last_delta_max = dmax;
-        stats->n_streams = s->n_streams;
+        stats->n_streams = pgsgd_session_n_streams(s);
         stats->early_stop = early;
         pgsgd_session_kernel_time(s, &stats->kernel_ms, nullptr, 0);
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -65,6 +65,9 @@ class HipEngine:
     def sync(self):
         return self.session.sync()
 
+    def warm_per_lane(self):
+        return bool(self.session.tile_info()["warm_per_lane"])
+
     def set_shard(self, rank, world, by_region=False):
         """True when the engine shards by tile (or by node region) itself (tile kernel): iteration()
         then takes the full term count of a block; False when the caller must shard the term count
@@ -142,8 +145,14 @@ class DistributedLayout:
         """Iteration `it` (0-based) on every rank with its exchanges.  Returns global max|Delta|."""
         eng = self.engine
         dmax = 0.0
-        for b in range(self.blocks):
-            eng.iteration_part(self.etas[it], it >= self.first_cooling, self._iteration_terms(), b, self.blocks)
+        # a tiled engine whose initial layout had no global structure runs the per-lane kernel until cooling: that
+        # phase takes the per-lane kernel's four exchanges per iteration
+        cooling = it >= self.first_cooling
+        blocks = self.blocks
+        if self.world > 1 and not cooling and getattr(eng, "warm_per_lane", lambda: False)():
+            blocks = max(blocks, 4)
+        for b in range(blocks):
+            eng.iteration_part(self.etas[it], cooling, self._iteration_terms(), b, blocks)
             if self.world > 1:
                 eng.exchange_begin(self._buf)
                 dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)

@@ -164,10 +164,12 @@ class LayoutSession:
         return w
 
     def tile_info(self):
-        """dict(tiled, n_tiles, n_nonlocal_tiles, n_work_items, region_nodes, tile_steps) of the session (tiled=False: per-lane kernel)."""
+        """dict(tiled, warm_per_lane, n_tiles, n_nonlocal_tiles, n_work_items, region_nodes, tile_steps) of the session
+        (tiled=False: per-lane kernel; warm_per_lane, known after upload(): the initial layout had no global
+        structure, so the iterations before cooling run the per-lane kernel)."""
         a, b, c_, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
         on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
-        return dict(tiled=bool(on), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
+        return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
 
     def tile_table(self):
         """Tiles in work order: dict of arrays t0, cum, n, path, and steps_total."""

@@ -627,3 +627,45 @@ def test_exchange_kernels_match_the_merge_rule_word_for_word(oa, graphs):
         e.sync()
         assert np.array_equal(e.session.download_words(), want)
         e.close()
+
+
+def test_kernel_plan_follows_graph_order_and_initial_layout(oa):
+    """The tile kernel refines a layout whose global structure is there; it moves a node end over long distances
+    only twice per iteration, which does not form that structure.  So (a) a graph whose node ranks do not follow
+    its paths runs the per-lane kernel, (b) an initial layout without global structure (`-N g`) runs the per-lane
+    kernel until cooling and the tile kernel after, (c) `-N d` on a sorted graph runs the tile kernel throughout;
+    the layouts of (a) and (b) are as good as the per-lane kernel's."""
+    from odgi_amd import _lib
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    # (a) randomly numbered nodes
+    perm = np.random.RandomState(3).permutation(g.n_nodes)
+    new_len = np.empty_like(g.node_len)
+    new_len[perm] = g.node_len
+    h = g.step_handle
+    gr = oa.Graph.from_arrays(new_len, g.path_first, (perm[h >> 1].astype(np.uint32) << 1) | (h & 1))
+    p = _params(oa, gr, min_term_updates=3 * gr.n_steps)
+    with oa.LayoutSession(gr, p) as s:
+        assert not s.tile_info()["tiled"]
+    X0, Y0 = oa.initial_layout(gr, "d", seed=7)
+    X, Y = X0.copy(), Y0.copy()
+    oa.path_linear_sgd_layout_gpu(gr, p, X, Y)
+    s_random = oa.path_stress(gr, X, Y, 1_000_000, seed=1)
+    # (b), (c) sorted graph, Gaussian vs default initial layout
+    res = {}
+    for init in "gd":
+        X0, Y0 = oa.initial_layout(g, init, seed=7)
+        for name, flags in (("default", 0), ("per_lane", _lib.FLAG_NO_TILES)):
+            p = _params(oa, g, flags=flags, min_term_updates=3 * g.n_steps)
+            with oa.LayoutSession(g, p) as s:
+                s.upload(X0, Y0)
+                info = s.tile_info()
+            if name == "default":
+                assert info["tiled"] and info["warm_per_lane"] == (init == "g")
+            X, Y = X0.copy(), Y0.copy()
+            oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+            res[init, name] = oa.path_stress(g, X, Y, 1_000_000, seed=1)
+    print(f"kernel plan: random numbering {s_random:.4f}; init g {res['g', 'default']:.4f} vs {res['g', 'per_lane']:.4f}; "
+          f"init d {res['d', 'default']:.4f} vs {res['d', 'per_lane']:.4f}")
+    assert s_random <= 1.15 * res["d", "per_lane"] + 0.01
+    assert res["g", "default"] <= 1.1 * res["g", "per_lane"] + 0.01
+    assert res["d", "default"] <= 1.15 * res["d", "per_lane"] + 0.01
