@@ -142,6 +142,10 @@ int pgsgd_init_layout(const pgsgd_graph_view* g, char mode, uint64_t seed, doubl
  * PGSGD_E_NODEVICE when no MI355X-class HIP device is usable: there is no CPU fallback. */
 int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p,
                      float* X, float* Y, pgsgd_stats* stats);
+/* The same run with double-precision coordinates: the result comes back at the full resolution of the device's
+ * fixed-point words (1/16 bp on a 3e7-bp layout, where fp32 is spaced 2-4 bp apart); what the `odgi layout`
+ * binary and the C++ shim use for their std::vector<std::atomic<double>> / .lay outputs. */
+int pgsgd_layout_run_f64(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, double* Y, pgsgd_stats* stats);
 
 /* ---- session API: the same run, one iteration at a time ------------------------------------ */
 /* Used by the multi-GPU driver (one process per GPU; the coordinate all-reduce between eta
@@ -153,6 +157,7 @@ void pgsgd_session_destroy(pgsgd_session* s);
 /* host fp32 X,Y [2N]  <->  device coordinate words (one 8-byte word per node end) */
 int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y);
 int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y);
+int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, double* Y); /* exact x_off + q / quanta_per_bp */
 /* device pointer to the 2N coordinate words, and their format: fixed_point 1 = {u32 Xq, u32 Yq}
  * with x = x_off + Xq / quanta_per_bp (frame chosen at upload), 0 = {f32 x, f32 y} */
 void* pgsgd_session_coords_ptr(pgsgd_session* s);

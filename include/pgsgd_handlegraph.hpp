@@ -119,20 +119,20 @@ void path_linear_sgd_layout_gpu(const Graph& graph, const PathIndex& /*path_inde
     p.progress = progress ? 1 : 0;
     p.snapshot = snapshot ? 1 : 0;
     p.snapshot_prefix = snapshot ? snapshot_prefix.c_str() : nullptr;
-    std::vector<float> xf(X.size()), yf(Y.size());
+    std::vector<double> xd(X.size()), yd(Y.size());
     for (size_t i = 0; i < X.size(); ++i) {
-        xf[i] = (float)X[i].load();
-        yf[i] = (float)Y[i].load();
+        xd[i] = X[i].load();
+        yd[i] = Y[i].load();
     }
     pgsgd_stats st;
-    const int rc = pgsgd_layout_run(&view, &p, xf.data(), yf.data(), &st);
+    const int rc = pgsgd_layout_run_f64(&view, &p, xd.data(), yd.data(), &st);  // full resolution of the device's coordinates
     if (rc != PGSGD_OK) {
         std::fprintf(stderr, "[odgi::path_linear_sgd_layout_gpu] error: %s: %s\n", pgsgd_strerror(rc), pgsgd_last_error());
         std::exit(1);
     }
     for (size_t i = 0; i < X.size(); ++i) {
-        X[i].store((double)xf[i]);
-        Y[i].store((double)yf[i]);
+        X[i].store(xd[i]);
+        Y[i].store(yd[i]);
     }
 }
 

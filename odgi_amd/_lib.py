@@ -63,10 +63,12 @@ SIGNATURES = [
     ("pgsgd_zeta_table", C.c_int, [f64, u64, u64, u64, P(f64), C.c_size_t]),
     ("pgsgd_init_layout", C.c_int, [P(GraphView), C.c_char, u64, P(f64), P(f64)]),
     ("pgsgd_layout_run", C.c_int, [P(GraphView), P(Params), P(C.c_float), P(C.c_float), P(Stats)]),
+    ("pgsgd_layout_run_f64", C.c_int, [P(GraphView), P(Params), P(f64), P(f64), P(Stats)]),
     ("pgsgd_session_create", C.c_int, [P(GraphView), P(Params), P(C.c_void_p)]),
     ("pgsgd_session_destroy", None, [C.c_void_p]),
     ("pgsgd_session_upload_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
     ("pgsgd_session_download_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
+    ("pgsgd_session_download_coords_f64", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_coords_ptr", C.c_void_p, [C.c_void_p]),
     ("pgsgd_session_download_words", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_coord_format", C.c_int, [C.c_void_p, P(C.c_int), P(f64), P(f64), P(f64)]),

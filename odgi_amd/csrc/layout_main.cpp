@@ -277,13 +277,11 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     if (rc) { fprintf(stderr, "[odgi::layout] error: %s\n", pgsgd_last_error()); return finish(1); }
 
     // the SGD itself, on the GPU (:333-387)
-    std::vector<float> Xf(n_ends), Yf(n_ends);
-    for (uint64_t i = 0; i < n_ends; ++i) { Xf[i] = (float)X[i]; Yf[i] = (float)Y[i]; }
     bool any_multi = max_path_step_count > 1;
     pgsgd_stats st;
     memset(&st, 0, sizeof st);
     if (any_multi && p.space >= 1) {
-        rc = pgsgd_layout_run(&view, &p, Xf.data(), Yf.data(), &st);
+        rc = pgsgd_layout_run_f64(&view, &p, X.data(), Y.data(), &st);  // coordinates at the device's full resolution
         if (rc) {
             fprintf(stderr, "[odgi::layout] error: %s: %s\n", pgsgd_strerror(rc), pgsgd_last_error());
             return finish(1);
@@ -292,7 +290,6 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
             fprintf(stderr, "[odgi::layout] %llu term updates in %.1f ms of kernel time (%.3g terms/s) on %u GPU streams\n",
                     (unsigned long long)st.term_updates, st.kernel_ms, st.kernel_ms > 0 ? 1e3 * (double)st.term_updates / st.kernel_ms : 0.0, st.n_streams);
     }
-    for (uint64_t i = 0; i < n_ends; ++i) { X[i] = Xf[i]; Y[i] = Yf[i]; }
 
     if (a.has("stress")) {
         double stress = 0, per_node = 0, per_bp = 0;

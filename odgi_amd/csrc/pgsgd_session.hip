@@ -672,6 +672,31 @@ extern "C" int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words) {
     return PGSGD_OK;
 }
 
+// Coordinates in double precision: exactly x_off + q / quanta_per_bp for the fixed-point format (fp32 cannot hold
+// 1/16 bp at genome-scale coordinates: its spacing is 2-16 bp from 3e7 bp on), the fp32 words widened otherwise.
+extern "C" int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, double* Y) {
+    pgsgd::clear_error();
+    if (!s || !X || !Y) return PGSGD_E_INVALID;
+    std::vector<uint64_t> w(2 * s->n_nodes);
+    const int rc = pgsgd_session_download_words(s, w.data());
+    if (rc) return rc;
+    const pgsgd::Xform& xf = s->dc.xf;
+    for (uint64_t i = 0; i < w.size(); ++i) {
+        if (s->fmt == pgsgd::kFmtQ32) {
+            X[i] = xf.x_off + (double)(uint32_t)w[i] * (double)xf.inv_scale;
+            Y[i] = xf.y_off + (double)(uint32_t)(w[i] >> 32) * (double)xf.inv_scale;
+        } else {
+            uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
+            float fx, fy;
+            memcpy(&fx, &lo, 4);
+            memcpy(&fy, &hi, 4);
+            X[i] = fx;
+            Y[i] = fy;
+        }
+    }
+    return PGSGD_OK;
+}
+
 extern "C" int pgsgd_session_coord_format(const pgsgd_session* s, int* fixed_point, double* x_off, double* y_off, double* quanta_per_bp) {
     if (!s) return PGSGD_E_INVALID;
     if (fixed_point) *fixed_point = s->fmt == pgsgd::kFmtQ32 ? 1 : 0;
@@ -984,7 +1009,24 @@ extern "C" int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t
 // the one-shot run: iteration control of path_sgd_layout.cpp:120-163 with exact iteration lengths
 int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);
 
+static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
+
 extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, pgsgd_stats* stats) {
+    return layout_run_impl(g, p, X, Y, nullptr, nullptr, stats);
+}
+
+// The same run with double-precision coordinates in and out: the initial layout is taken in fp32 (it only seeds
+// the SGD), the result comes back at the full resolution of the device's fixed-point words.
+extern "C" int pgsgd_layout_run_f64(const pgsgd_graph_view* g, const pgsgd_params* p, double* X, double* Y, pgsgd_stats* stats) {
+    pgsgd::clear_error();
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!g || !X || !Y) return PGSGD_E_INVALID;
+    std::vector<float> xf(2 * g->n_nodes), yf(2 * g->n_nodes);
+    for (uint64_t i = 0; i < xf.size(); ++i) { xf[i] = (float)X[i]; yf[i] = (float)Y[i]; }
+    return layout_run_impl(g, p, xf.data(), yf.data(), X, Y, stats);
+}
+
+static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
     pgsgd::clear_error();
     if (stats) memset(stats, 0, sizeof *stats);
     if (!g || !p || !X || !Y) return PGSGD_E_INVALID;
@@ -1041,7 +1083,7 @@ extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p
     }
     if (p->progress) fprintf(stderr, "\n");
     timer.lap("iterations");
-    if (rc == PGSGD_OK) rc = pgsgd_session_download_coords(s, X, Y);
+    if (rc == PGSGD_OK) rc = Xd ? pgsgd_session_download_coords_f64(s, Xd, Yd) : pgsgd_session_download_coords(s, X, Y);
     timer.lap("coordinates download");
     if (stats) {
         stats->iterations = iters;

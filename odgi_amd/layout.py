@@ -102,17 +102,23 @@ def initial_layout(graph: Graph, mode="d", seed=0):
 def path_linear_sgd_layout_gpu(graph: Graph, params: LayoutParams, X, Y):
     """The `--gpu` entry (path_sgd_layout.hpp:59-80): X,Y [2N] pre-initialised, updated IN PLACE.
 
-    Accepts float64 arrays like the reference's vector<atomic<double>> (converted to the kernel's
-    fp32 and back) or float32 arrays (used as is).  Returns the run statistics.
+    float64 arrays (the reference's vector<atomic<double>>) come back at the full resolution of the device's
+    fixed-point coordinates (pgsgd_layout_run_f64); float32 arrays are used as they are (pgsgd_layout_run).
+    Returns the run statistics.
     """
     if X.shape != (2 * graph.n_nodes,) or Y.shape != X.shape:
         raise ValueError("X and Y must have 2*node_count entries")
-    Xf = np.ascontiguousarray(X, dtype=np.float32)
-    Yf = np.ascontiguousarray(Y, dtype=np.float32)
     st = _lib.Stats()
     p = params.to_c()
-    check(lib.pgsgd_layout_run(C.byref(graph.view), C.byref(p), Xf.ctypes.data_as(_F32P), Yf.ctypes.data_as(_F32P),
-                               C.byref(st)), "layout_run")
+    if X.dtype == np.float32 and Y.dtype == np.float32:
+        Xf, Yf = np.ascontiguousarray(X), np.ascontiguousarray(Y)
+        check(lib.pgsgd_layout_run(C.byref(graph.view), C.byref(p), Xf.ctypes.data_as(_F32P), Yf.ctypes.data_as(_F32P),
+                                   C.byref(st)), "layout_run")
+    else:
+        Xf, Yf = np.ascontiguousarray(X, dtype=np.float64), np.ascontiguousarray(Y, dtype=np.float64)
+        f64p = C.POINTER(C.c_double)
+        check(lib.pgsgd_layout_run_f64(C.byref(graph.view), C.byref(p), Xf.ctypes.data_as(f64p), Yf.ctypes.data_as(f64p),
+                                       C.byref(st)), "layout_run_f64")
     X[...] = Xf
     Y[...] = Yf
     return {f: getattr(st, f) for f, _ in _lib.Stats._fields_}
@@ -155,6 +161,14 @@ class LayoutSession:
         X = np.zeros(n, dtype=np.float32)
         Y = np.zeros(n, dtype=np.float32)
         check(lib.pgsgd_session_download_coords(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
+        return X, Y
+
+    def download_f64(self):
+        """Coordinates in double precision: exactly x_off + q / quanta_per_bp of the fixed-point words."""
+        n = 2 * self.graph.n_nodes
+        X, Y = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
+        f64p = C.POINTER(C.c_double)
+        check(lib.pgsgd_session_download_coords_f64(self._h, X.ctypes.data_as(f64p), Y.ctypes.data_as(f64p)), "download_f64")
         return X, Y
 
     def download_words(self):

@@ -669,3 +669,33 @@ def test_kernel_plan_follows_graph_order_and_initial_layout(oa):
     assert s_random <= 1.15 * res["d", "per_lane"] + 0.01
     assert res["g", "default"] <= 1.1 * res["g", "per_lane"] + 0.01
     assert res["d", "default"] <= 1.15 * res["d", "per_lane"] + 0.01
+
+
+def test_double_precision_download_is_exact(oa, graphs):
+    """pgsgd_session_download_coords_f64 / pgsgd_layout_run_f64: the doubles are exactly x_off + q / quanta_per_bp of
+    the device words; the fp32 download is their rounding; on a far-away layout (coordinates ~1e9 bp, where fp32 is
+    spaced 64 bp apart) node ends one quantum apart stay distinct in double and collapse in fp32."""
+    g = graphs("LPA")
+    X0, Y0 = oa.initial_layout(g, "d", seed=4)
+    X0 = X0 + 1.0e9                                     # a layout far from the origin
+    p = _params(oa, g)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        s.upload(X0, Y0)
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+        s.sync()
+        fixed, x_off, y_off, q = s.coord_format()
+        w = s.download_words()
+        Xd, Yd = s.download_f64()
+        Xf, Yf = s.download()
+    assert fixed
+    assert np.array_equal(Xd, x_off + (w & np.uint64(0xffffffff)).astype(np.float64) / q)
+    assert np.array_equal(Yd, y_off + (w >> np.uint64(32)).astype(np.float64) / q)
+    assert np.array_equal(Xf, Xd.astype(np.float32)) and np.array_equal(Yf, Yd.astype(np.float32))
+    assert len(np.unique(Xd)) > 2 * len(np.unique(Xf))  # fp32 cannot tell neighbouring node ends apart out there
+    # the one-call form returns the same kind of coordinates and a layout of oracle quality
+    X, Y = X0.copy(), Y0.copy()
+    oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+    assert X.dtype == np.float64 and np.all(np.abs((X - x_off) * q - np.rint((X - x_off) * q)) < 1e-3)
+    assert oa.path_stress(g, X, Y, 500_000) < 2.0
