@@ -12,7 +12,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <charconv>
 #include <cstring>
+#include <thread>
 #include <fstream>
 #include <limits>
 
@@ -359,11 +362,46 @@ extern "C" int pgsgd_write_tsv(const char* path, uint64_t n_nodes, const uint32_
         std::vector<uint64_t> cur(start.begin(), start.end() - 1);
         for (uint64_t i = 0; i < n_nodes; ++i) order[(size_t)cur[comp[i]]++] = (uint32_t)i;
     }
+    // rows are formatted on host threads into per-chunk buffers (std::to_chars, general format, precision 16 =
+    // what `out << std::setprecision(16)` prints upstream, layout.cpp:23), then written in order
+    std::vector<uint32_t> comp_of_row((size_t)n_nodes);
     for (uint64_t c = 0; c < n_comp; ++c)
-        for (uint64_t k = start[c]; k < start[c + 1]; ++k) {
-            const uint64_t i = order[(size_t)k], pos = 2 * i;
-            fprintf(f, "%llu\t%.16g\t%.16g\t%llu\n", (unsigned long long)pos, X[pos], Y[pos], (unsigned long long)c);
-            fprintf(f, "%llu\t%.16g\t%.16g\t%llu\n", (unsigned long long)(pos + 1), X[pos + 1], Y[pos + 1], (unsigned long long)c);
+        for (uint64_t k = start[c]; k < start[c + 1]; ++k) comp_of_row[(size_t)k] = (uint32_t)c;
+    const uint64_t chunk = 1 << 16;
+    const uint64_t n_chunks = (n_nodes + chunk - 1) / chunk;
+    std::vector<std::string> out((size_t)n_chunks);
+    std::atomic<uint64_t> next{0};
+    auto format = [&]() {
+        char num[64];
+        for (uint64_t ci = next.fetch_add(1); ci < n_chunks; ci = next.fetch_add(1)) {
+            std::string& o = out[(size_t)ci];
+            o.reserve(chunk * 2 * 48);
+            const uint64_t e = std::min(n_nodes, (ci + 1) * chunk);
+            for (uint64_t k = ci * chunk; k < e; ++k) {
+                const uint64_t pos = 2 * (uint64_t)order[(size_t)k];
+                for (uint64_t end = pos; end < pos + 2; ++end) {
+                    auto put_u = [&](uint64_t v) { o.append(num, std::to_chars(num, num + sizeof num, v).ptr); };
+                    auto put_d = [&](double v) { o.append(num, std::to_chars(num, num + sizeof num, v, std::chars_format::general, 16).ptr); };
+                    put_u(end); o.push_back('\t');
+                    put_d(X[end]); o.push_back('\t');
+                    put_d(Y[end]); o.push_back('\t');
+                    put_u(comp_of_row[(size_t)k]); o.push_back('\n');
+                }
+            }
+        }
+    };
+    {
+        const unsigned nt = n_chunks > 1 ? std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), (unsigned)n_chunks})) : 1u;
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(format);
+        format();
+        for (auto& t : th) t.join();
+    }
+    for (const std::string& o : out)
+        if (fwrite(o.data(), 1, o.size(), f) != o.size()) {
+            pgsgd::set_error("short write to '%s'", path);
+            if (f != stdout) fclose(f);
+            return PGSGD_E_IO;
         }
     if (f != stdout) fclose(f); else fflush(f);
     return PGSGD_OK;
