@@ -3,7 +3,7 @@
 // .lay (src/algorithms/layout.cpp:43-66): f64 min_value, then an sdsl::enc_vector<> (Elias-delta
 // coder, sample density 128) over the IEEE-754 bit patterns of X[i]-min, Y[i]-min interleaved.
 // sdsl-lite is not available, so the container is restated from its on-disk form, which the
-// reference fixture test/DRB1-3123_unsorted.og.lay pins byte for byte (tests/test_lay_io.py):
+// reference fixture test/DRB1-3123_unsorted.og.lay pins byte for byte (tests/test_host_logic.py):
 //   u64 n | z: u64 bit_len, u8 width(=1), ceil(bit_len/64) u64 | samples: u64 bit_len, u8 width w,
 //   ceil(bit_len/64) u64.   samples holds 2*ceil(n/128)+2 w-bit ints: (value at 128k, bit offset of
 //   block k in z) pairs and a final (0, z_bits+1).  Non-sample elements are Elias-delta codes of
