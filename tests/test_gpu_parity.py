@@ -478,15 +478,17 @@ def test_tiled_kernel_with_tandem_repeats(oa):
     assert res["tiled"] <= 1.3 * res["per_lane"] + 0.05
 
 
-def test_tile_sharded_virtual_ranks(oa):
+@pytest.mark.parametrize("init", ["d", "g"])
+def test_tile_sharded_virtual_ranks(oa, init):
     """Multi-GPU path of the tile kernel on one GPU: two sessions play ranks 0 and 1 (tiles rank, rank+2, ...
     of every work item, each with its whole share of the iteration's terms), merged after every iteration
     by the exchange kernels, the all-reduce replaced by a sum on the device.  Both ranks must end with the
-    same coordinates, and the stress must stay within 25 % (+0.02) of the one-rank run's."""
+    same coordinates, and the stress must stay within 25 % (+0.02) of the one-rank run's.  With the Gaussian
+    initial layout the iterations before cooling run the per-lane kernel, each rank with its half of the terms."""
     import torch
     from odgi_amd.distributed import HipEngine
     g = oa.Graph.synthetic(300_000, 24, seed=7)
-    X0, Y0 = oa.initial_layout(g, "d", seed=7)
+    X0, Y0 = oa.initial_layout(g, init, seed=7)
     p = _params(oa, g, min_term_updates=3 * g.n_steps)
     etas = oa.path_linear_sgd_layout_schedule(p)
     res = {}
@@ -494,7 +496,7 @@ def test_tile_sharded_virtual_ranks(oa):
         engines = [HipEngine(g, _params(oa, g, min_term_updates=3 * g.n_steps, stream_offset=r * (1 << 20)), X0, Y0) for r in range(G)]
         for r, e in enumerate(engines):
             e.exchange_mark()
-            assert e.tiled and e.set_shard(r, G, by_region=False)
+            assert e.tiled and e.set_shard(r, G, by_region=False) and e.warm_per_lane() == (init == "g")
         bufs = [e.new_exchange_buffer() for e in engines]
         for it in range(p.iter_max):
             for e in engines:
@@ -515,7 +517,7 @@ def test_tile_sharded_virtual_ranks(oa):
             assert np.abs(out[0][0] - out[1][0]).max() < 1.0 and np.abs(out[0][1] - out[1][1]).max() < 1.0
         assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
         res[G] = oa.path_stress(g, out[0][0], out[0][1], 1_000_000, seed=1)
-    print(f"tile-sharded virtual ranks: stress G=1 {res[1]:.4f} G=2 {res[2]:.4f}")
+    print(f"tile-sharded virtual ranks, init {init}: stress G=1 {res[1]:.4f} G=2 {res[2]:.4f}")
     assert res[2] <= 1.25 * res[1] + 0.02
 
 
