@@ -537,7 +537,29 @@ def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
     assert s <= 0.0871 * 1.25
 
 
-@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123"])
+def _ragged_graph(oa):
+    """3000 nodes, 60 paths of 1..400 steps: single-step paths (never sampled), two-step paths, paths walking
+    backwards on the reverse strand, tiles of a few steps, runs that straddle region borders."""
+    rs = np.random.RandomState(12)
+    n = 3000
+    node_len = rs.randint(1, 60, n).astype(np.uint32)
+    handles, first = [], [0]
+    for p in range(60):
+        cnt = [1, 2, 3][p] if p < 3 else int(rs.randint(2, 400))
+        start = int(rs.randint(0, n - cnt))
+        ranks = np.arange(start, start + cnt)
+        if p % 5 == 4:                                   # reverse-strand walk
+            h = (2 * ranks[::-1] + 1).astype(np.uint32)
+        else:
+            h = (2 * ranks).astype(np.uint32)
+            flip = rs.rand(cnt) < 0.05
+            h[flip] |= 1
+        handles.append(h)
+        first.append(first[-1] + cnt)
+    return oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
+
+
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
@@ -549,15 +571,15 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")
     monkeypatch.setenv("PGSGD_TILE_GRID", "1")
     monkeypatch.setenv("PGSGD_TILE_LANES", "1")
-    g = oa.Graph.synthetic(3000, 4, seed=3) if graph_name == "synthetic" else graphs("DRB1-3123")
+    g = oa.Graph.synthetic(3000, 4, seed=3) if graph_name == "synthetic" else _ragged_graph(oa) if graph_name == "ragged" else graphs("DRB1-3123")
     og = orc.Graph.from_product(g)
     X0, Y0 = oa.initial_layout(g, "d", seed=5)
-    p = _params(oa, g, iter_max=6, min_term_updates=2 * g.n_steps)
+    p = _params(oa, g, iter_max=6, min_term_updates=(20 if graph_name == "ragged" else 2) * g.n_steps)
     etas = oa.path_linear_sgd_layout_schedule(p)
     with oa.LayoutSession(g, p) as s:
         info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
         assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64
-        assert (info["n_nonlocal_tiles"] == 0) == (graph_name == "synthetic")
+        assert (info["n_nonlocal_tiles"] == 0) == (graph_name != "DRB1-3123")
         assert len(items["local"]) == info["n_work_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
         # the product's tile table and work items are exactly the independent restatement's (tests/pyref.py)
         import pyref
