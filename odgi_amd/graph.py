@@ -64,9 +64,10 @@ class Graph:
     @classmethod
     def from_arrays(cls, node_len, path_first, step_handle, step_pos=None, step_path=None, edges=None, path_names=None):
         g = cls()
-        node_len = np.ascontiguousarray(node_len, dtype=np.uint32)
-        path_first = np.ascontiguousarray(path_first, dtype=np.uint64)
-        step_handle = np.ascontiguousarray(step_handle, dtype=np.uint32)
+        # copies: the arguments may be views into another Graph's native arrays, which die with that Graph
+        node_len = np.array(node_len, dtype=np.uint32, order="C")
+        path_first = np.array(path_first, dtype=np.uint64, order="C")
+        step_handle = np.array(step_handle, dtype=np.uint32, order="C")
         n_paths = len(path_first) - 1
         if step_path is None:
             step_path = np.repeat(np.arange(n_paths, dtype=np.uint32), np.diff(path_first).astype(np.int64))
@@ -75,8 +76,8 @@ class Graph:
             csum = np.cumsum(lens) - lens
             first = csum[np.minimum(path_first[:-1], max(len(csum) - 1, 0)).astype(np.int64)] if len(csum) else csum
             step_pos = csum - np.repeat(first, np.diff(path_first).astype(np.int64)) if len(csum) else csum
-        step_path = np.ascontiguousarray(step_path, dtype=np.uint32)
-        step_pos = np.ascontiguousarray(step_pos, dtype=np.uint64)
+        step_path = np.array(step_path, dtype=np.uint32, order="C")
+        step_pos = np.array(step_pos, dtype=np.uint64, order="C")
         g._arrays = (node_len, path_first, step_path, step_handle, step_pos)
         v = g.view
         v.n_nodes, v.n_steps, v.n_paths = len(node_len), len(step_handle), n_paths
