@@ -273,7 +273,8 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
 }
 
 // Long-range step pairs for the initial-layout check of a tiled session: first step uniform over all steps,
-// partner uniform over the same path (the pairs the non-cooling phase draws half of the time).  The tile kernel
+// partner uniform over the same path (the pairs the non-cooling phase draws half of the time), kept when they
+// are more than eight windows apart.  The tile kernel
 // moves a node end over long distances only twice per iteration (the capped far pulls of the two launches), which
 // is enough to refine a layout whose global structure is there — `-N d` on a sorted graph — and too little to
 // form it: from `-N g`, `-N r`, `-N h` or on a graph sorted only in blocks the tiled layouts end 6-40 % worse
@@ -284,6 +285,11 @@ static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
     pgsgd::Xoshiro256Plus rng;
     rng.seed(0x5eedc0de);
     s->check_pairs.clear();
+    // "long range" = farther than eight windows: nearer pairs are moved at full strength inside the windows
+    // whatever the initial layout (and the Gaussian Y of `-N d` dominates their distances)
+    uint64_t total_bp = 0;
+    for (uint64_t i = 0; i < g->n_nodes; ++i) total_bp += g->node_len[i];
+    const double d_min = 8.0 * 2.0 * (double)s->region * ((double)total_bp / (double)g->n_nodes);
     for (int tries = 0; tries < 65536 && s->check_pairs.size() < 16384; ++tries) {
         const uint64_t ka = pgsgd::uniform_below(rng, g->n_steps);
         const uint32_t path = g->step_path[ka];
@@ -291,7 +297,7 @@ static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
         if (cnt < 2) continue;
         const uint64_t kb = b + pgsgd::uniform_below(rng, cnt);
         const uint64_t pa = g->step_pos[ka], pb = g->step_pos[kb];
-        if (pa == pb) continue;
+        if ((double)(pa > pb ? pa - pb : pb - pa) < d_min) continue;
         pgsgd_session::CheckPair cp;
         cp.end_a = g->step_handle[ka];  // the end a step starts at: 2 * rank + is_reverse
         cp.end_b = g->step_handle[kb];
@@ -301,7 +307,7 @@ static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
 }
 
 static double check_pairs_stress(const pgsgd_session* s, const float* X, const float* Y) {
-    if (s->check_pairs.empty()) return 0.0;
+    if (s->check_pairs.size() < 256) return 0.0;  // (almost) no long-range pairs: nothing global to form
     double sum = 0;
     for (const auto& cp : s->check_pairs) {
         const double dx = (double)X[cp.end_a] - (double)X[cp.end_b], dy = (double)Y[cp.end_a] - (double)Y[cp.end_b];
