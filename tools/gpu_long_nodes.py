@@ -35,11 +35,17 @@ def binned(X, Y):
     return {f"d<{hi:g}": float(e[ok & (d >= lo_) & (d < hi)].mean()) for lo_, hi in bins}
 
 print(json.dumps(dict(what="initial", **binned(X0, Y0))), flush=True)
-for name, flags in (("per_lane_q32", _lib.FLAG_NO_TILES), ("per_lane_f32", _lib.FLAG_NO_TILES | _lib.FLAG_FP32_ATOMICS), ("default_plan", 0)):
-    p = oa.LayoutParams.defaults(g, device=0, flags=flags)
+streams = [int(x) for x in os.environ.get("STREAMS", "0").split(",")]
+variants = [("per_lane_q32", _lib.FLAG_NO_TILES, 0), ("per_lane_f32", _lib.FLAG_NO_TILES | _lib.FLAG_FP32_ATOMICS, 0), ("default_plan", 0, 0)]
+if streams != [0]:
+    variants = [(f"per_lane_q32_streams{n_}", _lib.FLAG_NO_TILES, n_) for n_ in streams] + [(f"per_lane_stores_streams{n_}", _lib.FLAG_NO_TILES | _lib.FLAG_HOGWILD_STORES, n_) for n_ in streams[:2]]
+for name, flags, ns in variants:
+    p = oa.LayoutParams.defaults(g, device=0, flags=flags, n_streams=ns)
     X, Y = X0.copy(), Y0.copy()
     st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
     print(json.dumps(dict(what=name, kernel_ms=st["kernel_ms"], stress=oa.path_stress(g, X, Y, 2_000_000, seed=1), **binned(X, Y))), flush=True)
+if os.environ.get("SKIP_ORACLE"):
+    sys.exit(0)
 p = oa.LayoutParams.defaults(g)
 Xo, Yo, st = orc.layout_hogwild(og, orc.params_from(p), os.cpu_count() or 1, X0, Y0, fast=True)
 print(json.dumps(dict(what="cpu_oracle", seconds=st["seconds"], terms=st["terms"], stress=oa.path_stress(g, Xo, Yo, 2_000_000, seed=1), **binned(Xo, Yo))), flush=True)
