@@ -59,7 +59,7 @@ struct pgsgd_session {
     uint32_t tile_lanes = 0;              // lanes of a tile-kernel launch (n_streams stays the per-lane count)
     struct CheckPair { uint32_t end_a, end_b; float d; };
     std::vector<CheckPair> check_pairs;   // long-range step pairs for the initial-layout check
-    uint32_t region = 512, tile_steps = 448, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
+    uint32_t region = 256, tile_steps = 224, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
@@ -412,15 +412,11 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     // fewer lanes than the GPU holds; everything else runs the per-lane kernel
     if (!(p->flags & (PGSGD_FLAG_NO_TILES | PGSGD_FLAG_COORD_LOAD_PLAIN | PGSGD_FLAG_ABLATE(15))) && s->fmt == pgsgd::kFmtQ32 &&
         s->upd == pgsgd::kUpdAtomic && !p->n_streams && p->terms_per_anchor <= 1) {
-        // Region size: a launch has N / 2R work items (one colour) and a workgroup takes one at a time, so
-        // R = 512 fills the ~1000 workgroup slots of the chip only from ~1e6 nodes; below that R = 256 doubles
-        // the work items at the same 256 lanes per workgroup (one lane per 4 window ends instead of 8;
-        // measured at 300k nodes: 1.97e10 vs 1.33e10 terms/s, stress 0.156 vs 0.155, and no gain at 1e6 nodes,
+        // Region size R = 256 (tiles of 224 steps), 256 lanes per workgroup = one lane per 4 window ends.  A launch has
+        // N / 2R work items and a workgroup takes one at a time, so smaller regions fill the chip from smaller graphs
+        // (300k nodes: 1.97e10 terms/s against 1.33e10 with R = 512) and cost nothing on large ones (1e6 nodes, five
+        // seeds each: 3.10e10 terms/s, stress 0.246 against 2.98e10, 0.255 with R = 512;
         // profiles/r01/tiles_region_256_vs_512.jsonl).  R = 128 with 256 lanes diverges.
-        if (g->n_nodes / (2ull * 512) < (uint64_t)(0.9 * 4 * prop.multiProcessorCount)) {
-            s->region = 256;
-            s->tile_steps = 224;
-        }
         if (const char* e = getenv("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
             const long r = atol(e);
             if (r >= 32 && r <= 2048 && (r & (r - 1)) == 0) {
