@@ -38,12 +38,6 @@ bool parse_uint(const char* b, const char* e, uint64_t* out) {
     return true;
 }
 
-struct ParsedPath {
-    std::vector<uint32_t> handles;
-    int err = 0;
-    std::string msg;
-};
-
 }  // namespace
 
 extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph** out) {
@@ -166,91 +160,120 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         }
     }
     timer.lap("gfa: distinct edges");
-    // paths: parsed in parallel, numbered in file order
+    // Paths are numbered in file order.  The segment list of a P line is cut into chunks at commas, so that one
+    // very long path (a reference chromosome next to fragmented assemblies) is parsed by all threads too:
+    // pass 1 counts the steps of every chunk, pass 2 parses them straight into the step arrays and sums the bp of
+    // each chunk, pass 3 turns the sums into the bp offset of every step (xp.cpp:607-617).
     const uint64_t P = p_lines.size();
-    std::vector<ParsedPath> parsed(P);
     g->path_names.resize(P);
-    std::atomic<uint64_t> next_path{0};
-    auto worker = [&]() {
-        for (;;) {
-            const uint64_t i = next_path.fetch_add(1);
-            if (i >= P) break;
-            const Line& ln = p_lines[i];
-            const char* nb = ln.b + 2;
-            const char* ne = next_tab(nb, ln.e);
-            g->path_names[i].assign(nb, ne);
-            const char* sb = ne < ln.e ? ne + 1 : ln.e;
-            const char* se = next_tab(sb, ln.e);
-            ParsedPath& pp = parsed[i];
-            // count commas for a single allocation
-            pp.handles.reserve((size_t)std::count(sb, se, ',') + 1);
-            const char* p = sb;
-            while (p < se) {
-                const char* c = (const char*)memchr(p, ',', (size_t)(se - p));
-                const char* te = c ? c : se;
-                if (te > p && !(te - p == 1 && *p == '*')) {
-                    const char orient = te[-1];
-                    uint64_t id;
-                    if ((orient != '+' && orient != '-') || !parse_uint(p, te - 1, &id)) {
-                        pp.err = PGSGD_E_FORMAT;
-                        pp.msg = "malformed path segment '" + std::string(p, te) + "' in path '" + g->path_names[i] + "'";
-                        break;
-                    }
-                    if (id < 1 || id > N) {
-                        pp.err = PGSGD_E_FORMAT;
-                        pp.msg = "path '" + g->path_names[i] + "' visits missing node '" + std::string(p, te - 1) + "'";
-                        break;
-                    }
-                    pp.handles.push_back((uint32_t)(2 * (id - 1) + (orient == '-' ? 1 : 0)));
-                }
-                p = c ? c + 1 : se;
-            }
+    struct Chunk { uint64_t path; const char* b; const char* e; uint64_t steps = 0, first = 0, bp = 0, pos0 = 0; int err = 0; std::string msg; };
+    std::vector<Chunk> chunks;
+    std::vector<uint64_t> first_chunk(P + 1, 0);
+    const size_t kChunkBytes = 1 << 18;
+    for (uint64_t i = 0; i < P; ++i) {
+        const Line& ln = p_lines[i];
+        const char* nb = ln.b + 2;
+        const char* ne = next_tab(nb, ln.e);
+        g->path_names[i].assign(nb, ne);
+        const char* sb = ne < ln.e ? ne + 1 : ln.e;
+        const char* se = next_tab(sb, ln.e);
+        first_chunk[i] = chunks.size();
+        const char* b = sb;
+        while (b < se) {
+            const char* e = (size_t)(se - b) > kChunkBytes ? (const char*)memchr(b + kChunkBytes, ',', (size_t)(se - b) - kChunkBytes) : nullptr;
+            e = e ? e + 1 : se;  // a chunk ends right after a comma
+            Chunk c;
+            c.path = i;
+            c.b = b;
+            c.e = e;
+            chunks.push_back(c);
+            b = e;
+        }
+    }
+    first_chunk[P] = chunks.size();
+    const int nt = std::max(1, std::min(n_threads, 64));
+    auto for_each_chunk = [&](auto&& fn) {
+        std::atomic<uint64_t> next{0};
+        auto body = [&]() {
+            for (uint64_t ci = next.fetch_add(1); ci < chunks.size(); ci = next.fetch_add(1)) fn(chunks[ci]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt && (size_t)t < chunks.size(); ++t) th.emplace_back(body);
+        body();
+        for (auto& t : th) t.join();
+    };
+    // a token is what lies between commas; empty tokens and the placeholder "*" are not steps
+    auto for_each_token = [](const Chunk& c, auto&& fn) {
+        const char* p = c.b;
+        while (p < c.e) {
+            const char* cm = (const char*)memchr(p, ',', (size_t)(c.e - p));
+            const char* te = cm ? cm : c.e;
+            if (te > p && !(te - p == 1 && *p == '*'))
+                if (!fn(p, te)) return;
+            p = cm ? cm + 1 : c.e;
         }
     };
-    {
-        const int nt = std::max(1, std::min(n_threads, 64));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
-        worker();
-        for (auto& t : th) t.join();
-    }
-    timer.lap("gfa: P lines (threads)");
-    for (uint64_t i = 0; i < P; ++i)
-        if (parsed[i].err) {
-            set_error("%s", parsed[i].msg.c_str());
-            const int rc = parsed[i].err;
-            delete g;
-            return rc;
-        }
+    for_each_chunk([&](Chunk& c) {
+        uint64_t n = 0;
+        for_each_token(c, [&](const char*, const char*) { ++n; return true; });
+        c.steps = n;
+    });
     g->path_first.assign(P + 1, 0);
-    for (uint64_t i = 0; i < P; ++i) g->path_first[i + 1] = g->path_first[i] + parsed[i].handles.size();
+    {
+        uint64_t k = 0;
+        for (uint64_t i = 0; i < P; ++i) {
+            g->path_first[i] = k;
+            for (uint64_t ci = first_chunk[i]; ci < first_chunk[i + 1]; ++ci) { chunks[ci].first = k; k += chunks[ci].steps; }
+        }
+        g->path_first[P] = k;
+    }
     const uint64_t S = g->path_first[P];
     g->step_path.resize(S);
     g->step_handle.resize(S);
     g->step_pos.resize(S);
-    std::atomic<uint64_t> next_fill{0};
-    auto filler = [&]() {
-        for (;;) {
-            const uint64_t i = next_fill.fetch_add(1);
-            if (i >= P) break;
-            uint64_t k = g->path_first[i], pos = 0;
-            for (uint32_t h : parsed[i].handles) {
-                g->step_path[k] = (uint32_t)i;
-                g->step_handle[k] = h;
-                g->step_pos[k] = pos;
-                pos += g->node_len[h >> 1];
-                ++k;
+    for_each_chunk([&](Chunk& c) {
+        uint64_t k = c.first, bp = 0;
+        const std::string& name = g->path_names[c.path];
+        for_each_token(c, [&](const char* p, const char* te) {
+            const char orient = te[-1];
+            uint64_t id;
+            if ((orient != '+' && orient != '-') || !parse_uint(p, te - 1, &id)) {
+                c.err = PGSGD_E_FORMAT;
+                c.msg = "malformed path segment '" + std::string(p, te) + "' in path '" + name + "'";
+                return false;
             }
-            std::vector<uint32_t>().swap(parsed[i].handles);
+            if (id < 1 || id > N) {
+                c.err = PGSGD_E_FORMAT;
+                c.msg = "path '" + name + "' visits missing node '" + std::string(p, te - 1) + "'";
+                return false;
+            }
+            g->step_path[k] = (uint32_t)c.path;
+            g->step_handle[k] = (uint32_t)(2 * (id - 1) + (orient == '-' ? 1 : 0));
+            bp += g->node_len[id - 1];
+            ++k;
+            return true;
+        });
+        c.bp = bp;
+    });
+    timer.lap("gfa: P lines (threads)");
+    for (const Chunk& c : chunks)  // the first error in file order
+        if (c.err) {
+            set_error("%s", c.msg.c_str());
+            const int rc = c.err;
+            delete g;
+            return rc;
         }
-    };
-    {
-        const int nt = std::max(1, std::min(n_threads, 64));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(filler);
-        filler();
-        for (auto& t : th) t.join();
+    for (uint64_t i = 0; i < P; ++i) {
+        uint64_t pos = 0;
+        for (uint64_t ci = first_chunk[i]; ci < first_chunk[i + 1]; ++ci) { chunks[ci].pos0 = pos; pos += chunks[ci].bp; }
     }
+    for_each_chunk([&](Chunk& c) {
+        uint64_t pos = c.pos0;
+        for (uint64_t k = c.first; k < c.first + c.steps; ++k) {
+            g->step_pos[k] = pos;
+            pos += g->node_len[g->step_handle[k] >> 1];
+        }
+    });
     timer.lap("gfa: step index (threads)");
     *out = g;
     return PGSGD_OK;
