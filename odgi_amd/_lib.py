@@ -128,7 +128,7 @@ for _name, _res, _args in SIGNATURES:
 class PgsgdError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
-        detail = lib.pgsgd_last_error().decode()
+        detail = lib.pgsgd_last_error().decode(errors="replace")  # messages may quote bytes of a damaged file
         super().__init__(f"{where}: {lib.pgsgd_strerror(code).decode()}" + (f" ({detail})" if detail else ""))
 
 

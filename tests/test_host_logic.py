@@ -284,3 +284,54 @@ def test_tsv_rows_are_printf_16_significant_digits(oa, tmp_path):
         for e in (2 * i, 2 * i + 1):
             want.append("%d\t%.16g\t%.16g\t%d" % (e, X[e], Y[e], comp[i]))
     assert lines[1:-1] == want
+
+
+def test_gfa_and_lay_readers_survive_corruption(oa, tmp_path):
+    """Random damage to a GFA or a .lay file ends in an error code or in a consistent result, never in a crash."""
+    from odgi_amd._lib import PgsgdError
+    rs = np.random.RandomState(7)
+    raw = bytearray(open(os.path.join(GOLDEN, "t.gfa"), "rb").read() + open(os.path.join(GOLDEN, "k.gfa"), "rb").read()[:0])
+    big = bytearray(open(os.path.join(GOLDEN, "DRB1-3123_unsorted.gfa"), "rb").read())
+    f = tmp_path / "f.gfa"
+    n_ok = n_err = 0
+    for t in range(120):
+        b = bytearray(big if t % 2 else raw)
+        for _ in range(rs.randint(1, 8)):
+            i = rs.randint(0, len(b))
+            b[i] = rs.choice([9, 10, 43, 45, 44, 42, 48 + rs.randint(10), rs.randint(256)])
+        if t % 7 == 0:
+            b = b[: rs.randint(1, len(b))]
+        f.write_bytes(bytes(b))
+        try:
+            g = oa.Graph.from_gfa(f, threads=3)
+        except PgsgdError as e:
+            assert e.code in (-5, -6, -7, -8)
+            n_err += 1
+            continue
+        n_ok += 1
+        assert int((g.step_handle >> 1).max(initial=0)) < g.n_nodes and g.path_first[-1] == g.n_steps
+        lens = g.node_len[g.step_handle >> 1].astype(np.uint64)
+        for p in range(g.n_paths):
+            a, e = int(g.path_first[p]), int(g.path_first[p + 1])
+            assert np.array_equal(g.step_pos[a:e], np.cumsum(lens[a:e]) - lens[a:e])
+    assert n_ok > 0 and n_err > 0
+    lay = bytearray(open(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"), "rb").read())
+    fl = tmp_path / "f.lay"
+    n_ok = n_err = 0
+    for t in range(120):
+        b = bytearray(lay)
+        for _ in range(rs.randint(1, 6)):
+            b[rs.randint(0, len(b))] = rs.randint(256)
+        if t % 5 == 0:
+            b = b[: rs.randint(1, len(b))]
+        if t % 11 == 0:
+            b[8:16] = rs.bytes(8)                      # the element count
+        fl.write_bytes(bytes(b))
+        try:
+            L = oa.Layout.load(fl)
+            n_ok += 1
+            assert len(L.X) == len(L.Y)
+        except PgsgdError as e:
+            assert e.code in (-4, -5, -6)
+            n_err += 1
+    assert n_ok > 0 and n_err > 0
