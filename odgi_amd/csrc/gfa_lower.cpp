@@ -32,7 +32,9 @@ bool parse_uint(const char* b, const char* e, uint64_t* out) {
     uint64_t v = 0;
     for (const char* p = b; p < e; ++p) {
         if (*p < '0' || *p > '9') return false;
-        v = v * 10 + (uint64_t)(*p - '0');
+        const uint64_t d = (uint64_t)(*p - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;  // does not fit 64 bits: not an id
+        v = v * 10 + d;
     }
     *out = v;
     return true;

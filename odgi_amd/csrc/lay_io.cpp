@@ -220,6 +220,7 @@ extern "C" int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** Xo, d
     uint64_t zbits; uint8_t zw;
     memcpy(&zbits, &b[p], 8); p += 8;
     zw = b[p++];
+    if (zbits > 8 * (uint64_t)size) { set_error("truncated .lay (deltas)"); return PGSGD_E_FORMAT; }
     const size_t zwords = (size_t)((zbits + 63) / 64);
     if (!need(zwords * 8 + 9)) { set_error("truncated .lay (deltas)"); return PGSGD_E_FORMAT; }
     std::vector<uint64_t> z(zwords + 1, 0);
@@ -227,6 +228,7 @@ extern "C" int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** Xo, d
     uint64_t sbits; uint8_t sw;
     memcpy(&sbits, &b[p], 8); p += 8;
     sw = b[p++];
+    if (sbits > 8 * (uint64_t)size) { set_error("truncated .lay (samples)"); return PGSGD_E_FORMAT; }
     const size_t swords = (size_t)((sbits + 63) / 64);
     if (!need(swords * 8) || sw == 0 || sw > 64 || (n && zw != 1)) { set_error("truncated or malformed .lay (samples)"); return PGSGD_E_FORMAT; }
     PackedInts sv;
@@ -235,6 +237,7 @@ extern "C" int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** Xo, d
     sv.w.assign(swords + 1, 0);
     memcpy(sv.w.data(), &b[p], swords * 8); p += swords * 8;
     if (n % 2) { set_error(".lay holds an odd number of values"); return PGSGD_E_FORMAT; }
+    if (n > zbits + sv.count) { set_error(".lay claims more values than its streams can hold"); return PGSGD_E_FORMAT; }  // >= 1 bit each
     const uint64_t blocks = (n + 127) / 128;
     if (n && sv.count < 2 * blocks + 2) { set_error(".lay sample table too small"); return PGSGD_E_FORMAT; }
     const uint64_t ends = n / 2;
@@ -243,22 +246,35 @@ extern "C" int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** Xo, d
     if (!X || !Y) { free(X); free(Y); return PGSGD_E_NOMEM; }
     BitReader br{z.data(), zbits, 0};
     uint64_t v = 0;
+    auto corrupt = [&](const char* what) {
+        free(X);
+        free(Y);
+        set_error(".lay %s", what);
+        return PGSGD_E_FORMAT;
+    };
     for (uint64_t i = 0; i < n; ++i) {
         if (i % 128 == 0) {
             v = sv.get(2 * (i / 128));
             br.pos = sv.get(2 * (i / 128) + 1);
+            if (br.pos > zbits) return corrupt("block offset beyond the delta stream");
         } else {
+            // Elias delta: L zeros, a one, L bits of the length, length-1 bits of the value; L <= 6, length <= 65
             int L = 0;
-            while (br.pos < zbits && !br.bit()) ++L;
+            for (;;) {
+                if (br.pos >= zbits || L > 6) return corrupt("delta stream overrun");
+                if (br.bit()) break;
+                ++L;
+            }
             uint64_t x;
             if (L == 0) {
                 x = 1;
             } else {
+                if (br.pos + (uint64_t)L > zbits) return corrupt("delta stream overrun");
                 const uint64_t len = br.get(L) | (1ull << L);
+                if (len > 65 || br.pos + (len - 1) > zbits) return corrupt("delta stream overrun");
                 const uint64_t u = br.get((int)len - 1);
                 x = len - 1 >= 64 ? u : (u | (1ull << (len - 1)));  // len 65 encodes 2^64 == 0
             }
-            if (br.pos > zbits) { free(X); free(Y); set_error(".lay delta stream overrun"); return PGSGD_E_FORMAT; }
             v += x;
         }
         double d;
