@@ -335,3 +335,40 @@ def test_gfa_and_lay_readers_survive_corruption(oa, tmp_path):
             assert e.code in (-4, -5, -6)
             n_err += 1
     assert n_ok > 0 and n_err > 0
+
+
+def test_readers_under_sanitizers(tmp_path):
+    """The GFA, .og and .lay readers built with AddressSanitizer + UBSan and fed damaged files (byte flips,
+    truncation, extreme values in length fields): no sanitizer report, no abnormal exit."""
+    import random
+    import subprocess
+    csrc = os.path.join(ROOT, "odgi_amd", "csrc")
+    exe = tmp_path / "fuzz_readers"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + os.path.join(ROOT, "include"), "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "fuzz_readers.cpp")] +
+                          [os.path.join(csrc, f) for f in ("gfa_lower.cpp", "og_reader.cpp", "lay_io.cpp", "pgsgd_host.cpp")] + ["-lpthread"])
+    rnd = random.Random(11)
+    extreme = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFC18, 1 << 63, 1 << 32, (1 << 31) - 1, 0]
+    sources = {"gfa": "DRB1-3123_unsorted.gfa", "og": "DRB1-3123_sorted.og", "lay": "DRB1-3123_unsorted.og.lay"}
+    env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1:detect_leaks=1")
+    for kind, name in sources.items():
+        blob = open(os.path.join(GOLDEN, name), "rb").read()
+        files = []
+        for t in range(90):
+            b = bytearray(blob)
+            for _ in range(rnd.randint(0, 6)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256) if kind != "gfa" else rnd.choice([9, 10, 43, 45, 44, 42, 48 + rnd.randrange(10)])
+            r = rnd.random()
+            if r < 0.15:
+                b = b[: rnd.randint(1, len(b))]
+            elif r < 0.7 and kind != "gfa":
+                i = rnd.choice([4, 8, 12, 16, 20, 24, 28, 36, 44, 52, rnd.randint(60, len(b) - 8), len(b) - rnd.randint(8, 120)])
+                b[i:i + 8] = rnd.choice(extreme).to_bytes(8, "little")
+            elif r < 0.5:
+                i = rnd.randrange(len(b))
+                b[i:i] = str(rnd.choice([0, 18446744073709551615, 99999999999999999999999, 4294967296])).encode()
+            f = tmp_path / f"{kind}{t}"
+            f.write_bytes(bytes(b))
+            files.append(str(f))
+        r = subprocess.run([str(exe), kind] + files, capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-3000:]
