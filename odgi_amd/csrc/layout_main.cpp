@@ -23,10 +23,10 @@ namespace {
 struct Opt { char s; const char* l; bool has_value; const char* meta; const char* help; };
 
 const Opt kOpts[] = {
-    {'i', "idx", true, "FILE", "Load the variation graph from this *FILE* (GFAv1)."},
+    {'i', "idx", true, "FILE", "Load the succinct variation graph in ODGI format from this *FILE* (the default extension is .og); a file name ending in gfa is read as GFAv1; - reads .og from standard input."},
     {'o', "out", true, "FILE", "Write the layout coordinates to this FILE in .lay binary format."},
     {'T', "tsv", true, "FILE", "Write the layout in TSV format to this FILE."},
-    {'X', "path-index", true, "FILE", "Load the path index from this FILE (not supported: the index is lowered from the GFA)."},
+    {'X', "path-index", true, "FILE", "Load the path index from this FILE (not supported: the index is lowered from the graph input)."},
     {'C', "temp-dir", true, "PATH", "directory for temporary files (accepted; no temporary files are written)"},
     {'f', "path-sgd-use-paths", true, "FILE", "Line separated list of paths used to derive the default term count, Zipf space and eta_max."},
     {'N', "layout-initialization", true, "C", "Layout initialization mode: d) node rank in X, gaussian noise in Y (default); r) uniform noise in X and Y; u) node rank in X, uniform noise in Y; g) gaussian noise in X and Y; h) Hilbert curve."},
