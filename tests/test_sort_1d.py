@@ -135,3 +135,18 @@ def test_1d_target_nodes_bit_exact_and_frozen(oa, orc, graphs, ographs):
     p = sort_params_defaults(g, device=0)
     Xf, _ = path_linear_sgd(g, p, target_nodes=frozen)
     assert np.array_equal(Xf[frozen == 1], X0[frozen == 1])
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_paths_one_node_long(oa):
+    """The reference's own unit test of the 1D path (src/unittest/sort.cpp:130-231, "Sorting a graph with paths 1 node
+    long"): ten nodes "C", ten paths of one step each, iter_max 30, theta 0.99, eps 0.01, min_term_updates = total
+    steps, space = min(10000, longest path) = 1, eta_max = 1, cooling_start 1.0.  No path has two steps, so nothing
+    is sampled (path_sgd.cpp:56-66): the order is the input order and every path still begins at its node."""
+    from odgi_amd.sort import path_linear_sgd_order
+    g = oa.Graph.from_arrays(np.ones(10, dtype=np.uint32), np.arange(11, dtype=np.uint64), (2 * np.arange(10)).astype(np.uint32))
+    p = oa.LayoutParams(iter_max=30, iter_with_max_learning_rate=0, min_term_updates=10, delta=0.0, eps=0.01, eta_max=1.0, theta=0.99,
+                        space=1, space_max=1000, space_quantization_step=100, cooling_start=1.0, device=0)
+    order, X, st = path_linear_sgd_order(g, p)
+    assert order.tolist() == list(range(10)) and X.tolist() == [float(i) for i in range(10)] and st["term_updates"] == 0
+    assert g.step_handle.tolist() == [2 * i for i in range(10)]
