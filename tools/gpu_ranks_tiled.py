@@ -8,8 +8,8 @@ import odgi_amd as oa
 from odgi_amd.distributed import HipEngine, shard_terms, split_blocks
 g = oa.Graph.synthetic(1_000_000, 50, seed=42)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
-# argv[1]: "terms" (every rank runs every tile with 1/G of its terms) or "tiles" (default: every rank
-# runs every G-th tile with its whole share)
+# argv[1]: "terms" (every rank runs every tile with 1/G of its terms), "tiles" (default: every rank runs every
+# G-th tile with its whole share) or "regions" (every rank runs every G-th work item = node region with all its tiles)
 # argv[2]: comma-separated G:exchanges list (default 1:1,8:1,8:2,4:1,2:1); argv[3]: replicates (initial layout / sampler seeds)
 mode = sys.argv[1] if len(sys.argv) > 1 else "tiles"
 cfgs = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "1:1,8:1,8:2,4:1,2:1").split(",")]
@@ -23,7 +23,7 @@ for rep in range(reps):
         for r in range(G):
             pr = oa.LayoutParams.defaults(g, device=0, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep)
             e = HipEngine(g, pr, X0, Y0); e.exchange_mark(); engines.append(e)
-            sharded = mode == "tiles" and e.set_shard(r, G, by_region=False)
+            sharded = (mode == "tiles" and e.set_shard(r, G, by_region=False)) or (mode == "regions" and e.set_shard(r, G, by_region=True))
         bufs = [e.new_exchange_buffer() for e in engines]
         kms = 0.0
         for it in range(p.iter_max):
