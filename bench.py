@@ -98,9 +98,14 @@ def main():
         drv.step(it)
     eng.session.kernel_time(reset=True)
     fence()
+    per_iter = []          # (iteration, update-kernel ms, launches, snapshot ms, drain ms) — host bookkeeping after each
+    k_prev = (0.0, 0, 0.0, 0.0)   # step's own sync (the product's run loop syncs every iteration for delta_max too)
     t1 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
         drv.step(it)
+        k = eng.session.kernel_time() + eng.session.aux_time()
+        per_iter.append((it, k[0] - k_prev[0], k[1] - k_prev[1], k[2] - k_prev[2], k[3] - k_prev[3]))
+        k_prev = k
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
@@ -108,6 +113,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = eng.session.kernel_time()
+    snapshot_ms, drain_ms = eng.session.aux_time()
 
     total_terms = float(p.min_term_updates) * args.steps
     value = total_terms / elapsed
@@ -141,6 +147,30 @@ def main():
                      "avg_kernel_ms": 1e3 * avg_kernel_s,
                      "terms_per_launch": my_terms, "bytes_per_term": BYTES_PER_TERM},
     }
+    # The same arithmetic over everything a step costs, not only its dominant kernel: with the streaming kernels
+    # around every tile launch (coordinate snapshot, far-update drain), and against the wall clock of the step.
+    info = eng.session.tile_info()
+    rf = out["roofline"]
+    step_terms = drv.my_terms()
+    all_ms = (kernel_ms + snapshot_ms + drain_ms) / args.steps
+    rf["aux_kernels_ms_per_step"] = {"snapshot_kernel": snapshot_ms / args.steps, "far_drain_kernel": drain_ms / args.steps}
+    rf["frac_all_kernels"] = BYTES_PER_TERM * step_terms / (all_ms / 1e3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0
+    rf["frac_wall"] = BYTES_PER_TERM * step_terms / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
+    first_cooling = p.first_cooling_iteration()
+    phases = {}
+    for name, sel in (("warm", lambda it: it < first_cooling), ("cooling", lambda it: it >= first_cooling)):
+        rows = [r for r in per_iter if sel(r[0])]
+        if rows:
+            ms = sum(r[1] for r in rows) / len(rows)
+            ms_all = sum(r[1] + r[3] + r[4] for r in rows) / len(rows)
+            phases[name] = {"iterations": [rows[0][0], rows[-1][0]], "update_kernel_ms_per_step": ms, "all_kernels_ms_per_step": ms_all,
+                            "frac": BYTES_PER_TERM * step_terms / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_all_kernels": BYTES_PER_TERM * step_terms / (ms_all / 1e3) / 1e9 / HBM_PEAK_GBS}
+    rf["phases"] = phases
+    rf["whole_schedule"] = bool(args.warmup + args.steps >= iters and args.warmup <= 2)
+    out["config"]["kernel_plan"] = ("per-lane kernel" if not info["tiled"] else
+                                    "per-lane kernel until cooling, tile kernel after" if info["warm_per_lane"] else
+                                    "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
@@ -149,6 +179,8 @@ def main():
             with open(prof) as f:
                 pj = json.load(f)
             out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_raw"] = pj.get("hbm_bytes_per_launch_raw")   # FETCH_SIZE + WRITE_SIZE as reported
+            out["roofline"]["traffic_note"] = pj.get("note")
             out["roofline"]["traffic_source"] = pj.get("source")
         except Exception as e:  # noqa: BLE001
             log(f"[bench] could not read {prof}: {e}")
@@ -168,11 +200,22 @@ def main():
         og = orc.Graph.from_product(g)
         cores = os.cpu_count() or 1
         _, _, st = orc.layout_hogwild(og, orc.params_from(p), cores, X0, Y0, max_seconds=args.cpu_seconds, fast=True)
+        # the same loop on ONE thread (`-t 1`), a quarter of the budget
+        _, _, st1 = orc.layout_hogwild(og, orc.params_from(p), 1, X0, Y0, max_seconds=max(1.0, args.cpu_seconds / 4), fast=True)
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+        except Exception:  # noqa: BLE001
+            pass
         out["cpu_baseline"] = {
             "value": st["terms"] / st["seconds"] if st["seconds"] > 0 else 0.0,
             "unit": "terms/s", "cores": cores, "kind": "port",
             "sample": f"{st['terms']} terms in {st['seconds']:.1f} s of the same workload "
                       f"({cores} Hogwild threads, fp64, CPU restatement of the reference — upstream is unbuildable here)",
+            "single_thread": {"value": st1["terms"] / st1["seconds"] if st1["seconds"] > 0 else 0.0, "cores": 1,
+                              "sample": f"{st1['terms']} terms in {st1['seconds']:.1f} s, same loop, one thread (-t 1)"},
+            "cpu_model": cpu_model,
         }
     eng.close()
     if world > 1:

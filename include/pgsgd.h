@@ -176,6 +176,12 @@ int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint
 int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
+/* Tile kernel only: time spent in the two streaming kernels around every tile launch (coordinate snapshot into the
+ * step records before it, far-update drain after it), same clock and reset as pgsgd_session_kernel_time. */
+int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, double* drain_ms);
+/* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
+ * direct atomic adds instead (0 in normal operation; the pool is sized from the tile table). */
+int64_t pgsgd_session_outbox_overflow(pgsgd_session* s);
 uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
 /* Multi-GPU sharding of the tile kernel.  Every iteration call then takes the FULL term count of the
  * block, of which only the owned tiles' share is applied.
@@ -200,12 +206,15 @@ int pgsgd_session_exchange_mark(pgsgd_session* s);
 int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats);
 int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size);
 /* Parity hooks of the tile kernel.  Every term of a tiled iteration is a pure function of (seed +
- * stream_offset, iteration number, term index); tile_table copies up to `capacity` tiles (in work order:
+ * stream_offset, iteration number, tile, lane of the tile, position in the lane's stream); tile_table copies up to `capacity` tiles (in work order:
  * first step, steps before the tile, steps, path) and returns their number; trace_tile_terms replays the
  * terms tile `tile` draws in iteration `epoch` (1-based) of n_terms terms: out[4*j + {0..3}] = {flat step
  * a, flat step b, end offset a, end offset b}; returns the number of terms. */
 int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0, uint64_t* cum, uint32_t* n, uint32_t* path,
                                  uint64_t capacity, uint64_t* steps_total);
+/* Parity hook: lanes that work on each tile at once (at most the workgroup size; fewer where one node is visited
+ * often inside the tile); lane l draws the tile's terms l, l + lanes, ... from its own stream.  Returns the tile count. */
+int64_t pgsgd_session_tile_lanes(const pgsgd_session* s, uint32_t* lanes, uint64_t capacity);
 /* Parity hook: the work items of the tile kernel in launch order; item i runs tiles [tile_begin[i], tile_end[i])
  * of the tile table on the node window starting at rank win0[i] (local[i] = 0: no window, every end in global
  * memory); the first *n_first items belong to the launch of the even regions.  Returns the item count. */

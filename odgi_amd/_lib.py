@@ -78,11 +78,14 @@ SIGNATURES = [
     ("pgsgd_session_iteration_part", C.c_int, [C.c_void_p, f64, C.c_int, u64, u32, u32]),
     ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
+    ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
+    ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),
     ("pgsgd_session_exchange_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_exchange_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("pgsgd_session_tile_table", i64, [C.c_void_p, P(u64), P(u64), P(u32), P(u32), u64, P(u64)]),
+    ("pgsgd_session_tile_lanes", i64, [C.c_void_p, P(u32), u64]),
     ("pgsgd_session_tile_items", i64, [C.c_void_p, P(u32), P(u32), P(u32), P(u32), u64, P(u64)]),
     ("pgsgd_session_trace_tile_terms", i64, [C.c_void_p, u64, C.c_int, u64, u64, P(u64), u64]),
     ("pgsgd_session_set_shard", C.c_int, [C.c_void_p, u32, u32, C.c_int]),

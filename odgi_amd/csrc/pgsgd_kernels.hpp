@@ -51,6 +51,7 @@ struct DevConst {
     const uint4* recs;
     const uint64_t* path_first;
     const double* zetas;
+    const double2* zeta_denom;  // [same index] {zeta_n, 1 - zeta2/zeta_n}: one 16-byte load per Zipf draw (zipf_tabled)
     uint64_t* coords;  // [2N] words
     uint64_t* rng;
     unsigned int* delta_max_bits;
@@ -103,6 +104,7 @@ struct Term {
     uint64_t kb;
     uint64_t pos_a, pos_b;
     uint32_t end_a, end_b;  // 2*rank + end offset
+    uint32_t handle_b;      // the partner step's handle (2*rank + is_reverse): end_b ^ handle_b = 1 when the far end was chosen
     uint32_t dither;        // low 32 bits of the draw whose top bit chose end a (otherwise unused)
 };
 
@@ -128,38 +130,61 @@ struct GlobalRecs {  // partner records straight from HBM
     __device__ __forceinline__ uint4 operator()(uint64_t k) const { return recs[k]; }
 };
 
-template <class RecFetch>
-__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng, const RecFetch& fetch) {
-    Term t;
+// What a term draws once its first step is fixed (:205-237, then the two end choices :253,262): none of it depends on
+// the partner's record, so the tile kernel can issue the partner's gather and go on with other work.
+struct PartnerDraw {
+    uint64_t kb;
+    uint32_t flip_a, flip_b;
+    uint32_t dither;  // low 32 bits of the draw whose top bit chose end a (otherwise unused)
+};
+
+__device__ __forceinline__ PartnerDraw draw_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng) {
+    PartnerDraw d;
     uint64_t b_rank;
     if (cooling || coin(rng)) {                                               // :205
         const bool back = (a.s_rank > 0 && coin(rng)) || a.s_rank == a.cnt - 1;  // :206
         const uint64_t room = back ? a.s_rank : a.cnt - a.s_rank - 1;
         const uint64_t jump = c.space < room ? c.space : room;
-        const double zeta_n = c.zetas[zeta_index(jump, c.space_max, c.space_quant)];
-        const uint64_t z = zipf(rng, c.zc, jump, zeta_n);
+        const double2 zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
+        const uint64_t z = zipf_tabled(rng, c.zc, jump, zd.x, zd.y);
         b_rank = back ? a.s_rank - z : a.s_rank + z;
     } else {
         b_rank = uniform_below(rng, a.cnt);                                   // :235-237
     }
-    t.kb = a.pstart + b_rank;
-    const uint4 rb = fetch(t.kb);
-    // :242-269 — choose an end of each node; the path position moves to that end.
-    // flip(0,1) is the top bit of one draw (uniform_int_distribution never rejects for range 2).
+    d.kb = a.pstart + b_rank;
+    // :242-269 — choose an end of each node; flip(0,1) is the top bit of one draw (uniform_int_distribution never
+    // rejects for range 2)
     const uint64_t draw_a = rng.next(), draw_b = rng.next();
-    const uint32_t flip_a = (uint32_t)(draw_a >> 63), flip_b = (uint32_t)(draw_b >> 63);
-    t.dither = (uint32_t)draw_a;
+    d.flip_a = (uint32_t)(draw_a >> 63);
+    d.flip_b = (uint32_t)(draw_b >> 63);
+    d.dither = (uint32_t)draw_a;
+    return d;
+}
+
+// the path position moves to the chosen end of each node (:242-269)
+__device__ __forceinline__ Term make_term(const Anchor& a, const PartnerDraw& d, const uint4& rb) {
+    Term t;
+    t.kb = d.kb;
+    t.dither = d.dither;
     const uint32_t h_a = a.rec.x, h_b = rb.x;
     uint64_t pos_a = (uint64_t)a.rec.z | ((uint64_t)a.rec.w << 32);
     uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
     uint32_t off_a = h_a & 1u, off_b = h_b & 1u;
-    if (flip_a) { pos_a += a.rec.y; off_a ^= 1u; }
-    if (flip_b) { pos_b += rb.y; off_b ^= 1u; }
+    if (d.flip_a) { pos_a += a.rec.y; off_a ^= 1u; }
+    if (d.flip_b) { pos_b += rb.y; off_b ^= 1u; }
     t.pos_a = pos_a;
     t.pos_b = pos_b;
     t.end_a = (h_a & ~1u) | off_a;
     t.end_b = (h_b & ~1u) | off_b;
+    t.handle_b = h_b;
     return t;
+}
+
+template <class RecFetch>
+__device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& a, uint32_t cooling, Xoshiro256Plus& rng, RecFetch&& fetch) {
+    const PartnerDraw d = draw_partner(c, a, cooling, rng);
+    const uint4 rb = fetch(d.kb);
+    return make_term(a, d, rb);
 }
 
 // The displacement of one term in bp, fp32 (path_sgd_layout.cpp:280-352); dx,dy = p_a - p_b.
@@ -565,12 +590,19 @@ __global__ void seed_streams_kernel(uint64_t* rng, uint32_t n_streams, uint64_t 
 }
 
 // SoA view -> 16-byte step records, on the device (the gather of node_len happens once, here)
+// recs2 (tile kernel only, may be null): 32-byte records whose first half is the same record and whose second half
+// is refreshed with the node's coordinates before every tile launch (snapshot_kernel)
 __global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len,
-                                   uint64_t n_steps, uint4* recs) {
+                                   uint64_t n_steps, uint4* recs, uint4* recs2) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t h = step_handle[k];
         const uint64_t pos = step_pos[k];
-        recs[k] = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
+        const uint4 r = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
+        recs[k] = r;
+        if (recs2) {
+            recs2[2 * k] = r;
+            recs2[2 * k + 1] = make_uint4(0, 0, 0, 0);
+        }
     }
 }
 

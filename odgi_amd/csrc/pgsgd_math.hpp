@@ -96,9 +96,27 @@ PGSGD_HD double fast_precise_pow(double a, double b) {
     return r * frac;
 }
 
+// fast_precise_pow(a, b) with the exponent split once, on the host: e = (int)b, bfrac = b - (double)e.  The same
+// operations in the same order, so the same bits; e is then a uniform (scalar) loop count instead of a per-lane one.
+PGSGD_HD double pow_split(double a, int e, double bfrac) {
+    const int64_t bits = __builtin_bit_cast(int64_t, a);
+    const int32_t hi = (int32_t)(bits >> 32);
+    const int32_t nhi = (int32_t)(bfrac * (double)(hi - 1072632447) + 1072632447.0);
+    const double frac = __builtin_bit_cast(double, (int64_t)((uint64_t)(uint32_t)nhi << 32));
+    double r = 1.0;
+    while (e) {
+        if (e & 1) r *= a;
+        a *= a;
+        e >>= 1;
+    }
+    return r * frac;
+}
+
 // constants of the Zipf sampler that depend on theta only
 struct ZipfConst {
     double theta, alpha, one_minus_theta, zeta2, one_plus_half_pow;
+    double alpha_frac, omt_frac;  // exponents split for pow_split
+    int alpha_e, omt_e;
     PGSGD_HD void init(double th) {
         theta = th;
         alpha = 1.0 / (1.0 - th);
@@ -106,6 +124,10 @@ struct ZipfConst {
         const double half_pow = fast_precise_pow(0.5, th);
         zeta2 = fast_precise_pow(1.0, th) + half_pow;
         one_plus_half_pow = 1.0 + half_pow;
+        alpha_e = (int)alpha;
+        alpha_frac = alpha - (double)alpha_e;
+        omt_e = (int)one_minus_theta;
+        omt_frac = one_minus_theta - (double)omt_e;
     }
 };
 
@@ -117,6 +139,23 @@ PGSGD_HD uint64_t zipf(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n, doubl
     if (uz < 1.0) return 1;
     if (uz < zc.one_plus_half_pow) return 2;
     const double v = 1.0 + (double)n * fast_precise_pow(eta * u - eta + 1.0, zc.alpha);
+    uint64_t r = (v >= 1.0 && v < 1.8446744073709552e19) ? (uint64_t)v : 1;
+    if (r < 1) r = 1;
+    if (r > n) r = n;
+    return r;
+}
+
+// The same draw with what depends on zeta_n alone taken from a table: denom = 1.0 - zc.zeta2 / zeta_n, computed once
+// per table entry by the same two fp64 operations (zipf_denominator), and the exponents pre-split (pow_split).
+// Bit-identical to zipf(): one fp64 division and two per-lane exponent loops less per draw.
+PGSGD_HD double zipf_denominator(const ZipfConst& zc, double zeta_n) { return 1.0 - zc.zeta2 / zeta_n; }
+PGSGD_HD uint64_t zipf_tabled(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n, double zeta_n, double denom) {
+    const double eta = (1.0 - pow_split(2.0 / (double)n, zc.omt_e, zc.omt_frac)) / denom;
+    const double u = canonical(g);
+    const double uz = u * zeta_n;
+    if (uz < 1.0) return 1;
+    if (uz < zc.one_plus_half_pow) return 2;
+    const double v = 1.0 + (double)n * pow_split(eta * u - eta + 1.0, zc.alpha_e, zc.alpha_frac);
     uint64_t r = (v >= 1.0 && v < 1.8446744073709552e19) ? (uint64_t)v : 1;
     if (r < 1) r = 1;
     if (r > n) r = n;

@@ -46,6 +46,7 @@ struct pgsgd_session {
     uint4* d_recs = nullptr;
     uint64_t* d_path_first = nullptr;
     double* d_zetas = nullptr;
+    double2* d_zeta_denom = nullptr;
     uint64_t* d_coords = nullptr;         // [2N] coordinate words
     uint64_t* d_base = nullptr;           // coordinates at the last exchange (multi-GPU only)
     uint64_t* d_rng = nullptr;
@@ -63,9 +64,22 @@ struct pgsgd_session {
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
-    unsigned long long* d_far = nullptr;  // [2] far-partner updates of the last launch of each colour
-    unsigned long long* h_far = nullptr;  // pinned copy
-    float far_mu_cap[2] = {1.0f, 1.0f};   // per colour, from the previous launch of that colour
+    unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
+    uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
+    uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
+    std::vector<uint64_t> ob_bucket_steps;  // path steps on the nodes of each outbox bucket (sizes the pool shares)
+    pgsgd::Outbox ob{};                   // far-update outbox (device pointers)
+    uint32_t* d_ob_chunk0 = nullptr;
+    uint32_t* d_ob_cap = nullptr;
+    uint64_t ob_budget_terms = 0;         // terms per call the pool was sized for
+    double ob_msgs_per_term = 0.5;        // bound on the messages of one launch per term of the call (set from the tile table)
+    unsigned long long* d_ob_overflow = nullptr;  // messages that found their bucket's pool share used up (sent as atomics)
+    uint64_t ob_total_chunks = 0;
+    double aux_ms[2] = {0, 0};            // snapshot_kernel, far_drain_kernel (HIP events)
+    uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
+    uint64_t term0_terms = 0;
+    uint32_t ob_part_shift = 13;          // log2 of the node ends one drain workgroup accumulates in LDS
+    unsigned long long* d_ob_spill = nullptr;
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     std::vector<pgsgd::WorkItem> h_items; // host copy of the work items, colour 0 first (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
@@ -77,8 +91,10 @@ struct pgsgd_session {
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_grid = 0;
-    // kernel timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events, pending_events;
+    // kernel timing: e[0..1] bracket the update kernel; a tile launch also has e[2] (before its snapshot kernel)
+    // and e[3] (after its drain kernel)
+    struct EvSet { hipEvent_t e[4]; int n; };
+    std::vector<EvSet> free_events, pending_events;
     double kernel_ms = 0;
     uint64_t launches = 0;
 };
@@ -101,14 +117,30 @@ static int pick_device(int requested, int* out) {
 }
 
 static int collect_events(pgsgd_session* s) {
-    for (auto& pr : s->pending_events) {
+    for (auto& ev : s->pending_events) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        HIP_TRY(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
         s->kernel_ms += ms;
         s->launches++;
-        s->free_events.push_back(pr);
+        if (ev.n == 4) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev.e[2], ev.e[0]));
+            s->aux_ms[0] += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev.e[1], ev.e[3]));
+            s->aux_ms[1] += ms;
+        }
+        s->free_events.push_back(ev);
     }
     s->pending_events.clear();
+    return PGSGD_OK;
+}
+
+static int take_events(pgsgd_session* s, pgsgd_session::EvSet* out) {
+    if (!s->free_events.empty()) {
+        *out = s->free_events.back();
+        s->free_events.pop_back();
+        return PGSGD_OK;
+    }
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&out->e[i]));
     return PGSGD_OK;
 }
 
@@ -369,10 +401,20 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         }
         for (unsigned t = 0; t < nt; ++t)
             if (bad[t]) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
+        // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
+        // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
+        // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (a second bucketing pass is the fix).
+        uint32_t ob_shift = 13;
+        while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
+        s->ob.shift = ob_shift;
+        s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
+        s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
+        s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
         for (uint64_t i = 0; i < g->n_nodes; ++i) {
             uint64_t v = 0;
             for (unsigned t = 0; t < nt; ++t) v += per_node[t][i];
             s->max_node_steps = std::max(s->max_node_steps, v);
+            s->ob_bucket_steps[(2 * i) >> ob_shift] += v;
         }
     }
     timer.lap("hottest node (host)");
@@ -433,7 +475,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
         }
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
-        s->tile_lds = (size_t)8 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
+        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) +
+                      (size_t)s->ob.n_buckets * (pgsgd::kObLine * sizeof(uint4) + 2 * sizeof(uint32_t)) + 8 + (size_t)pgsgd::kTileWaves * 64 * sizeof(uint2);
         int bpc = 0;
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
@@ -454,13 +497,9 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             }
             timer.lap("tile table (host)");
             if ((p->flags & PGSGD_FLAG_ONE_SIDED_FAR) && !ht.n_nonlocal) {
-                // experiment: nobody but its owner writes a window, so no copy of the staged state, half
-                // the LDS, more resident workgroups (never more lanes than the hot-node cap).  Ignored on
-                // graphs with window-less tiles, whose terms write into other workgroups' windows.
+                // experiment, not the reference's rule: a far term moves only its first end, by twice the step.
+                // Ignored on graphs with window-less tiles.
                 s->tile_far = pgsgd::kFarExclusive;
-                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4);
-                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(s->tile_far), (int)s->tile_block, s->tile_lds));
-                bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, cap / cu_lanes));
             }
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
             if (const char* e = getenv("PGSGD_TILE_GRID")) {
@@ -476,6 +515,16 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (s->tiled) {
                 sample_check_pairs(s, g);
                 s->tile_steps_total = ht.steps_total;
+                {   // a launch sends at most one message per term of a tile with a window, two per term of a window-less tile
+                    double bound = 0;
+                    for (int colour = 0; colour < 2; ++colour) {
+                        uint64_t with_window = 0, without = 0;
+                        for (const pgsgd::WorkItem& wi : ht.items[colour])
+                            for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) (wi.local ? with_window : without) += ht.tiles[ti].n;
+                        bound = std::max(bound, ((double)with_window + 2.0 * (double)without) / (double)std::max<uint64_t>(1, ht.steps_total));
+                    }
+                    s->ob_msgs_per_term = bound;
+                }
                 s->n_tiles = ht.tiles.size();
                 s->h_tiles = ht.tiles;
                 s->n_nonlocal_tiles = ht.n_nonlocal;
@@ -487,10 +536,12 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
                 S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
                 S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
-                S_TRY(hipMalloc(&s->d_far, 2 * sizeof(unsigned long long)));
-                S_TRY(hipMemset(s->d_far, 0, 2 * sizeof(unsigned long long)));
-                S_TRY(hipHostMalloc(&s->h_far, 2 * sizeof(unsigned long long)));
-                s->h_far[0] = s->h_far[1] = 0;
+                if ((sizeof(uint64_t) << s->ob_part_shift) > 48 * 1024)
+                    S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(sizeof(uint64_t) << s->ob_part_shift)));
+                S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
+                S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
+                S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
                 S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
             }
@@ -503,6 +554,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         uint32_t *d_handle = nullptr, *d_len = nullptr;
         uint64_t* d_pos = nullptr;
         S_TRY(hipMalloc(&s->d_recs, g->n_steps * sizeof(uint4)));
+        if (s->tiled) S_TRY(hipMalloc(&s->d_recs2, 2 * g->n_steps * sizeof(uint4)));
         S_TRY(hipMalloc(&d_handle, g->n_steps * sizeof(uint32_t)));
         S_TRY(hipMalloc(&d_pos, g->n_steps * sizeof(uint64_t)));
         S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
@@ -510,7 +562,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
         S_TRY(hipMemcpyAsync(d_len, g->node_len, g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         const int grid = (int)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 8);
-        hipLaunchKernelGGL(pgsgd::build_step_records, dim3(grid), dim3(256), 0, s->stream, d_handle, d_pos, d_len, g->n_steps, s->d_recs);
+        hipLaunchKernelGGL(pgsgd::build_step_records, dim3(grid), dim3(256), 0, s->stream, d_handle, d_pos, d_len, g->n_steps, s->d_recs, s->d_recs2);
         S_TRY(hipGetLastError());
         S_TRY(hipStreamSynchronize(s->stream));
         (void)hipFree(d_handle);
@@ -527,6 +579,12 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (rc) return fail(rc);
         S_TRY(hipMalloc(&s->d_zetas, nz * sizeof(double)));
         S_TRY(hipMemcpy(s->d_zetas, z.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+        pgsgd::ZipfConst zc;
+        zc.init(p->theta);
+        std::vector<double2> zd(nz);
+        for (size_t i = 0; i < nz; ++i) zd[i] = make_double2(z[i], pgsgd::zipf_denominator(zc, z[i]));
+        S_TRY(hipMalloc(&s->d_zeta_denom, nz * sizeof(double2)));
+        S_TRY(hipMemcpy(s->d_zeta_denom, zd.data(), nz * sizeof(double2), hipMemcpyHostToDevice));
     }
     S_TRY(hipMalloc(&s->d_coords, g->n_nodes * 2 * sizeof(uint64_t)));
     S_TRY(hipMemset(s->d_coords, 0, g->n_nodes * 2 * sizeof(uint64_t)));
@@ -546,6 +604,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.recs = s->d_recs;
     c.path_first = s->d_path_first;
     c.zetas = s->d_zetas;
+    c.zeta_denom = s->d_zeta_denom;
     c.coords = s->d_coords;
     c.rng = s->d_rng;
     c.delta_max_bits = s->d_delta_max;
@@ -571,11 +630,12 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (auto& pr : s->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    for (auto& pr : s->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& ev : s->pending_events) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev.e[i]);
+    for (auto& ev : s->free_events) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev.e[i]);
     if (s->d_recs) (void)hipFree(s->d_recs);
     if (s->d_path_first) (void)hipFree(s->d_path_first);
     if (s->d_zetas) (void)hipFree(s->d_zetas);
+    if (s->d_zeta_denom) (void)hipFree(s->d_zeta_denom);
     if (s->d_coords) (void)hipFree(s->d_coords);
     if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_rng) (void)hipFree(s->d_rng);
@@ -584,7 +644,15 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_far) (void)hipFree(s->d_far);
-    if (s->h_far) (void)hipHostFree(s->h_far);
+    if (s->d_recs2) (void)hipFree(s->d_recs2);
+    if (s->ob.pool) (void)hipFree(s->ob.pool);
+    if (s->ob.next) (void)hipFree(s->ob.next);
+    if (s->ob.fill) (void)hipFree(s->ob.fill);
+    if (s->d_ob_chunk0) (void)hipFree(s->d_ob_chunk0);
+    if (s->d_ob_cap) (void)hipFree(s->d_ob_cap);
+    if (s->d_ob_overflow) (void)hipFree(s->d_ob_overflow);
+    if (s->d_ob_spill) (void)hipFree(s->d_ob_spill);
+    if (s->d_term0) (void)hipFree(s->d_term0);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -741,6 +809,16 @@ extern "C" int64_t pgsgd_session_tile_table(const pgsgd_session* s, uint64_t* t0
     return (int64_t)cnt;
 }
 
+// lanes that work on each tile at once (the tile's hot-node cap, at most the workgroup size): lane l draws the tile's
+// terms l, l + lanes, ... from its own stream
+extern "C" int64_t pgsgd_session_tile_lanes(const pgsgd_session* s, uint32_t* lanes, uint64_t capacity) {
+    if (!s) return PGSGD_E_INVALID;
+    const uint64_t cnt = s->h_tiles.size();
+    for (uint64_t i = 0; i < cnt && i < capacity; ++i)
+        if (lanes) lanes[i] = std::min<uint32_t>(s->h_tiles[i].lanes, s->tile_block);
+    return (int64_t)cnt;
+}
+
 // work items in launch order (the first *n_first belong to the launch of the even regions, the rest to the odd ones)
 extern "C" int64_t pgsgd_session_tile_items(const pgsgd_session* s, uint32_t* tile_begin, uint32_t* tile_end, uint32_t* win0, uint32_t* local,
                                             uint64_t capacity, uint64_t* n_first) {
@@ -764,7 +842,8 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     HIP_TRY(hipSetDevice(s->device));
     const pgsgd::Tile t = s->h_tiles[tile];
     auto md = [](uint64_t a, uint64_t b, uint64_t c) { return (uint64_t)(((unsigned __int128)a * b) / c); };
-    const uint64_t cnt = md(t.cum + t.n, n_terms, s->tile_steps_total) - md(t.cum, n_terms, s->tile_steps_total);
+    const uint64_t term_begin = md(t.cum, n_terms, s->tile_steps_total), term_end = md(t.cum + t.n, n_terms, s->tile_steps_total);
+    const uint64_t cnt = term_end - term_begin;
     if (cnt > capacity_terms) { set_error("tile has %llu terms, buffer holds %llu", (unsigned long long)cnt, (unsigned long long)capacity_terms); return PGSGD_E_INVALID; }
     if (cnt == 0) return 0;
     uint64_t* d_out = nullptr;
@@ -774,7 +853,9 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     a.eta = 0.0f;
     a.cooling = cooling ? 1u : 0u;
     a.epoch = epoch;
-    hipLaunchKernelGGL(pgsgd::tile_trace_kernel, dim3(8), dim3(pgsgd::kTileBlock), 0, s->stream, s->dc, t, s->tile_steps_total, a, d_out);
+    const uint32_t lanes = std::min<uint32_t>(t.lanes, s->tile_block);
+    hipLaunchKernelGGL(pgsgd::tile_trace_kernel, dim3((lanes + pgsgd::kTileBlock - 1) / pgsgd::kTileBlock), dim3(pgsgd::kTileBlock), 0, s->stream, s->dc, t,
+                       tile, lanes, term_begin, term_end, a, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, cnt * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -802,6 +883,68 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
     if (region_nodes) *region_nodes = s->region;
     if (tile_steps) *tile_steps = s->tile_steps;
     return s->tiled ? (s->warm_per_lane ? 2 : 1) : 0;
+}
+
+// The outbox's message pool, sized for calls of n_terms terms: one launch (one colour of one part) sends at most one
+// message per term of its tiles (two for window-less tiles), i.e. about 0.5 * n_terms / n_parts when every partner is
+// far; shares go to the buckets in proportion to the path steps on their nodes (where partners land), plus one open
+// chunk per resident workgroup.  A bucket that still runs out falls back to direct atomics (outbox_push).
+static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
+    const uint64_t per_call = n_terms / std::max<uint32_t>(1, n_parts * s->tile_substeps * s->tshard_world * s->shard_world) + 1;
+    if (s->ob.pool && per_call <= s->ob_budget_terms) return PGSGD_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->ob.pool) { (void)hipFree(s->ob.pool); s->ob.pool = nullptr; }
+    if (s->ob.fill) { (void)hipFree(s->ob.fill); s->ob.fill = nullptr; }
+    const uint32_t B = s->ob.n_buckets;
+    double frac = 1.3 * s->ob_msgs_per_term;  // every partner far, and slack for buckets that draw more than their share
+    uint64_t open_chunks = s->tile_grid + 4;  // every resident workgroup may hold one partly filled chunk per bucket
+    if (const char* e = getenv("PGSGD_OUTBOX_FRACTION")) {  // test knob: a pool this small overflows into direct atomics
+        frac = std::max(0.0, atof(e));
+        open_chunks = 1;
+    }
+    uint64_t steps_total = 0;
+    for (uint64_t v : s->ob_bucket_steps) steps_total += v;
+    std::vector<uint32_t> chunk0(B), cap(B);
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        const double share = steps_total ? (double)s->ob_bucket_steps[b] / (double)steps_total : 1.0 / B;
+        uint64_t c = (uint64_t)std::ceil(frac * (double)per_call * share / (double)pgsgd::kObChunk) + open_chunks;
+        c = std::min<uint64_t>(c, pgsgd::kObOverflow - 1);
+        if ((total + c) * pgsgd::kObLinesPerChunk > 0xfffffffeull) { set_error("outbox pool exceeds 2^32 lines"); return PGSGD_E_UNSUPPORTED; }
+        if (total + c > 0xffffffffull) { set_error("outbox pool exceeds 2^32 chunks"); return PGSGD_E_UNSUPPORTED; }
+        chunk0[b] = (uint32_t)total;
+        cap[b] = (uint32_t)c;
+        total += c;
+    }
+    hipError_t e = hipMalloc(&s->ob.pool, total * pgsgd::kObChunk * sizeof(uint4));
+    if (e != hipSuccess) {
+        set_error("outbox pool of %.1f GB: %s", (double)total * pgsgd::kObChunk * 16 / 1e9, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP;
+    }
+    HIP_TRY(hipMalloc(&s->ob.fill, total * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(s->ob.fill, 0, total * sizeof(uint32_t)));
+    if (!s->d_ob_chunk0) {
+        HIP_TRY(hipMalloc(&s->d_ob_overflow, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(s->d_ob_overflow, 0, sizeof(unsigned long long)));
+        s->ob.overflow = s->d_ob_overflow;
+        HIP_TRY(hipMalloc(&s->d_ob_spill, 2 * s->n_nodes * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(s->d_ob_spill, 0, 2 * s->n_nodes * sizeof(unsigned long long)));
+        s->ob.spill = s->d_ob_spill;
+        HIP_TRY(hipMalloc(&s->d_ob_chunk0, B * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->d_ob_cap, B * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->ob.next, B * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->ob.next, 0, B * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMemcpy(s->d_ob_chunk0, chunk0.data(), B * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_ob_cap, cap.data(), B * sizeof(uint32_t), hipMemcpyHostToDevice));
+    s->ob.chunk0 = s->d_ob_chunk0;
+    s->ob.cap = s->d_ob_cap;
+    s->ob_budget_terms = per_call;
+    s->ob_total_chunks = total;
+    if (s->params.progress)
+        fprintf(stderr, "[odgi::path_linear_sgd_layout] far-update outbox: %u buckets of %u node ends, %.2f GB message pool\n", B, 1u << s->ob.shift,
+                (double)total * pgsgd::kObChunk * 16 / 1e9);
+    return PGSGD_OK;
 }
 
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
@@ -839,29 +982,31 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         a.cooling = cooling ? 1u : 0u;
         if (part == 0) s->tile_epoch++;
         a.epoch = s->tile_epoch;
-        if (s->tile_epoch == 1 && part == 0) {
-            // nothing was counted yet: assume three quarters of the partners of this call's terms are far,
-            // half of them in each colour's launch
-            const double h = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
-            s->far_mu_cap[0] = s->far_mu_cap[1] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
+        int rc = ensure_outbox(s, n_terms, n_parts);
+        if (rc) return rc;
+        if (s->term0_terms != n_terms) {  // every tile's exact share of this call's terms
+            const uint64_t nt = s->n_tiles + 1;
+            hipLaunchKernelGGL(pgsgd::tile_terms_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s->stream, s->d_tiles, s->n_tiles,
+                               s->tile_steps_total, n_terms, s->d_term0);
+            HIP_TRY(hipGetLastError());
+            s->term0_terms = n_terms;
         }
+        // nothing was counted before a colour's first launch: assume three quarters of the partners of this call's
+        // terms are far, half of them in each colour's launch
+        const double h0 = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
         // tile subsets: (part, window refresh, tile shard of this device) -> tiles with index = sub (mod n_sub)
         const uint32_t n_sub = n_parts * s->tile_substeps * s->tshard_world;
+        const int snap_grid = (int)std::min<uint64_t>((s->n_steps + 255) / 256, 256 * 16);
         for (uint32_t ps = part * s->tile_substeps; ps < (part + 1) * s->tile_substeps; ++ps)
         for (int colour = 0; colour < 2; ++colour) {
             const uint32_t sub = ps * s->tshard_world + s->tshard_rank;
             if (!s->n_items[colour]) continue;
-            HIP_TRY(hipMemsetAsync(s->d_queue + colour, 0, sizeof(uint32_t), s->stream));
-            HIP_TRY(hipMemsetAsync(s->d_far + colour, 0, sizeof(unsigned long long), s->stream));
-            std::pair<hipEvent_t, hipEvent_t> ev;
-            if (!s->free_events.empty()) {
-                ev = s->free_events.back();
-                s->free_events.pop_back();
-            } else {
-                HIP_TRY(hipEventCreate(&ev.first));
-                HIP_TRY(hipEventCreate(&ev.second));
-            }
+            pgsgd_session::EvSet ev;
+            rc = take_events(s, &ev);
+            if (rc) return rc;
+            ev.n = 4;
+            const uint32_t launches = s->far_launches[colour]++;
             pgsgd::TileArgs ta;
             ta.tiles = s->d_tiles;
             ta.items = s->d_items + (colour ? s->n_items[0] : 0);
@@ -869,41 +1014,48 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.n_items = s->n_items[colour];
             ta.region = s->region;
             ta.tile_steps = s->tile_steps;
-            ta.steps_total = s->tile_steps_total;
+            ta.term0 = s->d_term0;
             ta.sub = sub;
             ta.n_sub = n_sub;
             ta.shard_rank = s->shard_rank;
             ta.shard_world = s->shard_world;
-            ta.far_mu_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) ? 1.0f : s->far_mu_cap[colour];
-            ta.far_count = s->d_far + colour;
-            HIP_TRY(hipEventRecord(ev.first, s->stream));
+            // the far-pull count of this colour's previous launch stays on the device: no host round trip
+            const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
+            ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
+            ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
+            ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
+            ta.far_count = s->d_far + 2 * colour + (launches & 1u);
+            ta.recs2 = s->d_recs2;
+            ta.ob = s->ob;
+            HIP_TRY(hipEventRecord(ev.e[2], s->stream));
+            hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps,
+                               s->d_recs2, ta.queue, ta.far_count);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev.e[0], s->stream));
             hipLaunchKernelGGL(tile_kernel(s->tile_far), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(ev.second, s->stream));
+            HIP_TRY(hipEventRecord(ev.e[1], s->stream));
+            hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(s->ob.n_buckets << (s->ob.shift - s->ob_part_shift)), dim3(1024),
+                               sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ev.e[3], s->stream));
             s->pending_events.push_back(ev);
         }
         HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(s->h_far, s->d_far, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
-        // the cap of the next launches comes from this call's counts: wait for them (the caller syncs anyway)
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        for (int colour = 0; colour < 2; ++colour) {
-            const double h = (double)s->h_far[colour] / (double)(2 * s->n_nodes);
-            s->far_mu_cap[colour] = h > 1.0 ? (float)(1.0 / h) : 1.0f;
-        }
         return PGSGD_OK;
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
     const uint32_t abl = (s->params.flags >> 8) & 0xfu;
     iter_kernel_t kernel = select_kernel(s->pf_lds, plain, s->fmt, s->upd, s->dc.terms_per_anchor > 1, abl);
     if (!kernel) { set_error("no kernel instance for these debug flags"); return PGSGD_E_UNSUPPORTED; }
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!s->free_events.empty()) {
-        ev = s->free_events.back();
-        s->free_events.pop_back();
-    } else {
-        HIP_TRY(hipEventCreate(&ev.first));
-        HIP_TRY(hipEventCreate(&ev.second));
+    pgsgd_session::EvSet ev;
+    {
+        const int rc = take_events(s, &ev);
+        if (rc) return rc;
     }
+    ev.n = 2;
     HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
     pgsgd::IterArgs a;
     a.n_terms = n_terms;
@@ -912,10 +1064,10 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     a.epoch = 0;
     const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
     const uint32_t grid = (s->n_streams + block - 1) / block;
-    HIP_TRY(hipEventRecord(ev.first, s->stream));
+    HIP_TRY(hipEventRecord(ev.e[0], s->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, s->stream));
+    HIP_TRY(hipEventRecord(ev.e[1], s->stream));
     s->pending_events.push_back(ev);
     HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
     return PGSGD_OK;
@@ -940,7 +1092,25 @@ extern "C" int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uin
     if (!s) return PGSGD_E_INVALID;
     if (total_ms) *total_ms = s->kernel_ms;
     if (launches) *launches = s->launches;
-    if (reset) { s->kernel_ms = 0; s->launches = 0; }
+    if (reset) { s->kernel_ms = 0; s->launches = 0; s->aux_ms[0] = s->aux_ms[1] = 0; }
+    return PGSGD_OK;
+}
+
+extern "C" int64_t pgsgd_session_outbox_overflow(pgsgd_session* s) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (!s->d_ob_overflow) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned long long v = 0;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(&v, s->d_ob_overflow, sizeof v, hipMemcpyDeviceToHost));
+    return (int64_t)v;
+}
+
+extern "C" int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, double* drain_ms) {
+    if (!s) return PGSGD_E_INVALID;
+    if (snapshot_ms) *snapshot_ms = s->aux_ms[0];
+    if (drain_ms) *drain_ms = s->aux_ms[1];
     return PGSGD_OK;
 }
 

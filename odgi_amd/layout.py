@@ -186,7 +186,8 @@ class LayoutSession:
         return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
 
     def tile_table(self):
-        """Tiles in work order: dict of arrays t0, cum, n, path, and steps_total."""
+        """Tiles in work order: dict of arrays t0, cum, n, path, lanes (lanes that work on the tile at once, one term
+        stream each), and steps_total."""
         cnt = lib.pgsgd_session_tile_table(self._h, None, None, None, None, 0, None)
         t0, cum = np.zeros(cnt, dtype=np.uint64), np.zeros(cnt, dtype=np.uint64)
         n, path = np.zeros(cnt, dtype=np.uint32), np.zeros(cnt, dtype=np.uint32)
@@ -194,7 +195,9 @@ class LayoutSession:
         u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
         lib.pgsgd_session_tile_table(self._h, t0.ctypes.data_as(u64p), cum.ctypes.data_as(u64p), n.ctypes.data_as(u32p),
                                      path.ctypes.data_as(u32p), cnt, C.byref(tot))
-        return dict(t0=t0, cum=cum, n=n, path=path, steps_total=tot.value)
+        lanes = np.zeros(cnt, dtype=np.uint32)
+        lib.pgsgd_session_tile_lanes(self._h, lanes.ctypes.data_as(u32p), cnt)
+        return dict(t0=t0, cum=cum, n=n, path=path, lanes=lanes, steps_total=tot.value)
 
 
     def tile_items(self):
@@ -243,6 +246,19 @@ class LayoutSession:
         ms, n = C.c_double(), C.c_uint64()
         check(lib.pgsgd_session_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "kernel_time")
         return ms.value, n.value
+
+    def aux_time(self):
+        """(snapshot_ms, drain_ms): time in the streaming kernels around the tile launches since the last reset."""
+        a, b = C.c_double(), C.c_double()
+        check(lib.pgsgd_session_aux_time(self._h, C.byref(a), C.byref(b)), "aux_time")
+        return a.value, b.value
+
+    def outbox_overflow(self):
+        """Far updates applied as direct atomics because the message pool share of their bucket was used up."""
+        n = lib.pgsgd_session_outbox_overflow(self._h)
+        if n < 0:
+            check(int(n), "outbox_overflow")
+        return int(n)
 
     def trace_terms(self, cooling, terms_per_stream):
         """Sampler-only parity hook: uint64 [terms_per_stream, n_streams, 4] = (ka, kb, off_a, off_b)."""

@@ -64,12 +64,12 @@ def _load(name):
     lib.orc_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32,
                                     C.c_int, C.c_uint32, C.c_uint64, _U64P]
     lib.orc_tile_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
-                                   C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _U64P]
+                                   C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _U64P]
     lib.orc_tile_terms.restype = C.c_uint64
     lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, _F32P, _F32P, _F64P]
     lib.orc_tile_layout_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64,
-                                        C.c_uint64, _U64P, _U64P, _U32P, _U32P, C.c_uint64, C.c_uint64, C.c_uint64,
+                                        C.c_uint64, _U64P, _U64P, _U32P, _U32P, _U32P, C.c_uint64, C.c_uint64, C.c_uint64,
                                         _U32P, _U32P, _U32P, _U32P, C.c_uint32, C.c_double, C.c_double, C.c_double,
                                         _F32P, _F32P, C.POINTER(C.c_double), _U64P, C.POINTER(C.c_uint64)]
     lib.orc_tile_layout_q32.restype = None
@@ -81,6 +81,8 @@ def _load(name):
                                            C.c_uint32, _F64P, _F64P]
     lib.orc_layout_hogwild.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, _F64P,
                                        C.POINTER(HogStats)]
+    lib.orc_layout_hogwild_curve.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint32, C.c_double, _F64P, _F64P,
+                                             C.POINTER(HogStats), C.c_uint64, _U64P, _F64P, _F64P]
     lib.orc_sort_initial.argtypes = [C.POINTER(OrcGraph), _F64P]
     lib.orc_sort_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
                                          C.c_uint64, _U64P]
@@ -170,10 +172,11 @@ def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream,
     return out
 
 
-def tile_terms(g, p, seed_base, epoch, n_terms, steps_total, t0, cum, n, path, cooling, capacity=1 << 16):
+def tile_terms(g, p, seed_base, epoch, n_terms, steps_total, tile, lanes, t0, cum, n, path, cooling, capacity=1 << 16):
+    """Terms of tile number `tile` of the tile table, worked on by `lanes` lanes (one stream per lane), in term order."""
     out = np.zeros((capacity, 4), dtype=np.uint64)
-    cnt = lib().orc_tile_terms(C.byref(g.view), C.byref(p), seed_base, epoch, n_terms, steps_total, int(t0), int(cum), int(n), int(path),
-                               1 if cooling else 0, out.ctypes.data_as(_U64P))
+    cnt = lib().orc_tile_terms(C.byref(g.view), C.byref(p), seed_base, epoch, n_terms, steps_total, int(tile), int(lanes), int(t0), int(cum),
+                               int(n), int(path), 1 if cooling else 0, out.ctypes.data_as(_U64P))
     return out[:cnt]
 
 
@@ -201,7 +204,8 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
 
 def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, quanta_per_bp):
     """Sequential mirror of the tile kernel (one workgroup, one lane per tile).  `tiles` / `items` are the dicts of
-    LayoutSession.tile_table() / tile_items().  Returns X, Y (fp32), last delta_max, checksums[4], far terms."""
+    LayoutSession.tile_table() / tile_items(); tiles["lanes"] (lanes per tile, default 1 each) selects the term
+    streams.  Returns X, Y (fp32), last delta_max, checksums[4], far terms."""
     X = np.ascontiguousarray(X, dtype=np.float32).copy()
     Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
     d, far = C.c_double(), C.c_uint64()
@@ -209,9 +213,11 @@ def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, q
     u32 = lambda a: np.ascontiguousarray(a, dtype=np.uint32)
     u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
     t0, cum, tn, tp = u64(tiles["t0"]), u64(tiles["cum"]), u32(tiles["n"]), u32(tiles["path"])
+    tl = u32(tiles["lanes"]) if "lanes" in tiles else np.ones(len(t0), dtype=np.uint32)
     tb, te, w0, lo = u32(items["tile_begin"]), u32(items["tile_end"]), u32(items["win0"]), u32(items["local"])
     lib().orc_tile_layout_q32(C.byref(g.view), C.byref(p), seed_base, len(t0), t0.ctypes.data_as(_U64P), cum.ctypes.data_as(_U64P),
-                              tn.ctypes.data_as(_U32P), tp.ctypes.data_as(_U32P), int(tiles["steps_total"]), len(tb), int(items["n_first"]),
+                              tn.ctypes.data_as(_U32P), tp.ctypes.data_as(_U32P), tl.ctypes.data_as(_U32P), int(tiles["steps_total"]), len(tb),
+                              int(items["n_first"]),
                               tb.ctypes.data_as(_U32P), te.ctypes.data_as(_U32P), w0.ctypes.data_as(_U32P), lo.ctypes.data_as(_U32P),
                               int(region), x_off, y_off, quanta_per_bp, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P),
                               C.byref(d), ck.ctypes.data_as(_U64P), C.byref(far))
@@ -242,6 +248,20 @@ def layout_hogwild(g, p, nthreads, X, Y, max_seconds=0.0, fast=False):
     lib(fast).orc_layout_hogwild(C.byref(g.view), C.byref(p), nthreads, max_seconds,
                                  X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), C.byref(st))
     return X, Y, {"terms": st.terms, "iterations": st.iterations, "seconds": st.seconds}
+
+
+def layout_hogwild_curve(g, p, nthreads, X, Y, snap_iters, fast=False):
+    """layout_hogwild that also returns the coordinates after the iterations in snap_iters (1-based): X, Y, stats,
+    snapX [k, 2N], snapY [k, 2N]."""
+    X = np.ascontiguousarray(X, dtype=np.float64).copy()
+    Y = np.ascontiguousarray(Y, dtype=np.float64).copy()
+    it = np.ascontiguousarray(snap_iters, dtype=np.uint64)
+    sx = np.zeros((len(it), len(X)))
+    sy = np.zeros((len(it), len(X)))
+    st = HogStats()
+    lib(fast).orc_layout_hogwild_curve(C.byref(g.view), C.byref(p), nthreads, 0.0, X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P),
+                                       C.byref(st), len(it), it.ctypes.data_as(_U64P), sx.ctypes.data_as(_F64P), sy.ctypes.data_as(_F64P))
+    return X, Y, {"terms": st.terms, "iterations": st.iterations, "seconds": st.seconds}, sx, sy
 
 
 def _d(a):

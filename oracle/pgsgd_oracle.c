@@ -392,29 +392,33 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
     free(zetas);
 }
 
-/* Terms of the tile kernel (odgi_amd/csrc/pgsgd_tiles.hpp: sgd_tile_kernel / tile_trace_kernel): term q of an
- * iteration of n_terms terms belongs to the tile whose share [cum*M/S_tot, (cum+n)*M/S_tot) contains q; it has
- * its own generator seeded with seed_base + epoch*0x9e3779b97f4a7c15 + q, draws its first step uniformly in the
- * tile and its partner by the reference rule. */
+/* Terms of the tile kernel (odgi_amd/csrc/pgsgd_tiles.hpp: sgd_tile_kernel / tile_trace_kernel): the tile with index
+ * `tile` in the tile table runs the terms [cum*M/S_tot, (cum+n)*M/S_tot) of an iteration of M = n_terms terms; `lanes`
+ * lanes work on it, lane l drawing the tile's terms l, l + lanes, ... from its own generator, seeded with
+ * seed_base + epoch*0xd1342543de82ef95 + ((tile << 10) | l); a term draws its first step uniformly in the tile and its
+ * partner by the reference rule. */
 uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
-                        uint64_t steps_total, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path, int cooling, uint64_t* out) {
+                        uint64_t steps_total, uint64_t tile, uint32_t lanes, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path,
+                        int cooling, uint64_t* out) {
     const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
     double* zetas = (double*)malloc(nz * sizeof(double));
     orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
     const uint64_t term_begin = (uint64_t)(((unsigned __int128)cum * n_terms) / steps_total);
     const uint64_t term_end = (uint64_t)(((unsigned __int128)(cum + n) * n_terms) / steps_total);
-    for (uint64_t q = term_begin; q < term_end; ++q) {
+    for (uint32_t lane = 0; lane < lanes; ++lane) {
         uint64_t s[4];
-        orc_rng_seed(seed_base + epoch * 0x9e3779b97f4a7c15ull + q, s);
-        orc_anchor an;
-        an.pstart = g->path_first[path];
-        an.cnt = g->path_first[path + 1] - an.pstart;
-        an.k = t0 + orc_uniform_u64(s, n);
-        an.s_rank = an.k - an.pstart;
-        orc_term t;
-        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
-        uint64_t* o = out + (q - term_begin) * 4;
-        o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
+        orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | lane), s);
+        for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
+            orc_anchor an;
+            an.pstart = g->path_first[path];
+            an.cnt = g->path_first[path + 1] - an.pstart;
+            an.k = t0 + orc_uniform_u64(s, n);
+            an.s_rank = an.k - an.pstart;
+            orc_term t;
+            orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+            uint64_t* o = out + (q - term_begin) * 4;
+            o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
+        }
     }
     free(zetas);
     return term_end - term_begin;
@@ -607,6 +611,9 @@ typedef struct hog_shared {
     uint64_t total_terms;    /* atomic: sum of all worker counts */
     double max_seconds;
     struct timespec t0;
+    /* convergence curve (test infrastructure): after iteration snap_iters[k] the controller copies X,Y while the
+     * workers keep running, exactly like the reference's snapshot thread (path_sgd_layout.cpp:379-408) */
+    uint64_t n_snap; const uint64_t* snap_iters; double* snapX; double* snapY; uint64_t snaps_taken;
 } hog_shared;
 
 typedef struct hog_worker { hog_shared* sh; uint64_t tid; } hog_worker;
@@ -626,6 +633,12 @@ static void* hog_checker(void* arg) {                                   /* :120-
     while (__atomic_load_n(&sh->work_todo, __ATOMIC_SEQ_CST)) {
         if (__atomic_load_n(&sh->term_updates, __ATOMIC_SEQ_CST) > sh->p->min_term_updates) {
             sh->iteration++;
+            for (uint64_t k = 0; k < sh->n_snap; ++k)
+                if (sh->snap_iters[k] == sh->iteration) {
+                    const uint64_t n_ends = 2 * sh->g->n_nodes;
+                    for (uint64_t e = 0; e < n_ends; ++e) { sh->snapX[k * n_ends + e] = ld_f64(&sh->X[e]); sh->snapY[k * n_ends + e] = ld_f64(&sh->Y[e]); }
+                    sh->snaps_taken++;
+                }
             if (sh->iteration >= sh->p->iter_max) {
                 __atomic_store_n(&sh->work_todo, 0, __ATOMIC_SEQ_CST);
             } else if (ld_f64(&sh->Delta_max) <= sh->p->delta) {
@@ -692,6 +705,14 @@ static void* hog_work(void* arg) {                                      /* :165-
 
 void orc_layout_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds,
                         double* X, double* Y, orc_hogwild_stats* st) {
+    orc_layout_hogwild_curve(g, p, nthreads, max_seconds, X, Y, st, 0, NULL, NULL, NULL);
+}
+
+/* the same run, also copying the coordinates after the iterations listed in snap_iters[n_snap] (1-based counts of
+ * finished iterations) into snapX/snapY [n_snap][2N] */
+void orc_layout_hogwild_curve(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds,
+                              double* X, double* Y, orc_hogwild_stats* st,
+                              uint64_t n_snap, const uint64_t* snap_iters, double* snapX, double* snapY) {
     if (st) { st->terms = 0; st->iterations = 0; st->seconds = 0; }
     if (!has_multistep_path(g) || nthreads == 0) return;
     const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
@@ -706,6 +727,7 @@ void orc_layout_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthrea
     sh.eta = etas[0];
     sh.cooling = 0; sh.Delta_max = 0; sh.work_todo = 1; sh.iteration = 0;
     sh.max_seconds = max_seconds;
+    sh.n_snap = n_snap; sh.snap_iters = snap_iters; sh.snapX = snapX; sh.snapY = snapY;
     clock_gettime(CLOCK_MONOTONIC, &sh.t0);
     pthread_t checker;
     pthread_t* th = (pthread_t*)malloc(nthreads * sizeof(pthread_t));
@@ -1082,7 +1104,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
 
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
-                         uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
                          const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
                          double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
                          double* last_delta_max, uint64_t* checksum, uint64_t* far_terms) {
@@ -1105,6 +1127,10 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
     const uint32_t win_words = 4 * region;
     uint64_t* win = (uint64_t*)malloc(win_words * sizeof(uint64_t));
     uint64_t* orig = (uint64_t*)malloc(win_words * sizeof(uint64_t));
+    /* what a launch sees of node ends outside a window: their words when the launch began (snapshot_kernel); what it
+     * adds to them: collected (the outbox) and applied when the launch is over (far_drain_kernel) */
+    uint64_t* snap = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
+    uint64_t* outbox = (uint64_t*)calloc(n_ends, sizeof(uint64_t));
     const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
     const uint64_t n_terms = p->min_term_updates;
     float far_cap[2];
@@ -1121,6 +1147,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
         uint64_t far_count[2] = {0, 0};
         for (int colour = 0; colour < 2; ++colour) {
             const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
+            if (ib == ie) continue;
+            memcpy(snap, W, n_ends * sizeof(uint64_t));
             for (uint64_t it = ib; it < ie; ++it) {
                 const uint64_t wbase = 2 * (uint64_t)win0[it];
                 if (local[it])
@@ -1128,9 +1156,14 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                 for (uint32_t ti = tile_begin[it]; ti < tile_end[it]; ++ti) {
                     const uint64_t term_begin = (uint64_t)(((unsigned __int128)cum[ti] * n_terms) / steps_total);
                     const uint64_t term_end = (uint64_t)(((unsigned __int128)(cum[ti] + tn[ti]) * n_terms) / steps_total);
+                    /* lane l of the tile's lanes draws terms l, l + lanes, ... from its own stream; the mirror runs the
+                     * terms in term order (with one lane: the lane's order) */
+                    const uint32_t lanes = tlanes[ti];
+                    uint64_t* streams = (uint64_t*)malloc((size_t)lanes * 4 * sizeof(uint64_t));
+                    for (uint32_t l = 0; l < lanes; ++l)
+                        orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + (((uint64_t)ti << 10) | l), streams + 4 * (size_t)l);
                     for (uint64_t q = term_begin; q < term_end; ++q) {
-                        uint64_t s[4];
-                        orc_rng_seed(seed_base + epoch * 0x9e3779b97f4a7c15ull + q, s);
+                        uint64_t* s = streams + 4 * (size_t)((q - term_begin) % lanes);
                         orc_anchor an;
                         an.pstart = g->path_first[tpath[ti]];
                         an.cnt = g->path_first[tpath[ti] + 1] - an.pstart;
@@ -1142,9 +1175,11 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         const uint64_t eb = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
                         const int in_a = local[it] && ea >= wbase && ea - wbase < win_words;
                         const int in_b = local[it] && eb >= wbase && eb - wbase < win_words;
-                        uint64_t* pa = in_a ? &win[ea - wbase] : &W[ea];
-                        uint64_t* pb = in_b ? &win[eb - wbase] : &W[eb];
-                        const uint64_t wa = *pa, wb = *pb;
+                        /* a partner step inside the tile comes with no snapshot (its record is the tile's LDS copy): a
+                         * window-less tile then reads the partner's word where it reads the first end's, in global memory */
+                        const int b_in_tile = t.kb - t0[ti] < (uint64_t)tn[ti];
+                        const uint64_t wa = in_a ? win[ea - wbase] : W[ea];
+                        const uint64_t wb = in_b ? win[eb - wbase] : b_in_tile ? W[eb] : snap[eb];
                         const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
                         const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
                         float r_x, r_y;
@@ -1160,14 +1195,16 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         if ((qx | qy) == 0) continue;
                         if (!in_b) far_count[colour]++;
                         const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-                        *pb += delta;
-                        *pa -= delta;
+                        if (in_b) win[eb - wbase] += delta; else outbox[eb] += delta;
+                        if (in_a) win[ea - wbase] -= delta; else outbox[ea] -= delta;
                     }
+                    free(streams);
                 }
-                if (local[it])
+                if (local[it])   /* the window's only writer since it was staged: plain stores */
                     for (uint32_t i = 0; i < win_words; ++i)
-                        if (wbase + i < n_ends) W[wbase + i] += win[i] - orig[i];
+                        if (wbase + i < n_ends) W[wbase + i] = win[i];
             }
+            for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
         }
         for (int colour = 0; colour < 2; ++colour) {
             const double h = (double)far_count[colour] / (double)n_ends;
@@ -1186,5 +1223,5 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
         X[i] = (float)(x_off + (double)(uint32_t)W[i] * (double)inv_scale);
         Y[i] = (float)(y_off + (double)(uint32_t)(W[i] >> 32) * (double)inv_scale);
     }
-    free(W); free(zetas); free(etas); free(win); free(orig);
+    free(W); free(zetas); free(etas); free(win); free(orig); free(snap); free(outbox);
 }

@@ -74,7 +74,8 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
                      uint32_t stream_offset, int cooling, uint32_t terms_per_anchor, uint64_t terms_per_stream, uint64_t* out);
 /* the terms one tile of the device's tile kernel draws in iteration `epoch`; returns their number */
 uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
-                        uint64_t steps_total, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path, int cooling, uint64_t* out);
+                        uint64_t steps_total, uint64_t tile, uint32_t lanes, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path,
+                        int cooling, uint64_t* out);
 /* fp32 mirror of the device arithmetic; bit-exact with the GPU for n_streams == 1 */
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
                             uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
@@ -85,7 +86,7 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 /* sequential mirror of the tile kernel run by one workgroup with one lane per tile (see the .c file) */
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
-                         uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
                          const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
                          double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
                          double* last_delta_max, uint64_t* checksum, uint64_t* far_terms);
@@ -110,6 +111,9 @@ typedef struct orc_hogwild_stats {
 } orc_hogwild_stats;
 void orc_layout_hogwild(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds,
                         double* X, double* Y, orc_hogwild_stats* st);
+void orc_layout_hogwild_curve(const orc_graph* g, const orc_params* p, uint32_t nthreads, double max_seconds,
+                              double* X, double* Y, orc_hogwild_stats* st,
+                              uint64_t n_snap, const uint64_t* snap_iters, double* snapX, double* snapY);
 
 /* quality metrics */
 double orc_path_stress_sampled(const orc_graph* g, const double* X, const double* Y,

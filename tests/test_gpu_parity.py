@@ -91,12 +91,12 @@ def test_many_paths_use_the_global_path_table(oa, orc):
     Xg, Yg, dmax_g, fmt, w0, w1 = _run_session(oa, g, p1, X0, Y0)
     Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p1), p1.seed, 1, X0, Y0, fmt[1], fmt[2], fmt[3])
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo) and dmax_g == dmax_o
-    X, Y = X0.copy(), Y0.copy()
-    st = oa.path_linear_sgd_layout_gpu(g, _params(oa, g), X, Y)
-    Xc, Yc, _ = orc.layout_hogwild(og, orc.params_from(_params(oa, g)), 4, X0, Y0)
-    s_gpu, s_cpu = orc.path_stress_sampled(og, X, Y, 300_000), orc.path_stress_sampled(og, Xc, Yc, 300_000)
-    print(f"5000 paths: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} streams {st['n_streams']}")
-    assert np.isfinite(X).all() and s_gpu <= 1.3 * s_cpu + 0.05
+    # full run, three initial layouts on each side (see "statistical parity" below): short paths (< 30 steps) make
+    # this a noisy little graph: CPU runs scatter by +-10 %, hence the 20 % band
+    gpu, cpu = _gpu_runs(oa, orc, g, og, _params(oa, g)), _cpu_runs(oa, orc, g, og, "5000-paths", _params(oa, g))
+    s_gpu, s_cpu = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu]))
+    print(f"5000 paths: stress gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} streams {gpu[0][2]}")
+    assert s_gpu <= 1.2 * s_cpu
 
 
 def test_single_step_and_ragged_paths(oa, orc, tmp_path):
@@ -178,62 +178,97 @@ def test_fixed_point_frame_and_roundtrip(oa, graphs):
     assert np.abs(Y - Y0.astype(np.float32)).max() <= 1.0 / q + np.abs(Y0).max() * 2 ** -23
 
 
+# ---- statistical parity of full (concurrent) runs -------------------------------------------------
+# The reference is Hogwild and not reproducible run to run (path_sgd_layout.cpp:165-377), so parity of a full
+# run is on layout quality, measured with one evaluator (orc.path_stress_sampled, 1e6 pairs, fixed evaluator seed)
+# over THREE initial layouts (`-N d`, seeds 11/12/13) on each side: mean of three GPU runs (different sampler
+# seeds) against the median of three runs of the CPU restatement (4 Hogwild threads, from the same three initial
+# layouts; the median because LPA's sampled stress is heavy-tailed on the CPU side).
+# Measured run-to-run spread (round 1 logs profiles/r01/pytest_gpu_v*.log, and 3 x 3 CPU runs when this was written):
+#   graph       CPU restatement            GPU default          GPU terms_per_anchor=4   GPU fp32 + Hogwild stores
+#   DRB1-3123   0.622 .. 0.695 (cv 4 %)    0.660 .. 0.662       -                        0.74 .. 0.89
+#   LPA         0.835 .. 2.215 (heavy tail) 0.828 .. 0.833      0.853 .. 0.857           0.828 .. 0.832 (stores)
+#   chr6.C4     0.519 .. 0.534 (cv 1.5 %)  0.539 .. 0.540       0.568 .. 0.570           -
+# Band: the median of three CPU runs is good to ~3 % (DRB1-3123), the GPU mean to < 1 %, so the default mode must be
+# within 10 % (3 sigma); the optional modes get what they were measured to cost: anchor groups of four +8 % -> 15 %,
+# Hogwild stores (lost updates under thousands of lanes) +13..36 % -> 50 %.
+_INIT_SEEDS = (11, 12, 13)
+_CPU_RUNS = {}
+
+
+def _cpu_runs(oa, orc, g, og, name, p, init="d"):
+    """Sampled stress (and `odgi stats -s` 2D path distance) of three CPU-restatement runs; cached per configuration."""
+    key = (name, init, p.theta, p.cooling_start, p.iter_max, p.min_term_updates, p.space, p.space_max, p.space_quantization_step)
+    if key not in _CPU_RUNS:
+        runs = []
+        for seed in _INIT_SEEDS:
+            X0, Y0 = oa.initial_layout(g, init, seed=seed)
+            Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
+            runs.append((orc.path_stress_sampled(og, Xo, Yo, 1_000_000), orc.path_distance(og, Xo, Yo)[0]))
+        _CPU_RUNS[key] = runs
+    return _CPU_RUNS[key]
+
+
+def _gpu_runs(oa, orc, g, og, p, init="d"):
+    import dataclasses
+    runs = []
+    for i, seed in enumerate(_INIT_SEEDS):
+        X0, Y0 = oa.initial_layout(g, init, seed=seed)
+        X, Y = X0.copy(), Y0.copy()
+        st = oa.path_linear_sgd_layout_gpu(g, dataclasses.replace(p, seed=p.seed + 7919 * i), X, Y)
+        assert st["iterations"] == p.iter_max and st["term_updates"] == p.iter_max * p.min_term_updates
+        assert np.isfinite(X).all() and np.isfinite(Y).all()
+        runs.append((orc.path_stress_sampled(og, X, Y, 1_000_000), orc.path_distance(og, X, Y)[0], st["n_streams"]))
+    return runs
+
+
 @pytest.mark.parametrize("name,flags,m", [("DRB1-3123", 0, 1), ("LPA", 0, 1), ("chr6.C4", 0, 1), ("LPA", 2, 1), ("LPA", 4, 1),
                                           ("DRB1-3123", 6, 1), ("LPA", 0, 4), ("chr6.C4", 0, 4)])
 def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, flags, m):
-    """BASELINE configs 1-3 with reference defaults.  The reference itself is Hogwild and not
-    reproducible run to run; parity is on layout quality: sampled path stress of the GPU layout
-    within 25 % (+0.02 absolute; 50 % for the optional Hogwild-store modes) of the CPU oracle's Hogwild layout
-    from the same initial layout."""
+    """BASELINE configs 1-3 with reference defaults: mean sampled path stress of three GPU layouts within the band
+    stated above of the median of three CPU-restatement layouts from the same initial layouts; the same for the
+    `odgi stats -s` 2D path distance."""
     from odgi_amd import _lib
     g, og = graphs(name), ographs(name)
     p = _params(oa, g, flags=flags, terms_per_anchor=m)  # 0 default; 2 fp32 atomics; 4 Hogwild stores; 6 fp32 + stores
-    X0, Y0 = oa.initial_layout(g, "d", seed=11)
-    X, Y = X0.copy(), Y0.copy()
-    st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
-    assert st["iterations"] == 30 and st["term_updates"] == 30 * p.min_term_updates
-    assert np.isfinite(X).all() and np.isfinite(Y).all()
-    Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
-    s_gpu = orc.path_stress_sampled(og, X, Y, 1_000_000)
-    s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
-    s_init = orc.path_stress_sampled(og, X0, Y0, 1_000_000)
-    print(f"{name} flags {flags} m {m}: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f} init {s_init:.1f} streams {st['n_streams']}")
-    # Hogwild stores (the optional PGSGD_FLAG_HOGWILD_STORES modes) lose updates under thousands of concurrent
-    # lanes and scatter more from run to run (DRB1-3123, fp32 + stores: 0.74 ... 0.89 over seven runs against
-    # 0.64 ... 0.66 for the oracle): 50 % for them, 25 % for the default atomic adds
-    tol = 1.5 if flags & _lib.FLAG_HOGWILD_STORES else 1.25
-    assert s_gpu <= tol * s_cpu + 0.02
-    d_gpu, d_cpu = orc.path_distance(og, X, Y)[0], orc.path_distance(og, Xo, Yo)[0]
-    assert d_gpu <= 1.25 * d_cpu + 0.5          # `odgi stats -s` 2D figure, same tolerance
+    gpu, cpu = _gpu_runs(oa, orc, g, og, p), _cpu_runs(oa, orc, g, og, name, p)
+    s_gpu, s_cpu = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu]))
+    d_gpu, d_cpu = float(np.mean([r[1] for r in gpu])), float(np.median([r[1] for r in cpu]))
+    band = 1.5 if flags & _lib.FLAG_HOGWILD_STORES else 1.15 if m > 1 else 1.10
+    print(f"{name} flags {flags} m {m}: stress gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} "
+          f"mean/median {s_gpu:.4f}/{s_cpu:.4f} band {band}; path distance {d_gpu:.3f}/{d_cpu:.3f}; streams {gpu[0][2]}")
+    assert s_gpu <= band * s_cpu
+    assert d_gpu <= band * d_cpu
 
 
 def test_reference_layout_quality_bar(oa, orc, graphs, ographs):
     """The GPU layout of DRB1-3123_unsorted is at least as good as the layout the reference
     committed for it (exhaustive path stress 0.0871), within 25 %."""
+    import dataclasses
     g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
-    p = _params(oa, g)
-    X, Y = oa.initial_layout(g, "d", seed=3)
-    oa.path_linear_sgd_layout_gpu(g, p, X, Y)
-    s = orc.path_stress_exhaustive(og, X, Y)
-    print("DRB1-3123_unsorted exhaustive stress", s)
-    assert s <= 0.0871 * 1.25
+    vals = []
+    for i, seed in enumerate(_INIT_SEEDS):
+        X, Y = oa.initial_layout(g, "d", seed=seed)
+        oa.path_linear_sgd_layout_gpu(g, dataclasses.replace(_params(oa, g), seed=9399220 + 7919 * i), X, Y)
+        vals.append(orc.path_stress_exhaustive(og, X, Y))
+    print("DRB1-3123_unsorted exhaustive stress", vals, "(the reference's own layout of this graph: 0.0871; GPU runs in round 1: 0.0755 .. 0.0762)")
+    assert float(np.mean(vals)) <= 0.0871 * 1.10
 
 
 def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs):
     """BASELINE config 3 in small: deterministic -N h initial layout, theta and -K sweep."""
     g, og = graphs("chr6.C4"), ographs("chr6.C4")
-    X0, Y0 = oa.initial_layout(g, "h")
-    # theta 0.5 makes the partner distribution nearly flat: from the compact Hilbert start the
-    # layout barely unfolds and the CPU oracle itself lands anywhere in 60..160 from run to run
-    # (profiles/r01/pytest_gpu_*.log), so that point only gets a factor-3 band.
-    for theta, K, tol in [(0.5, 0.5, 3.0), (0.9, 0.25, 1.3), (0.999, 0.75, 1.3)]:
+    # The Hilbert initial layout is deterministic (no seed): the three runs of each side differ by sampler seed
+    # (GPU) and thread timing (CPU).  theta 0.5 makes the partner distribution nearly flat: from the compact
+    # Hilbert start the layout barely unfolds and the CPU restatement itself lands anywhere in 60..160 from run
+    # to run (profiles/r01/pytest_gpu_*.log), so that point only gets a factor-2 band on mean vs median; the
+    # other two scatter by < 5 % on either side: 15 %.
+    for theta, K, band in [(0.5, 0.5, 2.0), (0.9, 0.25, 1.15), (0.999, 0.75, 1.15)]:
         p = _params(oa, g, theta=theta, cooling_start=K)
-        X, Y = X0.copy(), Y0.copy()
-        oa.path_linear_sgd_layout_gpu(g, p, X, Y)
-        Xo, Yo, _ = orc.layout_hogwild(og, orc.params_from(p), 4, X0, Y0)
-        s_gpu, s_cpu = orc.path_stress_sampled(og, X, Y, 500_000), orc.path_stress_sampled(og, Xo, Yo, 500_000)
-        print(f"theta {theta} K {K}: gpu {s_gpu:.4f} cpu {s_cpu:.4f}")
-        assert s_gpu <= tol * s_cpu + 0.03
+        gpu, cpu = _gpu_runs(oa, orc, g, og, p, init="h"), _cpu_runs(oa, orc, g, og, "chr6.C4", p, init="h")
+        s_gpu, s_cpu = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu]))
+        print(f"theta {theta} K {K}: gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]}")
+        assert s_gpu <= band * s_cpu
 
 
 def test_delta_early_stop_and_counts(oa, graphs):
@@ -294,8 +329,11 @@ def test_cli_end_to_end(oa, orc, graphs, ographs, tmp_path):
     assert L.size() == 2 * 4955
     rows = tsv.read_text().splitlines()
     assert rows[0] == "idx\tX\tY\tcomponent" and len(rows) == 1 + 2 * 4955
-    x1 = float(rows[1].split("\t")[1])
-    assert x1 == L.X[0]
+    # the TSV prints 16 significant digits (reference layout.cpp:23, `<< std::setprecision(16)`), the .lay holds the
+    # exact double; the device's fixed-point coordinates (multiples of 2^-k bp) can need 17-18 digits
+    for row, x, y in ((rows[1], L.X[0], L.Y[0]), (rows[-1], L.X[-1], L.Y[-1])):
+        f = row.split("\t")
+        assert float(f[1]) == float("%.16g" % x) and float(f[2]) == float("%.16g" % y)
     assert min(L.X.min(), L.Y.min()) == pytest.approx(1000.0)   # component packing border
     assert orc.path_stress_sampled(og, L.X, L.Y, 500_000) < 2.0
     # the standalone binary gives the same interface
@@ -381,8 +419,9 @@ def test_tiled_kernel_matches_per_lane_kernel_and_oracle(oa, orc):
 
 
 def test_tiled_kernel_terms_bit_exact_and_tile_table(oa, orc):
-    """Every term of the tile kernel is a function of (seed, iteration, term index): the oracle reproduces
-    the terms of any tile bit for bit; the tile table partitions the steps and the terms exactly."""
+    """Every term of the tile kernel is a function of (seed, iteration, tile, lane of the tile, position in the lane's
+    stream): the oracle reproduces the terms of any tile bit for bit; the tile table partitions the steps and the
+    terms exactly."""
     g = oa.Graph.synthetic(300_000, 24, seed=7)
     og = orc.Graph.from_product(g)
     p = _params(oa, g, stream_offset=5)
@@ -403,8 +442,8 @@ def test_tiled_kernel_terms_bit_exact_and_tile_table(oa, orc):
         for tile in (0, 1, n_tiles // 2, n_tiles - 1, int(np.argmin(tt["n"]))):
             for cooling, epoch in ((False, 1), (True, 17)):
                 got = s.trace_tile_terms(tile, cooling, epoch, M)
-                want = orc.tile_terms(og, orc.params_from(p), p.seed + 5, epoch, M, tt["steps_total"], tt["t0"][tile], tt["cum"][tile],
-                                      tt["n"][tile], tt["path"][tile], cooling)
+                want = orc.tile_terms(og, orc.params_from(p), p.seed + 5, epoch, M, tt["steps_total"], tile, tt["lanes"][tile], tt["t0"][tile],
+                                      tt["cum"][tile], tt["n"][tile], tt["path"][tile], cooling)
                 assert len(got) == int(shares[tile]) and np.array_equal(got, want)
                 ka = got[:, 0].astype(np.int64)
                 assert ka.min() >= tt["t0"][tile] and ka.max() < tt["t0"][tile] + tt["n"][tile]   # first step inside the tile
@@ -435,6 +474,35 @@ def test_tiled_kernel_with_unsorted_stretches(oa):
     s_init, s_end = oa.path_stress(g2, X0, Y0, 500_000), oa.path_stress(g2, X, Y, 500_000)
     print(f"unsorted stretches: {info['n_nonlocal_tiles']} non-local tiles, stress {s_init:.1f} -> {s_end:.4f}")
     assert s_end < 1.0 and s_end < 1e-3 * s_init
+
+
+def test_outbox_overflow_falls_back_to_direct_atomics(oa, monkeypatch):
+    """Far updates travel through the outbox (per-bucket chunks of a message pool, drained after the launch).  A pool
+    that is far too small must not lose or duplicate a single quantum: buckets that run out of chunks send the rest as
+    direct atomic adds.  Coordinate sums conserved exactly, layout as good as with the full pool."""
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    X0, Y0 = oa.initial_layout(g, "d", seed=7)
+    p = _params(oa, g, min_term_updates=3 * g.n_steps, iter_max=12)
+    res = {}
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    for name, frac in (("full", None), ("tiny", "0.02")):
+        if frac is None:
+            monkeypatch.delenv("PGSGD_OUTBOX_FRACTION", raising=False)
+        else:
+            monkeypatch.setenv("PGSGD_OUTBOX_FRACTION", frac)
+        with oa.LayoutSession(g, p) as s:
+            s.upload(X0, Y0)
+            w0 = s.download_words()
+            for it in range(p.iter_max):
+                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            assert s.sync() > 0
+            X, Y = s.download()
+            w1 = s.download_words()
+            assert (s.outbox_overflow() > 1_000_000) == (name == "tiny")
+        assert _words_conserved(w0, w1) and np.isfinite(X).all() and np.isfinite(Y).all()
+        res[name] = oa.path_stress(g, X, Y, 1_000_000, seed=1)
+    print(f"outbox overflow: stress full pool {res['full']:.4f}, 2 % pool {res['tiny']:.4f}")
+    assert res["tiny"] <= 1.15 * res["full"] + 0.01
 
 
 def test_small_and_hub_graphs_run_the_per_lane_kernel(oa, graphs):
@@ -469,18 +537,20 @@ def test_tiled_kernel_with_tandem_repeats(oa):
         new_handles.append(h)
         new_first.append(new_first[-1] + len(h))
     g2 = oa.Graph.from_arrays(g.node_len, np.array(new_first, dtype=np.uint64), np.concatenate(new_handles))
-    X0, Y0 = oa.initial_layout(g2, "d", seed=9)
-    res = {}
-    for name, flags in (("tiled", 0), ("per_lane", _lib.FLAG_NO_TILES)):
-        p = _params(oa, g2, flags=flags, min_term_updates=3 * g2.n_steps)
-        X, Y, dmax, fmt, w0, w1 = _run_session(oa, g2, p, X0, Y0)
-        assert _words_conserved(w0, w1) and np.isfinite(X).all() and np.isfinite(Y).all()
-        res[name] = oa.path_stress(g2, X, Y, 1_000_000, seed=1)
+    res = {"tiled": [], "per_lane": []}
+    for rep in range(3):   # three initial layouts and sampler seeds per kernel
+        X0, Y0 = oa.initial_layout(g2, "d", seed=9 + rep)
+        for name, flags in (("tiled", 0), ("per_lane", _lib.FLAG_NO_TILES)):
+            p = _params(oa, g2, flags=flags, min_term_updates=3 * g2.n_steps, seed=9399220 + 7919 * rep)
+            X, Y, dmax, fmt, w0, w1 = _run_session(oa, g2, p, X0, Y0)
+            assert _words_conserved(w0, w1) and np.isfinite(X).all() and np.isfinite(Y).all()
+            res[name].append(oa.path_stress(g2, X, Y, 1_000_000, seed=1))
     with oa.LayoutSession(g2, _params(oa, g2)) as s:
         info = s.tile_info()
-    print(f"tandem repeats: tiled={info['tiled']} stress tiled {res['tiled']:.4f} per-lane {res['per_lane']:.4f}")
+    print(f"tandem repeats: tiled={info['tiled']} stress tiled {res['tiled']} per-lane {res['per_lane']}")
     assert info["tiled"]
-    assert res["tiled"] <= 1.3 * res["per_lane"] + 0.05
+    # single runs of either kernel scatter by ~10 % on this graph (round 1: 0.13 .. 0.16): means within 15 %
+    assert float(np.mean(res["tiled"])) <= 1.15 * float(np.mean(res["per_lane"])) + 0.01
 
 
 @pytest.mark.parametrize("init", ["d", "g"])
@@ -493,12 +563,13 @@ def test_tile_sharded_virtual_ranks(oa, init):
     import torch
     from odgi_amd.distributed import HipEngine
     g = oa.Graph.synthetic(300_000, 24, seed=7)
-    X0, Y0 = oa.initial_layout(g, init, seed=7)
     p = _params(oa, g, min_term_updates=3 * g.n_steps)
     etas = oa.path_linear_sgd_layout_schedule(p)
-    res = {}
-    for G in (1, 2):
-        engines = [HipEngine(g, _params(oa, g, min_term_updates=3 * g.n_steps, stream_offset=r * (1 << 20)), X0, Y0) for r in range(G)]
+    res = {1: [], 2: []}
+    for G, rep in ((1, 0), (2, 0), (1, 1), (2, 1), (1, 2), (2, 2)):
+        X0, Y0 = oa.initial_layout(g, init, seed=7 + rep)
+        engines = [HipEngine(g, _params(oa, g, min_term_updates=3 * g.n_steps, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep), X0, Y0)
+                   for r in range(G)]
         for r, e in enumerate(engines):
             e.exchange_mark()
             assert e.tiled and e.set_shard(r, G, by_region=False) and e.warm_per_lane() == (init == "g")
@@ -521,9 +592,10 @@ def test_tile_sharded_virtual_ranks(oa, init):
         if G > 1:
             assert np.abs(out[0][0] - out[1][0]).max() < 1.0 and np.abs(out[0][1] - out[1][1]).max() < 1.0
         assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
-        res[G] = oa.path_stress(g, out[0][0], out[0][1], 1_000_000, seed=1)
-    print(f"tile-sharded virtual ranks, init {init}: stress G=1 {res[1]:.4f} G=2 {res[2]:.4f}")
-    assert res[2] <= 1.25 * res[1] + 0.02
+        res[G].append(oa.path_stress(g, out[0][0], out[0][1], 1_000_000, seed=1))
+    print(f"tile-sharded virtual ranks, init {init}: stress G=1 {res[1]} G=2 {res[2]}")
+    # measured (profiles/r01/virtual_ranks_tiled_tile_shard.jsonl): G = 2 costs +5..11 % at this size
+    assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))
 
 
 def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
@@ -591,6 +663,7 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         tiles_py, items_py = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56)
         for k in ("t0", "cum", "n", "path"):
             assert np.array_equal(tiles[k], tiles_py[k]), k
+        assert np.all(tiles["lanes"] == 1)                       # PGSGD_TILE_LANES=1: one term stream per tile
         for k in ("tile_begin", "tile_end", "win0", "local"):
             assert np.array_equal(items[k], items_py[k]), k
         assert tiles["steps_total"] == tiles_py["steps_total"] and items["n_first"] == items_py["n_first"]
@@ -602,6 +675,7 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
             dmax_g = s.sync()
         Xg, Yg = s.download()
         w1 = s.download_words()
+        assert s.outbox_overflow() == 0      # every far update went through the outbox, as the mirror assumes
     Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
     assert far > 0 and not np.array_equal(w0, w1)
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
@@ -675,29 +749,38 @@ def test_kernel_plan_follows_graph_order_and_initial_layout(oa):
     p = _params(oa, gr, min_term_updates=3 * gr.n_steps)
     with oa.LayoutSession(gr, p) as s:
         assert not s.tile_info()["tiled"]
-    X0, Y0 = oa.initial_layout(gr, "d", seed=7)
-    X, Y = X0.copy(), Y0.copy()
-    oa.path_linear_sgd_layout_gpu(gr, p, X, Y)
-    s_random = oa.path_stress(gr, X, Y, 1_000_000, seed=1)
+    import dataclasses
+    reps = range(3)   # three initial layouts / sampler seeds for every configuration; means are compared
+    s_random = []
+    for rep in reps:
+        X0, Y0 = oa.initial_layout(gr, "d", seed=7 + rep)
+        X, Y = X0.copy(), Y0.copy()
+        oa.path_linear_sgd_layout_gpu(gr, dataclasses.replace(p, seed=9399220 + 7919 * rep), X, Y)
+        s_random.append(oa.path_stress(gr, X, Y, 1_000_000, seed=1))
     # (b), (c) sorted graph, Gaussian vs default initial layout
     res = {}
     for init in "gd":
-        X0, Y0 = oa.initial_layout(g, init, seed=7)
         for name, flags in (("default", 0), ("per_lane", _lib.FLAG_NO_TILES)):
-            p = _params(oa, g, flags=flags, min_term_updates=3 * g.n_steps)
-            with oa.LayoutSession(g, p) as s:
-                s.upload(X0, Y0)
-                info = s.tile_info()
-            if name == "default":
-                assert info["tiled"] and info["warm_per_lane"] == (init == "g")
-            X, Y = X0.copy(), Y0.copy()
-            oa.path_linear_sgd_layout_gpu(g, p, X, Y)
-            res[init, name] = oa.path_stress(g, X, Y, 1_000_000, seed=1)
-    print(f"kernel plan: random numbering {s_random:.4f}; init g {res['g', 'default']:.4f} vs {res['g', 'per_lane']:.4f}; "
-          f"init d {res['d', 'default']:.4f} vs {res['d', 'per_lane']:.4f}")
-    assert s_random <= 1.15 * res["d", "per_lane"] + 0.01
-    assert res["g", "default"] <= 1.2 * res["g", "per_lane"] + 0.01
-    assert res["d", "default"] <= 1.15 * res["d", "per_lane"] + 0.01
+            res[init, name] = []
+            for rep in reps:
+                X0, Y0 = oa.initial_layout(g, init, seed=7 + rep)
+                p = _params(oa, g, flags=flags, min_term_updates=3 * g.n_steps, seed=9399220 + 7919 * rep)
+                if rep == 0:
+                    with oa.LayoutSession(g, p) as s:
+                        s.upload(X0, Y0)
+                        info = s.tile_info()
+                    if name == "default":
+                        assert info["tiled"] and info["warm_per_lane"] == (init == "g")
+                X, Y = X0.copy(), Y0.copy()
+                oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+                res[init, name].append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
+    m = {k: float(np.mean(v)) for k, v in res.items()}
+    print(f"kernel plan: random numbering {s_random}; init g {res['g', 'default']} vs {res['g', 'per_lane']}; "
+          f"init d {res['d', 'default']} vs {res['d', 'per_lane']}")
+    # single runs scatter by ~10 % (round 1); means of three within 15 %
+    assert float(np.mean(s_random)) <= 1.15 * m["d", "per_lane"] + 0.01
+    assert m["g", "default"] <= 1.15 * m["g", "per_lane"] + 0.01
+    assert m["d", "default"] <= 1.15 * m["d", "per_lane"] + 0.01
 
 
 def test_double_precision_download_is_exact(oa, graphs):

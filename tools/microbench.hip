@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -104,6 +105,113 @@ __global__ void loads8(const float* buf, uint64_t n_slots8, uint64_t iters, uint
     if (acc == 0x12345678u) *sink = (uint32_t)acc;
 }
 
+// round 2 -----------------------------------------------------------------------------------------------------
+// 32-byte gathers (the tile kernel's far-partner record with the coordinate snapshot inside)
+__global__ void gather32(const uint4* buf, uint64_t n_elems32, uint64_t iters, uint32_t* sink) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t k = __umul64hi(xs(s), n_elems32);
+        const uint4 a = buf[2 * k], b = buf[2 * k + 1];
+        acc += a.x ^ b.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+// 64-bit atomic adds at workgroup scope (performed in the issuing XCD's L2) against agent scope
+template <int SCOPE>
+__global__ void atomics_scope(unsigned long long* buf, uint64_t n_slots, uint64_t iters) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t a = __umul64hi(xs(s), n_slots);
+        __hip_atomic_fetch_add(buf + a, 0x100000001ull, __ATOMIC_RELAXED, SCOPE);
+    }
+}
+
+// The far-update outbox: every lane appends 16-byte messages to one of B destination buckets.  A workgroup owns, per
+// bucket, a private chunk of CH messages in global memory; the slot inside the chunk comes from an LDS atomic on a
+// packed (chunk id, fill) word, a new chunk from one returning global atomic on the bucket's chunk counter.
+// SKEW: 0 = destinations uniform over the buckets; 1 = half of them in the workgroup's own bucket +-1.
+template <int CH, int SKEW>
+__global__ void outbox(uint4* pool, unsigned int* bucket_next, uint32_t B, uint32_t cap_chunks, uint64_t iters, unsigned int* overflow) {
+    extern __shared__ unsigned long long st[];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) st[b] = (0xffffffffull << 32) | (unsigned)CH;
+    __syncthreads();
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    const uint32_t home = blockIdx.x % B;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s);
+        uint32_t b = (uint32_t)__umul64hi(r, B);
+        if (SKEW && (r & 1)) b = (home + B + (uint32_t)((r >> 1) % 3) - 1) % B;
+        const uint4 msg = make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)i, b);
+        for (;;) {
+            const unsigned long long old = atomicAdd(&st[b], 1ull);
+            const uint32_t slot = (uint32_t)old, chunk = (uint32_t)(old >> 32);
+            if (slot < (uint32_t)CH) {
+                pool[((uint64_t)b * cap_chunks + chunk) * CH + slot] = msg;
+                break;
+            }
+            if (slot == (uint32_t)CH) {
+                uint32_t nc = atomicAdd(bucket_next + b, 1u);
+                if (nc >= cap_chunks) { atomicAdd(overflow, 1u); nc = cap_chunks - 1; }
+                atomicExch(&st[b], (unsigned long long)nc << 32);
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+}
+
+// the same messages sent as one agent-scope 64-bit atomic each (what the tile kernel does today)
+__global__ void outbox_atomic(unsigned long long* coords, uint64_t n_slots, uint64_t iters) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    for (uint64_t i = 0; i < iters; ++i) atomicAdd(coords + __umul64hi(xs(s), n_slots), 0x100000001ull);
+}
+
+// drain: one workgroup per bucket streams the bucket's chunks and adds the messages into an LDS window
+template <int CH>
+__global__ void drain(const uint4* pool, const unsigned int* bucket_next, uint32_t cap_chunks, unsigned long long* coords, uint32_t ends_per_bucket) {
+    extern __shared__ unsigned long long acc[];
+    const uint32_t b = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < ends_per_bucket; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+    const uint64_t n_msgs = (uint64_t)min(bucket_next[b], cap_chunks) * CH;
+    const uint4* src = pool + (uint64_t)b * cap_chunks * CH;
+    for (uint64_t i = threadIdx.x; i < n_msgs; i += blockDim.x) {
+        const uint4 m = src[i];
+        atomicAdd(&acc[m.x % ends_per_bucket], (unsigned long long)m.y | ((unsigned long long)m.z << 32));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ends_per_bucket; i += blockDim.x) coords[(uint64_t)b * ends_per_bucket + i] += acc[i];
+}
+
+// Scattered writes of G adjacent 16-byte pieces (G lanes of one wave, one instruction) to random G*16-byte aligned
+// places of a buffer far larger than the caches: does a write that covers a whole 64- or 128-byte unit avoid the
+// read-for-ownership a 16-byte one pays?
+template <int G>
+__global__ void wstore(uint4* buf, uint64_t n_groups, uint64_t iters) {
+    const uint32_t lane = threadIdx.x & 63u, grp = lane / G, piece = lane % G;
+    uint64_t s = 0x9E3779B97F4A7C15ull * (((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / G) * G + 1);  // same stream inside a group
+    (void)grp;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s);
+        buf[__umul64hi(r, n_groups) * G + piece] = make_uint4((uint32_t)r, (uint32_t)i, piece, 0u);
+    }
+}
+
+// streaming writes: MODE 0 = 16 bytes into every 32-byte record (what snapshot_kernel does), 1 = the whole 32-byte
+// record, 2 = a dense 16-byte array
+template <int MODE>
+__global__ void swrite(uint4* buf, uint64_t n, const uint32_t* src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = src[k];
+        const uint4 v = make_uint4(h, h + 1, h + 2, h + 3);
+        if (MODE == 0) buf[2 * k + 1] = v;
+        if (MODE == 1) { buf[2 * k] = v; buf[2 * k + 1] = v; }
+        if (MODE == 2) buf[k] = v;
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 3) {
     hipEvent_t a, b;
@@ -136,6 +244,88 @@ int main() {
         const double total = (double)lanes * iters;
         printf("{\"bench\": \"gather16\", \"MiB\": %llu, \"G_per_s_ilp1\": %.2f, \"ilp2\": %.2f, \"ilp4\": %.2f, \"near_pairs_G_gathers_per_s\": %.2f}\n",
                (unsigned long long)(bytes >> 20), total / ms1 / 1e6, total / ms2 / 1e6, total / ms4 / 1e6, total / msn / 1e6);
+    }
+    if (getenv("MICROBENCH_R2B")) {
+        (void)hipFree(g);
+        const size_t big2 = 3ull << 30;
+        CK(hipMalloc(&g, big2)); CK(hipMemset(g, 1, big2));
+        const uint64_t iters = 64;
+        auto ws = [&](auto kern, int G) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, g, big2 / 16 / G, iters); });
+            const double groups = (double)lanes / G * iters;
+            printf("{\"bench\": \"wstore\", \"bytes_per_write\": %d, \"G_writes_per_s\": %.2f, \"G_16B_pieces_per_s\": %.2f, \"GB_per_s\": %.1f}\n", 16 * G,
+                   groups / ms / 1e6, groups * G / ms / 1e6, groups * G * 16 / ms / 1e6);
+        };
+        ws(wstore<1>, 1); ws(wstore<2>, 2); ws(wstore<4>, 4); ws(wstore<8>, 8); ws(wstore<16>, 16);
+        uint32_t* src; const uint64_t n = 46667298ull;
+        CK(hipMalloc(&src, n * 4)); CK(hipMemset(src, 0, n * 4));
+        double m0 = time_ms([&] { hipLaunchKernelGGL(swrite<0>, dim3(4096), dim3(256), 0, 0, g, n, src); });
+        double m1 = time_ms([&] { hipLaunchKernelGGL(swrite<1>, dim3(4096), dim3(256), 0, 0, g, n, src); });
+        double m2 = time_ms([&] { hipLaunchKernelGGL(swrite<2>, dim3(4096), dim3(256), 0, 0, g, n, src); });
+        printf("{\"bench\": \"swrite\", \"steps\": %llu, \"ms_16B_of_32B\": %.3f, \"ms_32B\": %.3f, \"ms_16B_dense\": %.3f}\n", (unsigned long long)n, m0, m1, m2);
+        return 0;
+    }
+    if (getenv("MICROBENCH_R2")) {
+        (void)hipFree(g);
+        const size_t big2 = 6ull << 30;
+        CK(hipMalloc(&g, big2)); CK(hipMemset(g, 1, big2));
+        for (uint64_t bytes : {768ull << 20, 1536ull << 20}) {
+            const uint64_t iters = 256;
+            const double total = (double)lanes * iters;
+            double m16 = time_ms([&] { hipLaunchKernelGGL(gather16<1>, dim3(grid), dim3(block), 0, 0, g, bytes / 16, iters, sink); });
+            double m32 = time_ms([&] { hipLaunchKernelGGL(gather32, dim3(grid), dim3(block), 0, 0, g, bytes / 32, iters, sink); });
+            printf("{\"bench\": \"gather32\", \"MiB\": %llu, \"G_per_s_16B\": %.2f, \"G_per_s_32B\": %.2f}\n", (unsigned long long)(bytes >> 20), total / m16 / 1e6, total / m32 / 1e6);
+        }
+        for (uint64_t bytes : {1ull << 20, 16ull << 20, 128ull << 20}) {
+            const uint64_t iters = 128;
+            const double total = (double)lanes * iters;
+            double ma = time_ms([&] { hipLaunchKernelGGL(atomics_scope<__HIP_MEMORY_SCOPE_AGENT>, dim3(grid), dim3(block), 0, 0, (unsigned long long*)g, bytes / 8, iters); });
+            double mw = time_ms([&] { hipLaunchKernelGGL(atomics_scope<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(grid), dim3(block), 0, 0, (unsigned long long*)g, bytes / 8, iters); });
+            printf("{\"bench\": \"atomics_scope\", \"MiB\": %llu, \"G_per_s_agent\": %.2f, \"G_per_s_workgroup\": %.2f}\n", (unsigned long long)(bytes >> 20), total / ma / 1e6, total / mw / 1e6);
+        }
+        unsigned int *bucket_next, *overflow;
+        unsigned long long* dcoords;
+        CK(hipMalloc(&bucket_next, 4096 * 4)); CK(hipMalloc(&overflow, 4));
+        CK(hipMalloc(&dcoords, 1024ull * 8192 * 8)); CK(hipMemset(dcoords, 0, 1024ull * 8192 * 8));
+        for (uint32_t B : {256u, 512u, 1024u}) {
+            const uint64_t iters = 96;   // ~100 far messages per lane, as in one tile-kernel launch
+            const double total = (double)lanes * iters;
+            const uint32_t ch = 64;
+            const uint32_t cap = (uint32_t)(big2 / 16 / ch / B);
+            auto run = [&](auto kern, const char* name, int wg) {
+                const int gr = (int)(lanes / wg);
+                double best = 1e30;
+                unsigned int of = 0, used = 0;
+                for (int r = 0; r < 3; ++r) {
+                    hipMemset(bucket_next, 0, 4096 * 4); hipMemset(overflow, 0, 4);
+                    hipEvent_t a, b2; hipEventCreate(&a); hipEventCreate(&b2);
+                    hipEventRecord(a);
+                    hipLaunchKernelGGL(kern, dim3(gr), dim3(wg), B * 8, 0, g, bucket_next, B, cap, iters, overflow);
+                    hipEventRecord(b2); hipEventSynchronize(b2);
+                    float ms; hipEventElapsedTime(&ms, a, b2); if (ms < best) best = ms;
+                    hipEventDestroy(a); hipEventDestroy(b2);
+                }
+                hipMemcpy(&of, overflow, 4, hipMemcpyDeviceToHost);
+                std::vector<unsigned int> nx(B); hipMemcpy(nx.data(), bucket_next, B * 4, hipMemcpyDeviceToHost);
+                for (auto v : nx) used += v;
+                printf("{\"bench\": \"outbox\", \"variant\": \"%s\", \"buckets\": %u, \"wg\": %d, \"chunk_msgs\": %u, \"G_msgs_per_s\": %.2f, \"ms\": %.3f, \"overflow\": %u, \"chunks_used\": %u, \"fill\": %.3f}\n",
+                       name, B, wg, ch, total / best / 1e6, best, of, used, total / ((double)used * ch));
+            };
+            run(outbox<64, 0>, "uniform", 256);
+            run(outbox<64, 1>, "skewed", 256);
+            run(outbox<64, 0>, "uniform", 1024);
+            // drain of the last fill
+            const uint32_t epb = 8192;
+            double md = time_ms([&] { hipLaunchKernelGGL(drain<64>, dim3(B), dim3(1024), epb * 8, 0, g, bucket_next, cap, dcoords, epb); }, 2);
+            printf("{\"bench\": \"drain\", \"buckets\": %u, \"ends_per_bucket\": %u, \"ms\": %.3f, \"G_msgs_per_s\": %.2f}\n", B, epb, md, total / md / 1e6);
+        }
+        {
+            const uint64_t iters = 96;
+            const double total = (double)lanes * iters;
+            double ma = time_ms([&] { hipLaunchKernelGGL(outbox_atomic, dim3(grid), dim3(block), 0, 0, (unsigned long long*)g, (16ull << 20) / 8, iters); });
+            printf("{\"bench\": \"outbox\", \"variant\": \"agent atomics into 16 MiB\", \"G_msgs_per_s\": %.2f}\n", total / ma / 1e6);
+        }
+        return 0;
     }
     float* c = (float*)g;
     for (uint64_t bytes : {1ull << 20, 16ull << 20, 160ull << 20, 768ull << 20}) {
