@@ -107,6 +107,9 @@ typedef struct pgsgd_params {
                           /* m > 1 keeps each term's distribution (first step uniform, partner by    */
                           /* the reference's rule) but fetches and updates the first step once per m  */
                           /* terms — fewer scattered memory requests per term                         */
+    uint32_t n_devices;   /* GPUs of one node to run on (0/1 = one: `device`).  G > 1: devices device..device+G-1, */
+                          /* graph replicated, every step's terms split 1/G per GPU, coordinates merged with an   */
+                          /* RCCL all-reduce at every step (pgsgd_layout_run / _f64 only; sessions are per GPU)   */
 } pgsgd_params;
 
 #define PGSGD_DEFAULT_SEED 9399220ull
@@ -119,6 +122,8 @@ typedef struct pgsgd_stats {
     double   wall_ms;         /* upload + iterations + download                                    */
     uint32_t n_streams;       /* streams actually used                                             */
     uint32_t early_stop;      /* 1 if Delta_max <= delta ended the run (path_sgd_layout.cpp:142)    */
+    uint32_t frame_doublings; /* times the fixed-point coordinate frame was widened during the run  */
+    uint32_t reserved;
 } pgsgd_stats;
 
 /* Fill every field of *p with the reference defaults derived from the path index
@@ -174,6 +179,13 @@ int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t 
 int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint64_t n_terms, uint32_t part, uint32_t n_parts);
 /* Wait for the stream; returns max |Delta| of the last iteration in *delta_max (may be NULL). */
 int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
+/* The fixed-point coordinate frame (2^32 quanta per axis, 8x the layout's extent at upload).  Kernels flag any
+ * coordinate they see in the outer quarter of the frame; pgsgd_session_sync then doubles the frame (same centre, half
+ * the resolution) before the next iteration, so a node end never wraps around.  A session that is part of a multi-GPU
+ * run (exchange_mark / set_shard) only reports: its driver calls pgsgd_session_reframe on every rank in the same
+ * iteration when any rank's guard_hit is set. */
+int pgsgd_session_frame_status(const pgsgd_session* s, int* guard_hit, uint32_t* doublings);
+int pgsgd_session_reframe(pgsgd_session* s);
 /* Sum of update-kernel durations since creation / last reset, measured with HIP events. */
 int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* launches, int reset);
 /* Tile kernel only: time spent in the two streaming kernels around every tile launch (coordinate snapshot into the

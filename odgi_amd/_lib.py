@@ -35,12 +35,13 @@ class Params(C.Structure):
                 ("space", u64), ("space_max", u64), ("space_quantization_step", u64),
                 ("cooling_start", f64), ("seed", u64), ("n_streams", u32), ("stream_offset", u32),
                 ("device", i32), ("snapshot", i32), ("snapshot_prefix", C.c_char_p),
-                ("progress", i32), ("flags", u32), ("terms_per_anchor", u32)]
+                ("progress", i32), ("flags", u32), ("terms_per_anchor", u32), ("n_devices", u32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("iterations", u64), ("term_updates", u64), ("last_delta_max", f64),
-                ("kernel_ms", f64), ("wall_ms", f64), ("n_streams", u32), ("early_stop", u32)]
+                ("kernel_ms", f64), ("wall_ms", f64), ("n_streams", u32), ("early_stop", u32),
+                ("frame_doublings", u32), ("reserved", u32)]
 
 
 FLAG_COORD_LOAD_PLAIN = 0x1
@@ -77,6 +78,8 @@ SIGNATURES = [
     ("pgsgd_session_iteration", C.c_int, [C.c_void_p, f64, C.c_int, u64]),
     ("pgsgd_session_iteration_part", C.c_int, [C.c_void_p, f64, C.c_int, u64, u32, u32]),
     ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
+    ("pgsgd_session_frame_status", C.c_int, [C.c_void_p, P(C.c_int), P(u32)]),
+    ("pgsgd_session_reframe", C.c_int, [C.c_void_p]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
     ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),

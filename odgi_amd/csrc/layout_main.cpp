@@ -4,10 +4,16 @@
 // (src/subcommand/layout_main.cpp:18-466): flags :28-96, mandatory checks :113-125, "not optimized"
 // exit :148-151, derived defaults :198-204,251-266, initial layout :268-330, SGD dispatch :333-387,
 // component stacking :401-435, TSV/.lay output :438-463.  The SGD always runs on the GPU (`--gpu`
-// is accepted for command-line compatibility); input is GFA v1 (the reference's own conversion
-// route, src/utils.cpp:122-129) — `.og` and `-X` need sdsl/DYNAMIC on-disk forms.
+// is accepted for command-line compatibility); input is odgi's native `.og` or GFA v1, dispatched by
+// file name like the reference (src/utils.cpp:110-134).  `-X FILE` (a serialized XP index,
+// src/algorithms/xp.cpp:247-324) is refused with a message and exit code 1: the file is a dump of
+// sdsl-lite structures (csa_wt, enc_vector, bit_vector + rank/select supports) whose on-disk layout
+// is defined by a dependency that is absent from the reference tree, and the reference holds no XP
+// file to pin a reader against; the index is lowered from the graph input instead, which is what
+// the reference does when -X is not given (layout_main.cpp:220-227).
 // Additions: `--seed N` (reproducible initial layout and sampler; upstream's flag is commented
-// out, :76-80), `--gpu-streams N`, `--device N`, `--stress` (print layout quality to stderr).
+// out, :76-80), `--gpu-streams N`, `--device N`, `--gpus N` (multi-GPU, pgsgd_multi.cpp), `--stress` (print layout
+// quality to stderr).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +53,7 @@ const Opt kOpts[] = {
     {0, "gpu", false, "", "Enable computation with GPU (always on in this build)."},
     {0, "seed", true, "N", "Seed for the initial layout and the sampler streams (default: random initial layout, sampler seed 9399220)."},
     {0, "gpu-streams", true, "N", "Number of concurrent sampler streams on the GPU (default: from graph size)."},
+    {0, "gpus", true, "N", "Run on N GPUs of this node (devices --device .. --device+N-1): graph replicated, every iteration's terms split 1/N per GPU, coordinates merged with an RCCL all-reduce at every iteration (default: 1)."},
     {0, "device", true, "N", "HIP device ordinal (default: current)."},
     {0, "gpu-no-tiles", false, "", "Always use the per-lane kernel (one reference worker stream per GPU lane), never the tiled one."},
     {0, "gpu-terms-per-anchor", true, "N", "Partners drawn per sampled first step (default: 1 = the reference's term stream)."},
@@ -154,7 +161,8 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     if (a.has("threads") && !to_u64(a.get("threads"), &num_threads)) return bad("threads");
     if (num_threads == 0) num_threads = 1;
     if (a.has("path-index")) {
-        fprintf(stderr, "[odgi::layout] error: -X/--path-index is not supported by this build; the path index is lowered from the graph input.\n");
+        fprintf(stderr, "[odgi::layout] error: -X/--path-index is not supported by this build (serialized XP files are sdsl-lite dumps; there is no "
+                        "reference fixture to pin a reader against). Leave -X out: the path index is built from the graph input, as the reference does without -X.\n");
         return 1;
     }
     // utils.cpp:110-134: names ending in "gfa" are built from GFA, anything else (and "-" = stdin) is .og
@@ -263,6 +271,9 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
         if (!to_u64(a.get("device"), &device)) return finish(bad("device"));
         p.device = (int32_t)device;
     }
+    uint64_t gpus = 1;
+    if (a.has("gpus") && (!to_u64(a.get("gpus"), &gpus) || gpus == 0 || gpus > 64)) return finish(bad("gpus"));
+    p.n_devices = (uint32_t)gpus;
 
     // initial layout (:268-330)
     char init_mode = 'd';

@@ -84,6 +84,7 @@ extern "C" int pgsgd_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p)
     p->stream_offset = 0;
     p->device = -1;
     p->terms_per_anchor = 1;
+    p->n_devices = 1;
     return PGSGD_OK;
 }
 

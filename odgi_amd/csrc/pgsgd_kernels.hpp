@@ -55,6 +55,7 @@ struct DevConst {
     uint64_t* coords;  // [2N] words
     uint64_t* rng;
     unsigned int* delta_max_bits;
+    unsigned int* frame_flag;  // set when a coordinate is seen in the outer quarter of the fixed-point frame
     uint64_t n_steps;
     uint32_t n_paths;
     uint32_t n_streams;
@@ -65,6 +66,21 @@ struct DevConst {
     ZipfConst zc;
     Xform xf;
 };
+
+// Fixed-point frame guard.  A field of a coordinate word leaves [0, 2^32) by wrapping (and carries one quantum into
+// its neighbour), which would silently move a node end across the whole frame.  The frame is chosen 8x wider than the
+// layout, so kernels only watch the outer quarter on either side: a coordinate seen there sets frame_flag, and the
+// host doubles the frame (halving the resolution) before the next iteration (reframe_kernel).
+__device__ __forceinline__ bool in_frame_guard(uint64_t w) {
+    const uint32_t x = (uint32_t)w, y = (uint32_t)(w >> 32);
+    return (uint32_t)(x - 0x40000000u) >= 0x80000000u || (uint32_t)(y - 0x40000000u) >= 0x80000000u;
+}
+__global__ void reframe_kernel(uint64_t* words, uint64_t n) {  // same centre, twice the span: q' = q/2 + 2^30 per field
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = words[i];
+        words[i] = (uint64_t)(((uint32_t)w >> 1) + 0x40000000u) | ((uint64_t)(((uint32_t)(w >> 32) >> 1) + 0x40000000u) << 32);
+    }
+}
 
 struct IterArgs {
     uint64_t n_terms;
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     rng.s2 = c.rng[2 * L + g];
     rng.s3 = c.rng[3 * L + g];
     float dmax = 0.0f;
+    bool guard = false;
     if (!GROUPED) {
         for (uint64_t ti = g; ti < a.n_terms; ti += L) {
             const Anchor an = sample_anchor(c, pf, rng);
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
             if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
                 dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                 dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+                guard |= in_frame_guard(wa) | in_frame_guard(wb);
             } else {
                 dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
@@ -344,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
             if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
                 dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                 dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+                guard |= in_frame_guard(wa) | in_frame_guard(wb);
             } else {
                 dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
@@ -423,6 +442,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
     // per-wavefront reduction of the early-stop quantity, one atomic per wave (:341-347)
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------

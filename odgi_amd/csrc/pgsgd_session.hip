@@ -50,8 +50,9 @@ struct pgsgd_session {
     uint64_t* d_coords = nullptr;         // [2N] coordinate words
     uint64_t* d_base = nullptr;           // coordinates at the last exchange (multi-GPU only)
     uint64_t* d_rng = nullptr;
-    unsigned int* d_delta_max = nullptr;
-    unsigned int* h_delta_max = nullptr;  // pinned
+    unsigned int* d_delta_max = nullptr;  // [2]: max |Delta| of the iteration (float bits), frame-guard flag
+    unsigned int* h_delta_max = nullptr;  // pinned copy
+    uint32_t frame_doublings = 0;         // times the fixed-point frame was widened (reframe)
     pgsgd::DevConst dc{};
     // region-exclusive tiles
     bool tiled = false;
@@ -85,7 +86,8 @@ struct pgsgd_session {
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
-    uint32_t* d_queue = nullptr;          // [2] work-item counters
+    uint32_t n_windowless = 0;            // the last n_windowless items of colour 0 have no window (their own launch)
+    uint32_t* d_queue = nullptr;          // [3] work-item counters: colour 0, colour 1, colour 0's window-less items
     uint64_t tile_steps_total = 0;
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
     size_t tile_lds = 0;
@@ -192,9 +194,15 @@ struct HostTiles {
     uint64_t steps_total = 0, n_nonlocal = 0;
 };
 
-typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::IterArgs);
-static tile_kernel_t tile_kernel(int far) {
-    return far == pgsgd::kFarExclusive ? pgsgd::sgd_tile_kernel<1, pgsgd::kFarExclusive> : pgsgd::sgd_tile_kernel<1, pgsgd::kFarTwoSided>;
+typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::TileSampler, pgsgd::IterArgs);
+template <int FAR>
+static tile_kernel_t tile_kernel_f(bool cooling, bool local) {
+    using namespace pgsgd;
+    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true> : sgd_tile_kernel<1, FAR, false, true>;
+    return cooling ? sgd_tile_kernel<1, FAR, true, false> : sgd_tile_kernel<1, FAR, false, false>;
+}
+static tile_kernel_t tile_kernel(int far, bool cooling = false, bool local = true) {
+    return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided>(cooling, local);
 }
 
 static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
@@ -475,8 +483,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
         }
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
-        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) +
-                      (size_t)s->ob.n_buckets * (pgsgd::kObLine * sizeof(uint4) + 2 * sizeof(uint32_t)) + 8 + (size_t)pgsgd::kTileWaves * 64 * sizeof(uint2);
+        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
         int bpc = 0;
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
@@ -487,7 +494,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
         const bool force = getenv("PGSGD_TILE_FORCE") != nullptr;
-        if ((force || cap >= 4 * cu_lanes) && g->n_nodes >= 8ull * s->region) {
+        if ((force || cap >= 4 * cu_lanes) && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
             HostTiles ht = build_tiles(g, s->region, s->tile_steps);
             if (const char* e = getenv("PGSGD_TILE_LANES")) {
@@ -530,12 +537,14 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 s->n_nonlocal_tiles = ht.n_nonlocal;
                 s->n_items[0] = (uint32_t)ht.items[0].size();
                 s->n_items[1] = (uint32_t)ht.items[1].size();
+                s->n_windowless = (uint32_t)ht.n_nonlocal;
                 std::vector<pgsgd::WorkItem> all(ht.items[0]);
                 all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
                 s->h_items = all;
                 S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
                 S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
-                S_TRY(hipMalloc(&s->d_queue, 2 * sizeof(uint32_t)));
+                S_TRY(hipMalloc(&s->d_queue, 3 * sizeof(uint32_t)));
+                S_TRY(hipMemset(s->d_queue, 0, 3 * sizeof(uint32_t)));
                 if ((sizeof(uint64_t) << s->ob_part_shift) > 48 * 1024)
                     S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)(sizeof(uint64_t) << s->ob_part_shift)));
@@ -589,10 +598,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     S_TRY(hipMalloc(&s->d_coords, g->n_nodes * 2 * sizeof(uint64_t)));
     S_TRY(hipMemset(s->d_coords, 0, g->n_nodes * 2 * sizeof(uint64_t)));
     S_TRY(hipMalloc(&s->d_rng, (size_t)s->n_streams * 4 * sizeof(uint64_t)));
-    S_TRY(hipMalloc(&s->d_delta_max, sizeof(unsigned int)));
-    S_TRY(hipMemset(s->d_delta_max, 0, sizeof(unsigned int)));
-    S_TRY(hipHostMalloc(&s->h_delta_max, sizeof(unsigned int)));
-    *s->h_delta_max = 0;
+    S_TRY(hipMalloc(&s->d_delta_max, 2 * sizeof(unsigned int)));
+    S_TRY(hipMemset(s->d_delta_max, 0, 2 * sizeof(unsigned int)));
+    S_TRY(hipHostMalloc(&s->h_delta_max, 2 * sizeof(unsigned int)));
+    s->h_delta_max[0] = s->h_delta_max[1] = 0;
     {
         const int grid = (int)((s->n_streams + 255) / 256);
         hipLaunchKernelGGL(pgsgd::seed_streams_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_rng, s->n_streams,
@@ -608,6 +617,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.coords = s->d_coords;
     c.rng = s->d_rng;
     c.delta_max_bits = s->d_delta_max;
+    c.frame_flag = s->d_delta_max + 1;
     c.n_steps = g->n_steps;
     c.n_paths = (uint32_t)g->n_paths;
     c.n_streams = s->n_streams;
@@ -661,21 +671,25 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
 // Fixed-point frame for kFmtQ32: a power-of-two number of quanta per bp such that 2^32 quanta span
 // 8x the larger of the initial layout's extent and the longest path (the scale a path-guided
 // layout settles at), centred on the initial layout.
-static void choose_xform(pgsgd_session* s, const float* X, const float* Y) {
+static int choose_xform(pgsgd_session* s, const float* X, const float* Y) {
     const uint64_t n_ends = 2 * s->n_nodes;
-    double minx = X[0], maxx = X[0], miny = Y[0], maxy = Y[0];
+    double minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
     for (uint64_t i = 0; i < n_ends; ++i) {
         if (std::isfinite(X[i])) { minx = std::min<double>(minx, X[i]); maxx = std::max<double>(maxx, X[i]); }
         if (std::isfinite(Y[i])) { miny = std::min<double>(miny, Y[i]); maxy = std::max<double>(maxy, Y[i]); }
     }
+    if (!(minx <= maxx) || !(miny <= maxy)) { set_error("the initial layout has no finite coordinate"); return PGSGD_E_INVALID; }
+    double factor = 8.0;
+    if (const char* e = getenv("PGSGD_FRAME_SPAN")) factor = std::max(1.0, atof(e));  // test knob: a frame this tight must widen itself
     const double extent = std::max({maxx - minx, maxy - miny, (double)s->max_path_bp, 1.0});
-    const int span_log2 = (int)std::ceil(std::log2(8.0 * extent));
+    const int span_log2 = (int)std::ceil(std::log2(factor * extent));
     const double span = std::ldexp(1.0, span_log2);
     pgsgd::Xform& xf = s->dc.xf;
     xf.scale = (float)std::ldexp(1.0, 32 - span_log2);
     xf.inv_scale = (float)std::ldexp(1.0, span_log2 - 32);
     xf.x_off = 0.5 * (minx + maxx) - 0.5 * span;
     xf.y_off = 0.5 * (miny + maxy) - 0.5 * span;
+    return PGSGD_OK;
 }
 
 extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y) {
@@ -683,7 +697,11 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
     const uint64_t n_ends = 2 * s->n_nodes;
-    if (s->fmt == pgsgd::kFmtQ32) choose_xform(s, X, Y);
+    if (s->fmt == pgsgd::kFmtQ32) {
+        const int rc = choose_xform(s, X, Y);
+        if (rc) return rc;
+        s->frame_doublings = 0;
+    }
     if (s->tiled && !getenv("PGSGD_TILE_FORCE")) {
         // 0.1 = long-range distances off by a third on average; `-N d` on a sorted graph measures ~0.01
         const double st = check_pairs_stress(s, X, Y);
@@ -909,7 +927,7 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     for (uint32_t b = 0; b < B; ++b) {
         const double share = steps_total ? (double)s->ob_bucket_steps[b] / (double)steps_total : 1.0 / B;
         uint64_t c = (uint64_t)std::ceil(frac * (double)per_call * share / (double)pgsgd::kObChunk) + open_chunks;
-        c = std::min<uint64_t>(c, pgsgd::kObOverflow - 1);
+        c = std::min<uint64_t>(c, pgsgd::kObOverflow - 1);  // chunk ids must fit the workgroups' LDS line words
         if ((total + c) * pgsgd::kObLinesPerChunk > 0xfffffffeull) { set_error("outbox pool exceeds 2^32 lines"); return PGSGD_E_UNSUPPORTED; }
         if (total + c > 0xffffffffull) { set_error("outbox pool exceeds 2^32 chunks"); return PGSGD_E_UNSUPPORTED; }
         chunk0[b] = (uint32_t)total;
@@ -960,9 +978,13 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     // a tiled session whose initial layout had no global structure runs the per-lane kernel until cooling
     const bool use_tiles = s->tiled && !(s->warm_per_lane && !cooling);
     if (!use_tiles) {
-        if (s->tiled && s->tshard_world > 1) {  // the caller passed the whole iteration: this device's share
-            const uint64_t base = n_terms / s->tshard_world, rem = n_terms % s->tshard_world;
-            n_terms = base + (s->tshard_rank < rem ? 1 : 0);
+        // a sharded tiled session takes the whole iteration's term count (its tiles' share is applied); while it runs
+        // the per-lane kernel (warm phase of a layout without global structure) it applies this device's 1/G of them,
+        // whichever way the tiles are sharded
+        const uint32_t world = std::max(s->tshard_world, s->shard_world), rank = s->tshard_world > 1 ? s->tshard_rank : s->shard_rank;
+        if (s->tiled && world > 1) {
+            const uint64_t base = n_terms / world, rem = n_terms % world;
+            n_terms = base + (rank < rem ? 1 : 0);
         }
         if (n_parts > 1) {
             const uint64_t base = n_terms / n_parts, rem = n_terms % n_parts;
@@ -994,10 +1016,11 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         // nothing was counted before a colour's first launch: assume three quarters of the partners of this call's
         // terms are far, half of them in each colour's launch
         const double h0 = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
-        HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, 2 * sizeof(unsigned int), s->stream));
         // tile subsets: (part, window refresh, tile shard of this device) -> tiles with index = sub (mod n_sub)
         const uint32_t n_sub = n_parts * s->tile_substeps * s->tshard_world;
         const int snap_grid = (int)std::min<uint64_t>((s->n_steps + 255) / 256, 256 * 16);
+        bool snapshot_taken = false;
         for (uint32_t ps = part * s->tile_substeps; ps < (part + 1) * s->tile_substeps; ++ps)
         for (int colour = 0; colour < 2; ++colour) {
             const uint32_t sub = ps * s->tshard_world + s->tshard_rank;
@@ -1011,7 +1034,6 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.tiles = s->d_tiles;
             ta.items = s->d_items + (colour ? s->n_items[0] : 0);
             ta.queue = s->d_queue + colour;
-            ta.n_items = s->n_items[colour];
             ta.region = s->region;
             ta.tile_steps = s->tile_steps;
             ta.term0 = s->d_term0;
@@ -1021,29 +1043,63 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.shard_world = s->shard_world;
             // the far-pull count of this colour's previous launch stays on the device: no host round trip
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
+            static const double far_relax = getenv("PGSGD_FAR_RELAX") ? atof(getenv("PGSGD_FAR_RELAX")) : 1.0;  // A/B knob
+            ta.far_relax = (float)far_relax;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
+            ta.experiment = getenv("PGSGD_TILE_EXP") ? (uint32_t)atoi(getenv("PGSGD_TILE_EXP")) : 0u;
             ta.ob = s->ob;
+            pgsgd::TileSampler ts;
+            ts.zeta_denom = s->d_zeta_denom;
+            ts.space = (uint32_t)std::min<uint64_t>(s->params.space, 0xffffffffull);
+            ts.space_max = (uint32_t)std::min<uint64_t>(s->params.space_max, 0xffffffffull);
+            ts.space_quant = (uint32_t)std::min<uint64_t>(s->params.space_quantization_step, 0xffffffffull);
+            ts.omt_e = s->dc.zc.omt_e;
+            ts.alpha_e = s->dc.zc.alpha_e;
+            ts.omt_frac = s->dc.zc.omt_frac;
+            ts.alpha_frac = s->dc.zc.alpha_frac;
+            ts.one_plus_half_pow = s->dc.zc.one_plus_half_pow;
+            // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own
+            const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
+            ta.n_items = s->n_items[colour] - windowless;
             HIP_TRY(hipEventRecord(ev.e[2], s->stream));
-            hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps,
-                               s->d_recs2, ta.queue, ta.far_count);
-            HIP_TRY(hipGetLastError());
+            static const bool snapshot_per_launch = getenv("PGSGD_SNAPSHOT_PER_LAUNCH") != nullptr;  // A/B knob
+            if (!snapshot_taken || snapshot_per_launch) {  // once per call: partners outside a window are read as they were when the iteration began
+                hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
+                HIP_TRY(hipGetLastError());
+                snapshot_taken = true;
+            }
             HIP_TRY(hipEventRecord(ev.e[0], s->stream));
-            hipLaunchKernelGGL(tile_kernel(s->tile_far), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream, s->dc, ta, a);
-            HIP_TRY(hipGetLastError());
+            if (ta.n_items) {
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, true), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                                   s->dc, ta, ts, a);
+                HIP_TRY(hipGetLastError());
+            }
+            if (windowless) {
+                pgsgd::TileArgs tw = ta;
+                tw.items = ta.items + ta.n_items;
+                tw.n_items = windowless;
+                tw.queue = s->d_queue + 2;
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                                   s->dc, tw, ts, a);
+                HIP_TRY(hipGetLastError());
+            }
             HIP_TRY(hipEventRecord(ev.e[1], s->stream));
             hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(s->ob.n_buckets << (s->ob.shift - s->ob_part_shift)), dim3(1024),
-                               sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift);
+                               sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift, s->dc.frame_flag);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets);
+            // (the far counter the next launch will write: colours alternate unless one of them has no work items)
+            const int next_colour = s->n_items[1 - colour] ? 1 - colour : colour;
+            hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
+                               s->d_queue, s->d_far + 2 * next_colour + (s->far_launches[next_colour] & 1u));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ev.e[3], s->stream));
             s->pending_events.push_back(ev);
         }
-        HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
         return PGSGD_OK;
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
@@ -1056,7 +1112,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         if (rc) return rc;
     }
     ev.n = 2;
-    HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, 2 * sizeof(unsigned int), s->stream));
     pgsgd::IterArgs a;
     a.n_terms = n_terms;
     a.eta = (float)eta;
@@ -1069,7 +1125,43 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.e[1], s->stream));
     s->pending_events.push_back(ev);
-    HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+    return PGSGD_OK;
+}
+
+// Widen the fixed-point frame: same centre, twice the span, half the resolution (see in_frame_guard).
+extern "C" int pgsgd_session_reframe(pgsgd_session* s) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (s->fmt != pgsgd::kFmtQ32) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::reframe_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends);
+    HIP_TRY(hipGetLastError());
+    if (s->d_base) {
+        hipLaunchKernelGGL(pgsgd::reframe_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_base, n_ends);
+        HIP_TRY(hipGetLastError());
+    }
+    pgsgd::Xform& xf = s->dc.xf;
+    xf.x_off -= 2147483648.0 * (double)xf.inv_scale;  // centre x_off + 2^31 / scale stays where it is
+    xf.y_off -= 2147483648.0 * (double)xf.inv_scale;
+    xf.scale *= 0.5f;
+    xf.inv_scale *= 2.0f;
+    s->h_delta_max[1] = 0;
+    s->frame_doublings++;
+    if (s->params.progress)
+        fprintf(stderr, "\n[odgi::path_linear_sgd_layout] a node end reached the outer quarter of the fixed-point frame: frame doubled (now %g quanta per bp)\n",
+                (double)xf.scale);
+    return PGSGD_OK;
+}
+
+// guard_hit: a kernel of the last iteration saw a coordinate in the outer quarter of the frame and the session has not
+// widened the frame yet (a sharded session leaves that to its driver: every rank has to do it in the same iteration)
+extern "C" int pgsgd_session_frame_status(const pgsgd_session* s, int* guard_hit, uint32_t* doublings) {
+    if (!s) return PGSGD_E_INVALID;
+    if (guard_hit) *guard_hit = s->fmt == pgsgd::kFmtQ32 && s->h_delta_max[1] != 0;
+    if (doublings) *doublings = s->frame_doublings;
     return PGSGD_OK;
 }
 
@@ -1080,6 +1172,10 @@ extern "C" int pgsgd_session_sync(pgsgd_session* s, double* delta_max) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     int rc = collect_events(s);
     if (rc) return rc;
+    if (s->fmt == pgsgd::kFmtQ32 && s->h_delta_max[1] && !s->d_base && s->shard_world == 1 && s->tshard_world == 1) {
+        rc = pgsgd_session_reframe(s);  // a session on its own widens its frame itself
+        if (rc) return rc;
+    }
     if (delta_max) {
         float f;
         memcpy(&f, s->h_delta_max, sizeof f);
@@ -1182,6 +1278,7 @@ extern "C" int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t
 int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);
 
 static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
+int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
 
 extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, pgsgd_stats* stats) {
     return layout_run_impl(g, p, X, Y, nullptr, nullptr, stats);
@@ -1211,6 +1308,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         int dev;  // still refuse to "succeed" without a device: the product never runs on the CPU
         return pick_device(p->device, &dev);
     }
+    if (p->n_devices > 1) return pgsgd_layout_run_multi(g, p, X, Y, Xd, Yd, stats);  // pgsgd_multi.cpp
     const auto t0 = std::chrono::steady_clock::now();
     pgsgd::PhaseTimer timer;
     pgsgd_session* s = nullptr;
@@ -1263,6 +1361,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         stats->last_delta_max = dmax;
         stats->n_streams = pgsgd_session_n_streams(s);
         stats->early_stop = early;
+        stats->frame_doublings = s->frame_doublings;
         pgsgd_session_kernel_time(s, &stats->kernel_ms, nullptr, 0);
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

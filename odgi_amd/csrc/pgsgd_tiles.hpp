@@ -18,10 +18,10 @@ namespace pgsgd {
 // ("colour"): windows of one parity are disjoint, so every window has a single owner and no two private
 // copies of a node end exist at the same time (summing the moves of several stale copies of one end
 // overshoots — reproduced for tiles in tools/tile_sim.c).  Around every launch:
-//   snapshot_kernel   streams the coordinates of every step's node into the second half of the step's
-//                     32-byte record, so that a partner outside the window costs ONE gather that brings
-//                     its handle, position, node length and both end coordinates (as they were when the
-//                     launch began);
+//   snapshot_kernel   (once per iteration) streams the coordinates of every step's node into the second half of
+//                     the step's 32-byte record, so that a partner outside the window costs ONE gather that
+//                     brings its handle, position, node length and both end coordinates (as they were when
+//                     the iteration began);
 //   sgd_tile_kernel   a workgroup takes a work item, stages the window's 4R coordinate words in LDS and
 //                     runs the item's tiles: tile records in LDS, first step uniform inside the tile (each
 //                     tile gets its exact share of the iteration's terms, so the first step is uniform
@@ -58,9 +58,18 @@ struct WorkItem {
 constexpr uint32_t kObLine = 4;                      // messages per staged line (64 bytes)
 constexpr uint32_t kObChunk = 64;                    // messages per chunk (1 KiB)
 constexpr uint32_t kObLinesPerChunk = kObChunk / kObLine;
-constexpr uint32_t kObNone = 0xffffffu;              // LDS line word (chunk << 8 | lines used): no chunk yet
-constexpr uint32_t kObOverflow = 0xfffffeu;          // the bucket's share of the pool is used up
+constexpr uint32_t kObUsedBits = 10;                 // LDS line word per bucket: (chunk << 10) | lines claimed in the chunk
+constexpr uint32_t kObUsedMask = (1u << kObUsedBits) - 1;
+constexpr uint32_t kObNone = (1u << (32 - kObUsedBits)) - 1;   // no chunk yet
+constexpr uint32_t kObOverflow = kObNone - 1;                  // the bucket's share of the pool is used up
 constexpr uint32_t kObNoLine = 0xffffffffu;
+// Partners just outside the window are the bulk of the far ones (Zipf: a third of all messages go to the bucket the
+// window lies in), so the kObRings buckets at the window get a ring of kObRingLines staged lines each instead of
+// one: a wave claims slots for all its lanes with one LDS atomic and never waits for a line to be written out unless
+// 64 claims are outstanding.  (With one line per bucket a wave whose lanes hold 19 messages for the same bucket needs
+// five claim-write-flush rounds per trip: measured, the cooling iterations ran 45 % slower than with direct atomics.)
+constexpr uint32_t kObRings = 2;        // the window's bucket and the next one (a window can straddle a bucket border)
+constexpr uint32_t kObRingLines = 32;   // 128 slots: the waves of a workgroup drift apart by a trip or two
 struct Outbox {
     uint4* pool;               // [total chunks][kObChunk] messages
     const uint32_t* chunk0;    // [B] first chunk of the bucket's share of the pool
@@ -72,6 +81,9 @@ struct Outbox {
     uint32_t n_buckets;
     uint32_t shift;            // bucket = node end >> shift
 };
+
+constexpr int kTileBlock = 256;
+constexpr int kTileWaves = kTileBlock / 64;
 
 struct TileArgs {
     const Tile* tiles;
@@ -86,15 +98,15 @@ struct TileArgs {
     // learning-rate cap of terms whose partner is outside the window: 1/h, h = far pulls per node end in the previous
     // launch of this colour (read on the device: no host round trip), or far_mu_cap_first in the first iteration
     float far_mu_cap_first;
+    float far_relax;                   // A/B knob: factor on the cap (1 = as described)
     uint32_t far_from_prev;
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
     const uint4* recs2;                // [2S] step records with the coordinate snapshot: {handle,len,pos}, {w_first, w_second}
+    uint32_t experiment;               // PGSGD_TILE_EXP (profiling only, results invalid): 1 = far updates are dropped,
+                                       // 2 = staged but never written out
     Outbox ob;
 };
-
-constexpr int kTileBlock = 256;
-constexpr int kTileWaves = kTileBlock / 64;
 
 // Every (tile, lane) pair owns a generator per iteration: lane l of the `lanes` lanes that work on a tile draws the
 // tile's terms l, l + lanes, l + 2 lanes, ... from one stream.  Which workgroup runs a tile, and when, changes nothing
@@ -117,55 +129,99 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
     if (i == n_tiles) term0[i] = n_terms;
 }
 
-// LDS of one workgroup's outbox
+// LDS of one workgroup's outbox.  Every bucket has a ring of staged lines: one line for an ordinary bucket, kObRingLines
+// for the kObRings buckets around the workgroup's current window ("hot" rings; ring index kObHot + r).  Slots are claimed
+// from a monotonic head counter: slot s lives in line (s / kObLine) % lines of the ring, round s / (kObLine * lines); a
+// lane may write it once the line is back from its previous round (gen), and the writer that completes a line
+// (done == kObLine) writes it out and reopens it.
 struct OutboxLds {
-    uint4* stage;     // [B][kObLine]
-    uint32_t* cnt;    // [B] slots claimed (low half) | slots written (high half)
-    uint32_t* line;   // [B] (chunk << 8) | lines used in the chunk
-    uint2* list;      // [waves][64] lines completed in one round of one wave: {bucket, global line index}
+    uint4* stage;     // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
+    uint32_t* head;   // [B + kObRings] slots claimed
+    uint32_t* done;   // [B + kObRings * kObRingLines] slots written, per line
+    uint32_t* gen;    // [B + kObRings * kObRingLines] rounds completed, per line
+    uint32_t* line;   // [B] (chunk << 10) | lines claimed in the chunk
+    uint32_t* chunk0; // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
+    uint2* list;      // [waves][64] lines completed in one round of one wave: {staged line, global line index}
+    uint32_t n_buckets;
+    uint32_t ring_b0; // bucket of hot ring 0 (the window's), wave-uniform
 };
 
-// the next line of bucket b in the workgroup's current chunk (a new chunk when that one is full).  Called by the one
-// lane that completed the bucket's staged line: nobody else touches line[b] until that lane reopens the bucket.
+__host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
+    const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
+    return lines * kObLine * sizeof(uint4) + (size_t)kTileWaves * 64 * sizeof(uint2) +
+           ((size_t)n_buckets + kObRings + 2 * lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
+}
+
+// The next line of bucket b in the workgroup's current chunk (a new chunk when that one is full).  Several lanes may
+// ask for lines of one bucket at once (two lines of a ring completed in the same round): lines are claimed with an LDS
+// atomic; the lane that claims line kObLinesPerChunk replaces the chunk, the others wait for it without adding to the
+// word (every lane strays at most once per replacement, so the 10-bit field cannot overflow).
 __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b) {
-    const uint32_t lp = L.line[b];
-    uint32_t chunk = lp >> 8, used = lp & 0xffu;
-    if (chunk == kObOverflow) return kObNoLine;
-    if (chunk == kObNone || used == kObLinesPerChunk) {
-        if (chunk != kObNone) ob.fill[ob.chunk0[b] + chunk] = kObChunk;  // close the full chunk
-        const uint32_t nc = atomicAdd(ob.next + b, 1u);
-        if (nc >= ob.cap[b]) {
-            L.line[b] = kObOverflow << 8;
-            return kObNoLine;
+    for (;;) {
+        const uint32_t cur = __hip_atomic_load(L.line + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((cur >> kObUsedBits) == kObOverflow) return kObNoLine;
+        if ((cur & kObUsedMask) > kObLinesPerChunk) {  // being replaced
+            __builtin_amdgcn_s_sleep(1);
+            continue;
         }
-        chunk = nc;
-        used = 0;
+        const uint32_t lp = atomicAdd(L.line + b, 1u);
+        const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;
+        if (chunk == kObOverflow) continue;  // became so between the poll and the add
+        if (used < kObLinesPerChunk) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;
+        if (used == kObLinesPerChunk) {  // this lane replaces the full chunk and takes the new one's first line
+            if (chunk != kObNone) ob.fill[L.chunk0[b] + chunk] = kObChunk;
+            const uint32_t nc = atomicAdd(ob.next + b, 1u);
+            if (nc >= ob.cap[b]) {
+                atomicExch(L.line + b, kObOverflow << kObUsedBits);
+                return kObNoLine;
+            }
+            atomicExch(L.line + b, (nc << kObUsedBits) | 1u);
+            return (L.chunk0[b] + nc) * kObLinesPerChunk;
+        }
     }
-    L.line[b] = (chunk << 8) | (used + 1);
-    return (ob.chunk0[b] + chunk) * kObLinesPerChunk + used;
 }
 
 // Append one message per lane that has one.  Called by all 64 lanes of a wave together (converged).
-__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, uint64_t delta) {
+__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, uint64_t delta, bool dry = false) {
+    if (!__ballot(has)) return;
     const uint32_t b = end >> ob.shift;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t r = b - L.ring_b0;  // hot ring of the bucket, if it has one
+    const bool hot = has && r < kObRings;
+    // claim a slot: hot rings with one LDS atomic per wave and ring, ordinary buckets with one per lane
+    uint32_t slot = 0;
+#pragma unroll
+    for (uint32_t rr = 0; rr < kObRings; ++rr) {
+        const uint64_t m = __ballot(hot && r == rr);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(L.head + L.n_buckets + rr, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (hot && r == rr) slot = base + (uint32_t)__popcll(m & below);
+        }
+    }
+    if (has && !hot) slot = atomicAdd(L.head + b, 1u);
+    const uint32_t lines = hot ? kObRingLines : 1u;
+    const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + (slot / kObLine) % lines;  // staged line of the slot
+    const uint32_t round = slot / (kObLine * lines);
     uint2* list = L.list + (threadIdx.x >> 6) * 64;
     bool pending = has;
-    while (__ballot(pending)) {
+    do {
         bool completes = false;
-        if (pending && (__hip_atomic_load(L.cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu) < kObLine) {
-            // (a bucket whose line is full is being written out by the wave that completed it: try again next round)
-            const uint32_t slot = atomicAdd(L.cnt + b, 1u) & 0xffffu;
-            if (slot < kObLine) {
-                L.stage[b * kObLine + slot] = make_uint4(end, 0u, (uint32_t)delta, (uint32_t)(delta >> 32));
-                pending = false;
-                completes = (atomicAdd(L.cnt + b, 1u << 16) >> 16) + 1 == kObLine;  // the last of the line's writers
-            }
+        // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out)
+        if (pending && __hip_atomic_load(L.gen + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == round) {
+            L.stage[src * kObLine + slot % kObLine] = make_uint4(end, 0u, (uint32_t)delta, (uint32_t)(delta >> 32));
+            pending = false;
+            completes = atomicAdd(L.done + src, 1u) + 1 == kObLine;  // the last of the line's writers writes it out
+        } else if (pending) {
+            __builtin_amdgcn_s_sleep(2);  // waiting for another wave to write a line out: leave it the issue slots
         }
         const uint64_t mask = __ballot(completes);
-        if (mask) {  // wave-uniform: write the lines completed in this round, kObLine lanes per line
-            const uint32_t dst = completes ? outbox_next_line(ob, L, b) : 0u;
-            if (completes) list[__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(b, dst);
+        if (mask) {  // wave-uniform: the lines completed in this round, kObLine lanes per line
+            const uint32_t dst = (completes && !dry) ? outbox_next_line(ob, L, b) : 0u;
+            if (completes) list[__popcll(mask & below)] = make_uint2(src, dst);
             // the wave's LDS operations execute in order; keep the compiler from moving the reads below above the writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -176,7 +232,9 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
                 if (e < n) {
                     const uint2 it = list[e];
                     const uint4 m = L.stage[it.x * kObLine + piece];
-                    if (it.y != kObNoLine) {
+                    if (dry) {
+                        asm volatile("" ::"v"(m.x), "v"(m.w));
+                    } else if (it.y != kObNoLine) {
                         ob.pool[(uint64_t)it.y * kObLine + piece] = m;
                     } else {  // no room left in the pool: the spill words, added to the coordinates by the drain
                         atomicAdd(ob.spill + m.x, (unsigned long long)m.z | ((unsigned long long)m.w << 32));
@@ -187,7 +245,55 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            if (completes) __hip_atomic_store(L.cnt + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // reopen the bucket
+            if (completes) {  // reopen the line for its next round
+                __hip_atomic_store(L.done + src, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(L.gen + src, round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    } while (__ballot(pending));
+}
+
+// Write out the partly filled line of every ring in [first, first + count) (ring index: bucket, or n_buckets + r for a
+// hot ring), padded to a whole line with messages that add zero (so every line in the pool is full and is written as
+// one 64-byte unit), and put the rings back to their initial state.  Called by the whole workgroup, between barriers,
+// when no push is in flight: four consecutive lanes per ring.
+__device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const OutboxLds& L, uint32_t first, uint32_t count) {
+    const uint32_t piece = threadIdx.x % kObLine;
+    for (uint32_t base = 0; base < count; base += blockDim.x / kObLine) {
+        const uint32_t i = base + threadIdx.x / kObLine;
+        uint32_t n = 0, b = 0, src = 0;
+        if (i < count) {
+            const uint32_t ring = first + i, head = L.head[ring];
+            const bool hot = ring >= L.n_buckets;
+            b = hot ? L.ring_b0 + (ring - L.n_buckets) : ring;
+            n = head % kObLine;  // every full line went out when its last writer finished
+            src = hot ? L.n_buckets + (ring - L.n_buckets) * kObRingLines + (head / kObLine) % kObRingLines : ring;
+        }
+        uint32_t dst = 0;
+        if (n && piece == 0) dst = outbox_next_line(ob, L, b);
+        dst = __shfl(dst, (int)((threadIdx.x & 63u) & ~(kObLine - 1u)));
+        if (n) {
+            const uint4 m = piece < n ? L.stage[src * kObLine + piece] : make_uint4(b << ob.shift, 0u, 0u, 0u);
+            if (dst != kObNoLine) {
+                ob.pool[(uint64_t)dst * kObLine + piece] = m;
+            } else if (piece < n) {
+                atomicAdd(ob.spill + m.x, (unsigned long long)m.z | ((unsigned long long)m.w << 32));
+                atomicAdd(ob.overflow, 1ull);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const uint32_t ring = first + i;
+        L.head[ring] = 0;
+        if (ring < L.n_buckets) {
+            L.done[ring] = 0;
+            L.gen[ring] = 0;
+        } else {
+            for (uint32_t l = 0; l < kObRingLines; ++l) {
+                L.done[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
+                L.gen[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
+            }
         }
     }
 }
@@ -201,35 +307,89 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
 //                  reference's rule, never the default.
 constexpr int kFarTwoSided = 0, kFarExclusive = 2;
 
+// What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has
+// fewer than 2^32 path steps), and of the Zipf constants only the ones zipf_tabled reads are carried.  Fewer scalar
+// registers in the hot loop (the full DevConst + TileArgs do not fit the SGPR file and were spilled around the loop).
+struct TileSampler {
+    const double2* zeta_denom;
+    uint32_t space, space_max, space_quant;
+    int omt_e, alpha_e;
+    double omt_frac, alpha_frac, one_plus_half_pow;
+};
+
+// uniform_below for a range below 2^32: the same Lemire draw as pgsgd_math.hpp (same draws, same result), with the
+// 64 x 32-bit products written out
+__device__ __forceinline__ uint32_t uniform_below32(Xoshiro256Plus& g, uint32_t range) {
+    uint64_t x = g.next();
+    uint64_t low = x * range;
+    if (low < range) {
+        const uint64_t threshold = (0 - (uint64_t)range) % range;
+        while (low < threshold) {
+            x = g.next();
+            low = x * range;
+        }
+    }
+    return (uint32_t)(((x >> 32) * range + (((x & 0xffffffffull) * range) >> 32)) >> 32);
+}
+
+// dirty-Zipf draw of zipf_tabled() from the trimmed constants: the same operations in the same order
+__device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampler& ts, uint32_t n, double zeta_n, double denom) {
+    const double eta = (1.0 - pow_split(2.0 / (double)n, ts.omt_e, ts.omt_frac)) / denom;
+    const double u = canonical(g);
+    const double uz = u * zeta_n;
+    if (uz < 1.0) return 1;
+    if (uz < ts.one_plus_half_pow) return 2;
+    const double v = 1.0 + (double)n * pow_split(eta * u - eta + 1.0, ts.alpha_e, ts.alpha_frac);
+    uint64_t r = (v >= 1.0 && v < 1.8446744073709552e19) ? (uint64_t)v : 1;
+    if (r < 1) r = 1;
+    if (r > n) r = n;
+    return (uint32_t)r;
+}
+
 // a term whose first step and partner are drawn and whose partner record is on its way
 struct PendingTerm {
-    Anchor an;
-    PartnerDraw d;
-    uint4 rb;    // partner record {handle, len, pos}
-    uint4 snap;  // its coordinate snapshot {w_first, w_second} when the record came from global memory
+    uint4 ra;    // first step's record {handle, len, pos}
+    uint4 rb;    // partner's record
+    uint4 snap;  // the partner's coordinate snapshot {w_first, w_second} when its record came from global memory
+    uint32_t flips;   // bit 0: far end of the first step's node, bit 1: of the partner's
+    uint32_t dither;
     bool valid, from_global;
 };
 
-template <int COORD_LOAD, int FAR>
-__global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileArgs ta, IterArgs a) {
+// COOLING: the launch's iteration is a cooling one (every partner by Zipf) — known per launch, so the coin and the
+// uniform-partner branch are compiled out.  LOCAL: the work items have a window (the usual case); window-less items
+// (tiles of unsorted stretches) run in their own launch with every end read from global memory and every update sent
+// through the outbox.
+template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL>
+__global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
     uint4* trec = reinterpret_cast<uint4*>(lds + 4 * (size_t)ta.region);         // [T] tile records
     OutboxLds L;
-    L.stage = trec + ta.tile_steps;                                              // [B][kObLine]
-    L.cnt = reinterpret_cast<uint32_t*>(L.stage + (size_t)ta.ob.n_buckets * kObLine);
-    L.line = L.cnt + ta.ob.n_buckets;
-    L.list = reinterpret_cast<uint2*>(L.line + ta.ob.n_buckets + (ta.ob.n_buckets & 1u));  // 8-byte aligned
+    L.n_buckets = ta.ob.n_buckets;
+    {
+        const size_t lines = (size_t)L.n_buckets + kObRings * kObRingLines;
+        L.stage = trec + ta.tile_steps;
+        L.list = reinterpret_cast<uint2*>(L.stage + lines * kObLine);
+        L.head = reinterpret_cast<uint32_t*>(L.list + kTileWaves * 64);
+        L.done = L.head + L.n_buckets + kObRings;
+        L.gen = L.done + lines;
+        L.line = L.gen + lines;
+        L.chunk0 = L.line + L.n_buckets;
+        for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + 2 * lines; i += blockDim.x) L.head[i] = 0;
+    }
+    L.ring_b0 = 0x7fffffffu;
     __shared__ uint32_t s_item;
-    for (uint32_t b = threadIdx.x; b < ta.ob.n_buckets; b += blockDim.x) {
-        L.cnt[b] = 0;
-        L.line[b] = kObNone << 8;
+    for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
+        L.line[b] = (kObNone << kObUsedBits) | kObLinesPerChunk;
+        L.chunk0[b] = ta.ob.chunk0[b];
     }
     float dmax = 0.0f;
     uint32_t n_far = 0;
+    bool guard = false;  // a coordinate in the outer quarter of the fixed-point frame was seen (in_frame_guard)
     const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
     const uint32_t win_words = 4 * ta.region;
-    // A partner outside the window is read as it was when this launch began, and what the term adds to it reaches
+    // A partner outside the window is read as it was when the iteration began, and what the term adds to it reaches
     // its owner after the launch: all the far pulls an end receives during one launch are computed against one stale
     // position and land together.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
     // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = 1/h, h = far
@@ -240,16 +400,18 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
         const double h = (double)*ta.far_prev / (double)n_ends;
         far_mu_cap = h > 1.0 ? (float)(1.0 / h) : 1.0f;
     }
+    if (ta.far_relax != 1.0f) far_mu_cap = fminf(1.0f, far_mu_cap * ta.far_relax);
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ta.queue, 1u);
         __syncthreads();
         const uint32_t item = s_item * ta.shard_world + ta.shard_rank;
         if (item >= ta.n_items) break;
         const WorkItem wi = ta.items[item];
-        const uint64_t wbase = 2 * (uint64_t)wi.win0;  // first coordinate word of the window
-        if (wi.local) {
+        const uint32_t wbase = 2 * wi.win0;  // first coordinate word of the window
+        if (LOCAL) {
+            L.ring_b0 = wbase >> ta.ob.shift;  // the hot rings serve the window's bucket and the next one
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
-                win[i] = wbase + i < n_ends ? load_word<COORD_LOAD>(c.coords, (uint32_t)(wbase + i)) : 0;
+                win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(c.coords, wbase + i) : 0;
         }
         for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
             if (ti % ta.n_sub != ta.sub) continue;  // block-uniform
@@ -258,8 +420,9 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = c.recs[t.t0 + i];
             __syncthreads();
             const uint64_t term_begin = ta.term0[ti], term_end = ta.term0[ti + 1];
-            const uint64_t pstart = c.path_first[t.path];
-            const uint64_t cnt = c.path_first[t.path + 1] - pstart;
+            const uint32_t t0 = (uint32_t)t.t0;
+            const uint32_t pstart = (uint32_t)c.path_first[t.path];
+            const uint32_t cnt = (uint32_t)(c.path_first[t.path + 1] - c.path_first[t.path]);
             const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
@@ -267,61 +430,76 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and one trip more
             // than the longest lane needs: every trip draws term j and finishes term j - 1, whose partner record was
             // requested one trip earlier — the gather's latency hides behind the next term's sampling arithmetic.
-            const uint64_t trips = (term_end - term_begin + lanes - 1) / lanes;
+            const uint32_t n_tile_terms = (uint32_t)(term_end - term_begin);
+            const uint32_t trips = (n_tile_terms + lanes - 1) / lanes;
             PendingTerm P;
             P.valid = false;
-            for (uint64_t j = 0; j <= trips; ++j) {
+            for (uint32_t j = 0; j <= trips; ++j) {
                 PendingTerm N;
                 N.valid = false;
-                const uint64_t q = term_begin + threadIdx.x + j * lanes;
-                if (worker && j < trips && q < term_end) {
-                    // first step: uniform inside the tile; partner: the shared sampler (path_sgd_layout.cpp:205-270)
+                if (worker && j < trips && threadIdx.x + j * lanes < n_tile_terms) {
+                    // first step: uniform inside the tile; partner by the reference's rule (path_sgd_layout.cpp:205-237), then
+                    // the two end choices (:253,262) — draw_partner() with 32-bit step indices
                     N.valid = true;
-                    N.an.k = t.t0 + uniform_below(rng, t.n);
-                    N.an.pstart = pstart;
-                    N.an.cnt = cnt;
-                    N.an.s_rank = N.an.k - pstart;
-                    N.an.rec = trec[N.an.k - t.t0];
-                    N.d = draw_partner(c, N.an, a.cooling, rng);
+                    const uint32_t ka = uniform_below32(rng, t.n);  // offset inside the tile
+                    N.ra = trec[ka];
+                    const uint32_t s_rank = t0 + ka - pstart;
+                    uint32_t b_rank;
+                    if (COOLING || coin(rng)) {
+                        const bool back = (s_rank > 0 && coin(rng)) || s_rank == cnt - 1;
+                        const uint32_t room = back ? s_rank : cnt - s_rank - 1;
+                        const uint32_t jump = ts.space < room ? ts.space : room;
+                        const double2 zd = ts.zeta_denom[jump > ts.space_max ? ts.space_max + (jump - ts.space_max) / ts.space_quant + 1 : jump];
+                        const uint32_t z = zipf_tile(rng, ts, jump, zd.x, zd.y);
+                        b_rank = back ? s_rank - z : s_rank + z;
+                    } else {
+                        b_rank = uniform_below32(rng, cnt);
+                    }
+                    const uint64_t draw_a = rng.next(), draw_b = rng.next();
+                    N.flips = (uint32_t)(draw_a >> 63) | ((uint32_t)(draw_b >> 63) << 1);
+                    N.dither = (uint32_t)draw_a;
                     // the partner's record: the tile's LDS copy when it is a step of the tile, otherwise ONE 32-byte gather
                     // that also brings the coordinates both ends of its node had when this launch began
-                    N.from_global = !(N.d.kb - t.t0 < (uint64_t)t.n);
+                    const uint32_t kb = pstart + b_rank;
+                    N.from_global = !(kb - t0 < t.n);
                     if (N.from_global) {
-                        N.rb = ta.recs2[2 * N.d.kb];
-                        N.snap = ta.recs2[2 * N.d.kb + 1];
+                        N.rb = ta.recs2[2 * (uint64_t)kb];
+                        N.snap = ta.recs2[2 * (uint64_t)kb + 1];
                     } else {
-                        N.rb = trec[N.d.kb - t.t0];
+                        N.rb = trec[kb - t0];
                     }
                 }
                 bool msg_a = false, msg_b = false;
                 uint32_t end_a = 0, end_b = 0;
                 uint64_t delta = 0;
                 if (P.valid) {
-                    const Term tm = make_term(P.an, P.d, P.rb);
-                    end_a = tm.end_a;
-                    end_b = tm.end_b;
+                    // the path position moves to the chosen end of each node (:242-269)
+                    uint64_t pos_a = (uint64_t)P.ra.z | ((uint64_t)P.ra.w << 32), pos_b = (uint64_t)P.rb.z | ((uint64_t)P.rb.w << 32);
+                    if (P.flips & 1u) pos_a += P.ra.y;
+                    if (P.flips & 2u) pos_b += P.rb.y;
+                    end_a = P.ra.x ^ (P.flips & 1u);
+                    end_b = P.rb.x ^ (P.flips >> 1);
                     // ends inside the staged window live in LDS (unsigned compare covers "below the window")
-                    const uint32_t la = end_a - (uint32_t)wbase, lb = end_b - (uint32_t)wbase;
-                    const bool in_a = wi.local && la < win_words, in_b = wi.local && lb < win_words;
+                    const uint32_t la = end_a - wbase, lb = end_b - wbase;
+                    const bool in_a = LOCAL && la < win_words, in_b = LOCAL && lb < win_words;
                     const uint64_t wa = in_a ? win[la] : load_word<COORD_LOAD>(c.coords, end_a);
                     uint64_t wb;
                     if (in_b) wb = win[lb];
                     else if (P.from_global)  // the snapshot that came with the record; w_first belongs to end `handle`
-                        wb = ((end_b ^ tm.handle_b) & 1u) ? ((uint64_t)P.snap.z | ((uint64_t)P.snap.w << 32))
-                                                           : ((uint64_t)P.snap.x | ((uint64_t)P.snap.y << 32));
+                        wb = (P.flips & 2u) ? ((uint64_t)P.snap.z | ((uint64_t)P.snap.w << 32)) : ((uint64_t)P.snap.x | ((uint64_t)P.snap.y << 32));
                     else wb = load_word<COORD_LOAD>(c.coords, end_b);  // window-less tile, partner inside the tile
                     const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                     const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
                     float r_x, r_y, abs_delta;
                     const bool one_sided = FAR == kFarExclusive && !in_b;
-                    term_displacement(a.eta, tm.pos_a, tm.pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : far_mu_cap);
+                    term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : far_mu_cap);
                     if (one_sided) {
                         r_x *= 2.0f;
                         r_y *= 2.0f;
                     }
                     dmax = fmaxf(dmax, abs_delta);
-                    const float ux = (float)(tm.dither & 0xffffu) * (1.0f / 65536.0f);
-                    const float uy = (float)(tm.dither >> 16) * (1.0f / 65536.0f);
+                    const float ux = (float)(P.dither & 0xffffu) * (1.0f / 65536.0f);
+                    const float uy = (float)(P.dither >> 16) * (1.0f / 65536.0f);
                     float fx = r_x * c.xf.scale;
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
@@ -338,53 +516,45 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         else msg_a = true;
                     }
                 }
-                outbox_push(ta.ob, L, msg_b, end_b, delta);
-                if (!wi.local) outbox_push(ta.ob, L, msg_a, end_a, 0ull - delta);  // block-uniform: window-less tiles only
+                if (ta.experiment & 1u) msg_a = msg_b = false;
+                outbox_push(ta.ob, L, msg_b, end_b, delta, (ta.experiment & 2u) != 0);
+                if (!LOCAL) outbox_push(ta.ob, L, msg_a, end_a, 0ull - delta);
                 P = N;
             }
         }
         __syncthreads();
-        if (wi.local) {  // the window's only writer since it was staged: plain, coalesced stores
+        if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
-                if (wbase + i < n_ends) c.coords[wbase + i] = win[i];
+                if ((uint64_t)wbase + i < n_ends) {
+                    c.coords[wbase + i] = win[i];
+                    guard |= in_frame_guard(win[i]);
+                }
+            // the hot rings move on with the window: write out what they hold and unbind them
+            outbox_flush_rings(ta.ob, L, L.n_buckets, kObRings);
         }
         __syncthreads();  // s_item and the window are reused
     }
-    // write out the partly filled lines (16-byte stores: few) and close the chunks this workgroup still has open
-    for (uint32_t b = threadIdx.x; b < ta.ob.n_buckets; b += blockDim.x) {
-        const uint32_t n = L.cnt[b] & 0xffffu;  // every claimed slot is written: the workgroup is past its last barrier
-        if (n) {
-            const uint32_t dst = outbox_next_line(ta.ob, L, b);
-            for (uint32_t i = 0; i < n; ++i) {
-                const uint4 m = L.stage[b * kObLine + i];
-                if (dst != kObNoLine) {
-                    ta.ob.pool[(uint64_t)dst * kObLine + i] = m;
-                } else {
-                    atomicAdd(ta.ob.spill + m.x, (unsigned long long)m.z | ((unsigned long long)m.w << 32));
-                    atomicAdd(ta.ob.overflow, 1ull);
-                }
-            }
-        }
-        const uint32_t lp = L.line[b], chunk = lp >> 8, used = lp & 0xffu;
-        if (chunk < kObOverflow) ta.ob.fill[ta.ob.chunk0[b] + chunk] = n ? (used - 1) * kObLine + n : used * kObLine;
+    // write out the partly filled lines and close the chunks this workgroup still has open
+    outbox_flush_rings(ta.ob, L, 0, L.n_buckets);
+    for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
+        const uint32_t lp = L.line[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;
+        if (chunk < kObOverflow) ta.ob.fill[ta.ob.chunk0[b] + chunk] = used * kObLine;
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
     if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(ta.far_count, (unsigned long long)n_far);
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
 }
 
-// Before every tile launch: every 32-byte step record is rewritten — the static half from the 16-byte records, the
+// Once per iteration (before the launch of the first colour): every 32-byte step record is rewritten — the static half from the 16-byte records, the
 // second half with the coordinates of the two ends of the step's node (the end the step enters first) — so that a
 // partner outside the window costs one gather, not a record gather plus a dependent coordinate load.  Whole-line
 // writes (writing only the second halves costs a read-for-ownership of every line: 0.70 against 0.47 ms at 4.7e7
-// steps, profiles/r02/microbench_r2b.jsonl).  Also resets the launch's work queue and far-pull counter.
-__global__ void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2,
-                                uint32_t* queue, unsigned long long* far_count) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *queue = 0;
-        *far_count = 0;
-    }
+// steps, profiles/r02/microbench_r2b.jsonl).  Partners outside a window are thus read as they were when the iteration
+// began, in both colours' launches (refreshing before every launch bought nothing measurable in layout quality and
+// cost another 0.6 ms per iteration at 4.7e7 steps).
+__global__ void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 r = recs[k];
         const uint4 pr = *reinterpret_cast<const uint4*>(coords + (r.x & ~1u));  // both ends of the node, 16-byte aligned
@@ -397,7 +567,7 @@ __global__ void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint6
 // node range up in LDS and moves the node ends.  Nothing else writes coordinates while it runs, so the
 // read-modify-write of a word is plain.  part_shift = log2 of the node ends one workgroup accumulates; a bucket wider
 // than that is read by several workgroups, each keeping its own part (large graphs only).
-__global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift) {
+__global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift, unsigned int* frame_flag) {
     extern __shared__ uint64_t acc[];
     const uint32_t parts = 1u << (ob.shift - part_shift);
     const uint32_t b = blockIdx.x / parts, part = blockIdx.x % parts, span = 1u << part_shift;
@@ -407,25 +577,44 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     const uint64_t n_slots = (uint64_t)(handed < cap ? handed : cap) * kObChunk;
     const uint64_t first = (uint64_t)ob.chunk0[b] * kObChunk;
     const uint64_t base = ((uint64_t)b << ob.shift) + ((uint64_t)part << part_shift);
-    for (uint64_t i = threadIdx.x; i < n_slots; i += blockDim.x) {
-        if ((uint32_t)(i % kObChunk) >= ob.fill[ob.chunk0[b] + (uint32_t)(i / kObChunk)]) continue;
-        const uint4 m = ob.pool[first + i];
-        const uint64_t off = (uint64_t)m.x - base;
-        if (off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + off), (unsigned long long)m.z | ((unsigned long long)m.w << 32));
+    // four independent message loads per lane in flight before the LDS adds (one workgroup streams ~12 MB)
+    for (uint64_t i0 = threadIdx.x; i0 < n_slots; i0 += 4ull * blockDim.x) {
+        uint4 m[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t i = i0 + (uint64_t)k * blockDim.x;
+            ok[k] = i < n_slots && (uint32_t)(i % kObChunk) < ob.fill[ob.chunk0[b] + (uint32_t)(i / kObChunk)];
+            if (ok[k]) m[k] = ob.pool[first + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const uint64_t off = (uint64_t)m[k].x - base;
+            if (off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + off), (unsigned long long)m[k].z | ((unsigned long long)m[k].w << 32));
+        }
     }
     __syncthreads();
+    bool guard = false;
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
         if (base + i >= n_ends) break;
         const uint64_t sp = ob.spill[base + i];
         if (sp) ob.spill[base + i] = 0;
-        if (acc[i] + sp != 0) coords[base + i] += acc[i] + sp;
+        if (acc[i] + sp != 0) {
+            const uint64_t w = coords[base + i] + acc[i] + sp;
+            coords[base + i] = w;
+            guard |= in_frame_guard(w);
+        }
     }
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(frame_flag, 1u);
 }
 
-// the drain is done with the chunk counters: ready for the next launch
-__global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets) {
+// the drain is done with the chunk counters; the next launch's work queues and far-pull counter start from zero
+__global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets, uint32_t* queues, unsigned long long* far_next) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_buckets) next[b] = 0;
+    if (b < 3) queues[b] = 0;
+    if (b == 0) *far_next = 0;
 }
 
 // sampler-only replay of one tile's terms (parity hook): out[(q - first_term)*4 + {0..3}] = {ka, kb, off_a, off_b};

@@ -159,9 +159,16 @@ class DistributedLayout:
                 eng.exchange_end(self._buf, self.world)
             dmax = max(dmax, eng.sync())
         if self.world > 1:
-            t = torch.tensor([dmax], dtype=torch.float64, device=self._buf.device)
+            # one MAX all-reduce carries max|Delta| and the ranks' frame-guard flags: when any rank saw a coordinate in
+            # the outer quarter of the fixed-point frame, every rank widens its frame before the next iteration
+            status = getattr(getattr(eng, "session", None), "frame_status", None)
+            hit = 1.0 if status is not None and status()[0] else 0.0
+            t = torch.tensor([dmax, hit], dtype=torch.float64, device=self._buf.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            dmax = float(t.item())
+            vals = t.tolist()
+            dmax = float(vals[0])
+            if vals[1] > 0 and status is not None:
+                eng.session.reframe()
         self.iterations_done = it + 1
         return dmax
 

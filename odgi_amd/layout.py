@@ -44,6 +44,7 @@ class LayoutParams:
     progress: bool = False
     flags: int = 0
     terms_per_anchor: int = 1
+    n_devices: int = 1   # GPUs of one node for the one-call run (C++ threads + RCCL inside the library)
 
     @classmethod
     def defaults(cls, graph: Graph, **overrides):
@@ -64,7 +65,7 @@ class LayoutParams:
         p = _lib.Params()
         for f in ("iter_max", "iter_with_max_learning_rate", "min_term_updates", "delta", "eps", "eta_max",
                   "theta", "space", "space_max", "space_quantization_step", "cooling_start", "seed",
-                  "n_streams", "stream_offset", "device", "flags", "terms_per_anchor"):
+                  "n_streams", "stream_offset", "device", "flags", "terms_per_anchor", "n_devices"):
             setattr(p, f, getattr(self, f))
         p.snapshot = 1 if self.snapshot_prefix else 0
         self._prefix_bytes = self.snapshot_prefix.encode() if self.snapshot_prefix else None
@@ -246,6 +247,17 @@ class LayoutSession:
         ms, n = C.c_double(), C.c_uint64()
         check(lib.pgsgd_session_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "kernel_time")
         return ms.value, n.value
+
+    def frame_status(self):
+        """(guard_hit, doublings): whether the last iteration saw a coordinate in the outer quarter of the fixed-point
+        frame that the session has not answered yet (sharded sessions leave the widening to their driver), and how
+        often the frame was doubled so far."""
+        hit, n = C.c_int(), C.c_uint32()
+        check(lib.pgsgd_session_frame_status(self._h, C.byref(hit), C.byref(n)), "frame_status")
+        return bool(hit.value), int(n.value)
+
+    def reframe(self):
+        check(lib.pgsgd_session_reframe(self._h), "reframe")
 
     def aux_time(self):
         """(snapshot_ms, drain_ms): time in the streaming kernels around the tile launches since the last reset."""

@@ -1127,7 +1127,7 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
     const uint32_t win_words = 4 * region;
     uint64_t* win = (uint64_t*)malloc(win_words * sizeof(uint64_t));
     uint64_t* orig = (uint64_t*)malloc(win_words * sizeof(uint64_t));
-    /* what a launch sees of node ends outside a window: their words when the launch began (snapshot_kernel); what it
+    /* what a launch sees of node ends outside a window: their words when the iteration began (snapshot_kernel); what it
      * adds to them: collected (the outbox) and applied when the launch is over (far_drain_kernel) */
     uint64_t* snap = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
     uint64_t* outbox = (uint64_t*)calloc(n_ends, sizeof(uint64_t));
@@ -1145,10 +1145,11 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
         const uint64_t epoch = iter + 1;
         float dmax = 0.0f;
         uint64_t far_count[2] = {0, 0};
+        int snap_taken = 0;
         for (int colour = 0; colour < 2; ++colour) {
             const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
             if (ib == ie) continue;
-            memcpy(snap, W, n_ends * sizeof(uint64_t));
+            if (!snap_taken) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }   /* once per iteration */
             for (uint64_t it = ib; it < ie; ++it) {
                 const uint64_t wbase = 2 * (uint64_t)win0[it];
                 if (local[it])

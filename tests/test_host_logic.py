@@ -178,7 +178,7 @@ def test_c_abi_exports_every_declared_symbol(oa):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 48 and C.sizeof(_lib.Params) == 136
+    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 56 and C.sizeof(_lib.Params) == 136
 
 
 def test_no_cpu_fallback_without_a_device(oa, graphs):
@@ -213,6 +213,12 @@ def test_cli_argument_handling(oa, tmp_path, capfd):
     assert oa.main_layout(["-i", str(bad), "-o", str(tmp_path / "x.lay")]) == 1
     assert "not optimized" in capfd.readouterr().err
     assert oa.main_layout(["-i", "graph.og", "-o", "x"]) == 1
+    capfd.readouterr()
+    # -X FILE (a serialized XP index, xp.cpp:247-324) is refused explicitly, before anything is read: no reference-held
+    # XP file exists to pin a reader of the sdsl-lite dump against
+    assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "x.lay"), "-X", str(tmp_path / "no.xp")]) == 1
+    err = capfd.readouterr().err
+    assert "-X/--path-index is not supported" in err and "Leave -X out" in err
     import torch
     if not torch.cuda.is_available():  # a valid command line still ends in a loud device error
         assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "t.lay")]) == 1

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $PWD/bench.py --cpu-seconds 0"   # the default bench command minus the CPU baseline leg
+CMD="python $PWD/bench.py --cpu-seconds 0 --steps 20 --warmup 5"   # the driver's bench command minus the CPU baseline leg
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o bench -- $CMD > "$OUT/kt.json" 2> "$OUT/kt.err")
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o bench -- $CMD > "$OUT/fetch.json" 2> "$OUT/fetch.err")
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o bench -- $CMD > "$OUT/write.json" 2> "$OUT/write.err")
