@@ -79,6 +79,11 @@ typedef struct pgsgd_graph_view {
                                            /* a term whose partner lies outside the staged window moves */
                                            /* only its first end, by twice the step; no far write;      */
                                            /* ignored on graphs with window-less tiles                  */
+#define PGSGD_FLAG_HOT_NODE_CAP      0x40u /* per-lane kernel, experiment: bound the lanes by the bulk of the nodes (2*S /  */
+                                           /* s*, nodes busier than s* carry a tenth of the steps) instead of by the       */
+                                           /* busiest one, and cap the learning rate of terms on busier nodes at 1/h.      */
+                                           /* 12x faster on a hub graph (DRB1-3123_unsorted) at +30 % stress, worse        */
+                                           /* everywhere else (profiles/r02/hotcap_per_lane_*.jsonl): never the default    */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

@@ -56,6 +56,13 @@ struct DevConst {
     uint64_t* rng;
     unsigned int* delta_max_bits;
     unsigned int* frame_flag;  // set when a coordinate is seen in the outer quarter of the fixed-point frame
+    // Concurrent terms on one node end are all computed from the same (stale) position and then added up; with mu = 1 each
+    // is a full projection, so h of them overshoot h-fold.  With L lanes in flight an end of a node that carries s of the S
+    // path steps sees h = L * s / S terms at once: terms that touch such a node are capped at mu = 1/h (together they
+    // still amount to one projection).  node_steps = path steps per node, null when no node reaches h > 1 (every large
+    // graph); hot_scale = L / S.
+    const uint32_t* node_steps;
+    float hot_scale;
     uint64_t n_steps;
     uint32_t n_paths;
     uint32_t n_streams;
@@ -223,6 +230,14 @@ __device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uin
     r_y = r * dy;
 }
 
+// learning-rate cap of a term by the expected number of concurrent terms on its busier node (DevConst::node_steps)
+__device__ __forceinline__ float hot_mu_cap(const DevConst& c, uint32_t end_a, uint32_t end_b) {
+    if (!c.node_steps) return 1.0f;
+    const uint32_t sa = c.node_steps[end_a >> 1], sb = c.node_steps[end_b >> 1];
+    const float h = c.hot_scale * (float)(sa > sb ? sa : sb);
+    return h > 1.0f ? 1.0f / h : 1.0f;
+}
+
 __device__ __forceinline__ uint64_t pack_f32(float x, float y) {
     return (uint64_t)__float_as_uint(x) | ((uint64_t)__float_as_uint(y) << 32);
 }
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
             }
             float r_x, r_y, abs_delta;
-            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta, hot_mu_cap(c, t.end_a, t.end_b));
             dmax = fmaxf(dmax, abs_delta);
             if (ABL == 1 || ABL == 4) {
                 dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
             }
             float r_x, r_y, abs_delta;
-            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta);
+            term_displacement(a.eta, t.pos_a, t.pos_b, dx, dy, r_x, r_y, abs_delta, hot_mu_cap(c, t.end_a, t.end_b));
             dmax = fmaxf(dmax, abs_delta);
             if (ABL == 1 || ABL == 4) {
                 dmax = fmaxf(dmax, fabsf(r_x) + fabsf(r_y));  // keep the arithmetic alive
@@ -610,12 +625,70 @@ __global__ void seed_streams_kernel(uint64_t* rng, uint32_t n_streams, uint64_t 
 }
 
 // SoA view -> 16-byte step records, on the device (the gather of node_len happens once, here)
+// ---- index build on the device (the reference walks its paths under OpenMP, src/cuda/layout.cu:371-410) ----
+// path steps on every node (the hot-node rule and the outbox pool shares need them) and the range check of the handles
+__global__ void node_steps_kernel(const uint32_t* step_handle, uint64_t n_steps, uint32_t n_nodes, uint32_t* node_steps, unsigned int* bad_handle) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = step_handle[k] >> 1;
+        if (r >= n_nodes) atomicOr(bad_handle, 1u);
+        else atomicAdd(node_steps + r, 1u);
+    }
+}
+
+// Per tile of consecutive path steps: lowest and highest node rank and the most visits of one node.  One wavefront per
+// tile; the tile's ranks sit in LDS and every lane counts the occurrences of its ranks (T^2 / 64 compares per lane:
+// 900 at T = 224).  out[3 * tile + {0,1,2}] = {rmin, rmax, maxmult}.
+__global__ __launch_bounds__(256) void tile_stats_kernel(const uint32_t* step_handle, const uint64_t* tile_t0, const uint32_t* tile_n, uint64_t n_tiles,
+                                                         uint32_t tile_cap, uint32_t* out) {
+    extern __shared__ uint32_t s_ranks[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* ranks = s_ranks + (size_t)wave * tile_cap;
+    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (uint64_t)gridDim.x * 4) {
+        const uint64_t t0 = tile_t0[t];
+        const uint32_t n = tile_n[t];
+        uint32_t rmin = 0xffffffffu, rmax = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t r = step_handle[t0 + i] >> 1;
+            ranks[i] = r;
+            rmin = r < rmin ? r : rmin;
+            rmax = r > rmax ? r : rmax;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t mult = 1;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t r = ranks[i];
+            uint32_t c = 0;
+            for (uint32_t j = 0; j < n; ++j) c += ranks[j] == r ? 1u : 0u;
+            mult = c > mult ? c : mult;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t a = __shfl_xor(rmin, off), b = __shfl_xor(rmax, off), m = __shfl_xor(mult, off);
+            rmin = a < rmin ? a : rmin;
+            rmax = b > rmax ? b : rmax;
+            mult = m > mult ? m : mult;
+        }
+        if (lane == 0) {
+            out[3 * t] = rmin;
+            out[3 * t + 1] = rmax;
+            out[3 * t + 2] = mult;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // recs2 (tile kernel only, may be null): 32-byte records whose first half is the same record and whose second half
 // is refreshed with the node's coordinates before every tile launch (snapshot_kernel)
-__global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len,
-                                   uint64_t n_steps, uint4* recs, uint4* recs2) {
+// bad_handle: set when a step names a node rank outside the graph (the caller's arrays are not trusted: such a step
+// would index node_len and, later, the coordinates out of bounds)
+__global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len, uint32_t n_nodes,
+                                   uint64_t n_steps, uint4* recs, uint4* recs2, unsigned int* bad_handle) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t h = step_handle[k];
+        uint32_t h = step_handle[k];
+        if ((h >> 1) >= n_nodes) {
+            atomicOr(bad_handle, 1u);
+            h = 0;
+        }
         const uint64_t pos = step_pos[k];
         const uint4 r = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
         recs[k] = r;

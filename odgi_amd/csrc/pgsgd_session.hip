@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -69,6 +70,8 @@ struct pgsgd_session {
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
     uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
     std::vector<uint64_t> ob_bucket_steps;  // path steps on the nodes of each outbox bucket (sizes the pool shares)
+    std::vector<uint32_t> node_steps;       // path steps on every node (automatic stream count only)
+    uint32_t* d_node_steps = nullptr;       // uploaded when the hot-node learning-rate cap is active
     pgsgd::Outbox ob{};                   // far-update outbox (device pointers)
     uint32_t* d_ob_chunk0 = nullptr;
     uint32_t* d_ob_cap = nullptr;
@@ -146,6 +149,37 @@ static int take_events(pgsgd_session* s, pgsgd_session::EvSet* out) {
     return PGSGD_OK;
 }
 
+// PGSGD_FLAG_HOT_NODE_CAP (experiment, off by default).  Can write conflicts on busy nodes be answered by a capped
+// learning rate instead of by fewer lanes (auto_streams)?  Measured, three seeds each, against the lane rule and the
+// CPU restatement (profiles/r02/hotcap_per_lane_*.jsonl):
+//  * every lane the GPU holds, every term capped at 1/h (h = L * steps on the node / S concurrent terms per node end):
+//    no — on the fixture graphs h is 30-80 for EVERY node, an iteration then amounts to a few projections per node end
+//    instead of hundreds, and the layouts end at stress 3.6 ... 5e4 (against 0.3 ... 0.9);
+//  * lanes bounded by the BULK of the nodes (L = 2 S / s*, nodes with more than s* steps carry a tenth of all steps),
+//    only terms on busier nodes capped — this function: a hub no longer idles the GPU (DRB1-3123_unsorted, one node
+//    with 268 of 21 882 steps: 3584 lanes instead of 128, 12x faster) but its layout is 30 % worse (0.44 vs 0.33), and
+//    where the lane count stays the same the cap alone costs 5-25 % stress (DRB1-3123 0.84 vs 0.69, chr6.C4 0.57 vs 0.53).
+// The reference's rule wants full projections on every pair; fewer lanes keep that, smaller steps do not.
+static uint32_t capped_streams(const pgsgd_session* s, int cus, int blocks_per_cu, uint64_t terms_per_launch) {
+    const uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
+    uint64_t n = std::min<uint64_t>(full, std::max<uint64_t>(terms_per_launch / 8, 256));  // at least eight terms per lane and launch
+    const uint64_t by_busiest = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
+    if (by_busiest < n && !s->node_steps.empty()) {
+        std::vector<uint32_t> v(s->node_steps);
+        std::sort(v.begin(), v.end(), std::greater<uint32_t>());
+        uint64_t acc = 0, s_star = v.front();
+        for (uint32_t c : v) {  // busiest first: stop when a tenth of the steps is covered
+            s_star = c;
+            acc += c;
+            if (10 * acc >= s->n_steps) break;
+        }
+        n = std::min<uint64_t>(n, std::max<uint64_t>(by_busiest, 2 * s->n_steps / std::max<uint64_t>(1, s_star)));
+    }
+    n = std::max<uint64_t>(64, (n / 64) * 64);
+    if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
+    return (uint32_t)n;
+}
+
 static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
     // Full residency of the update kernel, unless the graph cannot take that many concurrent terms.
     // Concurrent displacements of one node end are all computed from the same (stale) position and
@@ -205,14 +239,16 @@ static tile_kernel_t tile_kernel(int far, bool cooling = false, bool local = tru
     return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided>(cooling, local);
 }
 
-static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) {
-    struct Raw { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
-    std::vector<Raw> raw;
+struct RawTile { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
+
+// paths cut into tiles of T consecutive steps (host: one entry per tile, no pass over the steps)
+static std::vector<RawTile> cut_tiles(const pgsgd_graph_view* g, uint32_t T) {
+    std::vector<RawTile> raw;
     for (uint64_t p = 0; p < g->n_paths; ++p) {
         const uint64_t b = g->path_first[p], cnt = g->path_first[p + 1] - b;
         if (cnt <= 1) continue;  // single-step paths are never sampled (path_sgd_layout.cpp:189-192)
         for (uint64_t o = 0; o < cnt; o += T) {
-            Raw r;
+            RawTile r;
             r.t0 = b + o;
             r.n = (uint32_t)std::min<uint64_t>(T, cnt - o);
             r.path = (uint32_t)p;
@@ -222,55 +258,62 @@ static HostTiles build_tiles(const pgsgd_graph_view* g, uint32_t R, uint32_t T) 
             raw.push_back(r);
         }
     }
-    {   // rank range and the most visits of one node, per tile, on a few host threads
-        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        auto scan = [&](unsigned tid) {
-            std::vector<uint32_t> ranks;
-            for (size_t i = tid; i < raw.size(); i += nt) {
-                Raw& r = raw[i];
-                ranks.clear();
-                for (uint64_t k = r.t0; k < r.t0 + r.n; ++k) {
-                    const uint32_t rank = g->step_handle[k] >> 1;
-                    r.rmin = std::min(r.rmin, rank);
-                    r.rmax = std::max(r.rmax, rank);
-                    ranks.push_back(rank);
-                }
-                std::sort(ranks.begin(), ranks.end());
-                for (size_t a = 0, b2 = 0; a < ranks.size(); a = b2) {
-                    while (b2 < ranks.size() && ranks[b2] == ranks[a]) ++b2;
-                    r.maxmult = std::max<uint32_t>(r.maxmult, (uint32_t)(b2 - a));
-                }
-            }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
-        scan(0);
-        for (auto& t : th) t.join();
+    return raw;
+}
+
+// rank range and the most visits of one node, per tile: on the device, from the uploaded step handles
+static int device_tile_stats(hipStream_t stream, const uint32_t* d_handle, uint32_t T, std::vector<RawTile>& raw) {
+    const uint64_t n = raw.size();
+    if (!n) return PGSGD_OK;
+    std::vector<uint64_t> t0(n);
+    std::vector<uint32_t> tn(n), out(3 * n);
+    for (uint64_t i = 0; i < n; ++i) { t0[i] = raw[i].t0; tn[i] = raw[i].n; }
+    uint64_t* d_t0 = nullptr;
+    uint32_t *d_n = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_t0, n * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&d_n, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_out, 3 * n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t0, t0.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n, tn.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(pgsgd::tile_stats_kernel, dim3(grid), dim3(256), 4 * (size_t)T * sizeof(uint32_t), stream, d_handle, d_t0, d_n, n, T, d_out);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, 3 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_t0);
+    (void)hipFree(d_n);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error("tile statistics on the device: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
+    for (uint64_t i = 0; i < n; ++i) { raw[i].rmin = out[3 * i]; raw[i].rmax = out[3 * i + 1]; raw[i].maxmult = out[3 * i + 2]; }
+    return PGSGD_OK;
+}
+
+// bind tiles to region windows and order the work (host: linear in the number of tiles)
+static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, uint32_t R) {
     // local tiles grouped by (colour, region of rmin); a tile that does not fit two regions is its own global item
-    struct Group { uint32_t r0; uint64_t steps; std::vector<uint32_t> members; };
+    struct Group { uint32_t r0 = 0; uint64_t steps = 0; std::vector<uint32_t> members; };
     std::vector<Group> groups[2];
     std::vector<uint32_t> nonlocal;
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> key;  // (r0, raw index)
+    {   // one bucket per region, tiles in input order inside it (a stable counting sort by region)
+        const uint64_t n_regions = (n_nodes + R - 1) / R;
+        std::vector<Group> by_region(n_regions);
         for (uint32_t i = 0; i < raw.size(); ++i) {
             const uint32_t r0 = raw[i].rmin / R;
-            if ((uint64_t)raw[i].rmax < ((uint64_t)r0 + 2) * R) key.emplace_back(r0, i);
-            else nonlocal.push_back(i);
-        }
-        std::sort(key.begin(), key.end());
-        for (size_t i = 0; i < key.size();) {
-            Group gr;
-            gr.r0 = key[i].first;
-            gr.steps = 0;
-            size_t j = i;
-            for (; j < key.size() && key[j].first == gr.r0; ++j) {
-                gr.members.push_back(key[j].second);
-                gr.steps += raw[key[j].second].n;
+            if ((uint64_t)raw[i].rmax < ((uint64_t)r0 + 2) * R) {
+                Group& gr = by_region[r0];
+                gr.members.push_back(i);
+                gr.steps += raw[i].n;
+            } else {
+                nonlocal.push_back(i);
             }
-            groups[gr.r0 & 1u].push_back(std::move(gr));
-            i = j;
         }
+        for (uint64_t r0 = 0; r0 < n_regions; ++r0)
+            if (!by_region[r0].members.empty()) {
+                by_region[r0].r0 = (uint32_t)r0;
+                groups[r0 & 1u].push_back(std::move(by_region[r0]));
+            }
     }
     HostTiles ht;
     ht.n_nonlocal = nonlocal.size();
@@ -357,6 +400,8 @@ static double check_pairs_stress(const pgsgd_session* s, const float* X, const f
     return sum / (double)s->check_pairs.size();
 }
 
+static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts);
+
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
     pgsgd::clear_error();
     if (!out || !p) return PGSGD_E_INVALID;
@@ -364,6 +409,12 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     int rc = pgsgd_validate_view(g);
     if (rc) return rc;
     if (g->n_steps == 0 || g->n_paths == 0) { set_error("graph has no path steps"); return PGSGD_E_INVALID; }
+    {   // path_sgd_layout.cpp:64-74: nothing can be sampled unless some path has more than one step (the sampler would
+        // draw first steps for ever, :182-192)
+        bool multi = false;
+        for (uint64_t i = 0; i < g->n_paths && !multi; ++i) multi = g->path_first[i + 1] - g->path_first[i] > 1;
+        if (!multi) { set_error("no path has more than one step: there is no term to sample"); return PGSGD_E_INVALID; }
+    }
     if (p->space == 0 || p->space_quantization_step == 0 || !(p->theta < 1.0) || p->iter_max == 0) {
         set_error("invalid SGD parameters (space, quantization step, theta < 1, iter_max)");
         return PGSGD_E_INVALID;
@@ -385,47 +436,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const uint64_t e = g->path_first[i + 1];
         if (e > g->path_first[i]) {
             const uint64_t last = e - 1;
+            if ((g->step_handle[last] >> 1) >= g->n_nodes) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
             s->max_path_bp = std::max(s->max_path_bp, g->step_pos[last] + g->node_len[g->step_handle[last] >> 1]);
         }
     }
-    if (!p->n_streams) {  // only the automatic stream count needs the hottest node
-        const unsigned nt = g->n_steps > (1u << 22) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<std::vector<uint32_t>> per_node(nt, std::vector<uint32_t>(g->n_nodes, 0));
-        std::vector<int> bad(nt, 0);
-        auto count = [&](unsigned tid) {
-            const uint64_t b = g->n_steps * tid / nt, e = g->n_steps * (tid + 1) / nt;
-            uint32_t* c = per_node[tid].data();
-            for (uint64_t k = b; k < e; ++k) {
-                const uint32_t r = g->step_handle[k] >> 1;
-                if (r >= g->n_nodes) { bad[tid] = 1; return; }
-                c[r]++;
-            }
-        };
-        {
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; ++t) th.emplace_back(count, t);
-            count(0);
-            for (auto& t : th) t.join();
-        }
-        for (unsigned t = 0; t < nt; ++t)
-            if (bad[t]) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
-        // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
-        // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
-        // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (DESIGN.md: a second bucketing pass is the fix).
-        uint32_t ob_shift = 13;
-        while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
-        s->ob.shift = ob_shift;
-        s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
-        s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
-        s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
-        for (uint64_t i = 0; i < g->n_nodes; ++i) {
-            uint64_t v = 0;
-            for (unsigned t = 0; t < nt; ++t) v += per_node[t][i];
-            s->max_node_steps = std::max(s->max_node_steps, v);
-            s->ob_bucket_steps[(2 * i) >> ob_shift] += v;
-        }
-    }
-    timer.lap("hottest node (host)");
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
         return code;
@@ -440,6 +454,48 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     s->own_stream = true;
+    // The index is built on the device from the uploaded arrays: the step handles go up first, the
+    // per-node step counts (hot-node rule, outbox pool shares, range check of the handles) and the per-tile rank
+    // ranges come from kernels over them; the host only cuts paths into tiles and groups tiles by region, both linear
+    // in the number of TILES.
+    uint32_t* d_handle = nullptr;
+    S_TRY(hipMalloc(&d_handle, g->n_steps * sizeof(uint32_t)));
+    struct HandleGuard { uint32_t*& p; ~HandleGuard() { if (p) (void)hipFree(p); } } handle_guard{d_handle};
+    S_TRY(hipMemcpyAsync(d_handle, g->step_handle, g->n_steps * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    {
+        uint32_t* d_counts = nullptr;
+        unsigned int* d_bad = nullptr;
+        unsigned int h_bad = 0;
+        S_TRY(hipMalloc(&d_counts, g->n_nodes * sizeof(uint32_t)));
+        S_TRY(hipMalloc(&d_bad, sizeof(unsigned int)));
+        S_TRY(hipMemsetAsync(d_counts, 0, g->n_nodes * sizeof(uint32_t), s->stream));
+        S_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s->stream));
+        const int grid = (int)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(pgsgd::node_steps_kernel, dim3(grid), dim3(256), 0, s->stream, d_handle, g->n_steps, (uint32_t)g->n_nodes, d_counts, d_bad);
+        S_TRY(hipGetLastError());
+        s->node_steps.resize(g->n_nodes);
+        S_TRY(hipMemcpyAsync(s->node_steps.data(), d_counts, g->n_nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        S_TRY(hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        S_TRY(hipStreamSynchronize(s->stream));
+        (void)hipFree(d_counts);
+        (void)hipFree(d_bad);
+        if (h_bad) { set_error("a step names a node rank outside the graph"); return fail(PGSGD_E_INVALID); }
+        // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
+        // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
+        // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (DESIGN.md: a second bucketing pass is the fix).
+        uint32_t ob_shift = 13;
+        while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
+        s->ob.shift = ob_shift;
+        s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
+        s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
+        s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
+        for (uint64_t i = 0; i < g->n_nodes; ++i) {
+            const uint64_t v = s->node_steps[i];
+            s->max_node_steps = std::max(s->max_node_steps, v);
+            s->ob_bucket_steps[(2 * i) >> ob_shift] += v;
+        }
+    }
+    timer.lap("step handles up, steps per node (device)");
     hipDeviceProp_t prop;
     S_TRY(hipGetDeviceProperties(&prop, dev));
 
@@ -454,7 +510,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         iter_kernel_t k = select_kernel(s->pf_lds, false, s->fmt, s->upd, p->terms_per_anchor > 1, 0);
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k, pgsgd::kBlock, s->lds_bytes));
         if (bpc < 1) bpc = 1;
-        s->n_streams = auto_streams(s, prop.multiProcessorCount, bpc);
+        s->n_streams = (p->flags & PGSGD_FLAG_HOT_NODE_CAP) ? capped_streams(s, prop.multiProcessorCount, bpc, p->min_term_updates)
+                                                            : auto_streams(s, prop.multiProcessorCount, bpc);
     }
 
     // region-exclusive tiles: with the default coordinate format, update mode and term stream, an
@@ -496,13 +553,16 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool force = getenv("PGSGD_TILE_FORCE") != nullptr;
         if ((force || cap >= 4 * cu_lanes) && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
-            HostTiles ht = build_tiles(g, s->region, s->tile_steps);
+            std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
+            rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
+            if (rc) return fail(rc);
+            HostTiles ht = group_tiles(raw, g->n_nodes, s->region);
             if (const char* e = getenv("PGSGD_TILE_LANES")) {
                 const long l = atol(e);
                 if (l >= 1)
                     for (pgsgd::Tile& t : ht.tiles) t.lanes = std::min<uint32_t>(t.lanes, (uint32_t)l);
             }
-            timer.lap("tile table (host)");
+            timer.lap("tile table (device statistics, host grouping)");
             if ((p->flags & PGSGD_FLAG_ONE_SIDED_FAR) && !ht.n_nonlocal) {
                 // experiment, not the reference's rule: a far term moves only its first end, by twice the step.
                 // Ignored on graphs with window-less tiles.
@@ -560,21 +620,31 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     timer.lap("stream, occupancy, tile upload");
     // step records: upload the SoA arrays, pack on the device, drop the staging copies
     {
-        uint32_t *d_handle = nullptr, *d_len = nullptr;
+        uint32_t* d_len = nullptr;
         uint64_t* d_pos = nullptr;
         S_TRY(hipMalloc(&s->d_recs, g->n_steps * sizeof(uint4)));
         if (s->tiled) S_TRY(hipMalloc(&s->d_recs2, 2 * g->n_steps * sizeof(uint4)));
-        S_TRY(hipMalloc(&d_handle, g->n_steps * sizeof(uint32_t)));
         S_TRY(hipMalloc(&d_pos, g->n_steps * sizeof(uint64_t)));
         S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
-        S_TRY(hipMemcpyAsync(d_handle, g->step_handle, g->n_steps * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
         S_TRY(hipMemcpyAsync(d_len, g->node_len, g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         const int grid = (int)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 8);
-        hipLaunchKernelGGL(pgsgd::build_step_records, dim3(grid), dim3(256), 0, s->stream, d_handle, d_pos, d_len, g->n_steps, s->d_recs, s->d_recs2);
+        unsigned int* d_bad = nullptr;
+        unsigned int h_bad = 0;
+        S_TRY(hipMalloc(&d_bad, sizeof(unsigned int)));
+        S_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s->stream));
+        hipLaunchKernelGGL(pgsgd::build_step_records, dim3(grid), dim3(256), 0, s->stream, d_handle, d_pos, d_len, (uint32_t)g->n_nodes, g->n_steps,
+                           s->d_recs, s->d_recs2, d_bad);
         S_TRY(hipGetLastError());
+        S_TRY(hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
         S_TRY(hipStreamSynchronize(s->stream));
-        (void)hipFree(d_handle);
+        (void)hipFree(d_bad);
+        if (h_bad) {
+            (void)hipFree(d_pos);
+            (void)hipFree(d_len);
+            set_error("a step names a node rank outside the graph");
+            return fail(PGSGD_E_INVALID);
+        }
         (void)hipFree(d_pos);
         (void)hipFree(d_len);
     }
@@ -628,9 +698,22 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.terms_per_anchor = p->terms_per_anchor ? p->terms_per_anchor : 1;
     c.seed_base = p->seed + (uint64_t)p->stream_offset;
     c.zc.init(p->theta);
+    c.node_steps = nullptr;
+    c.hot_scale = (float)((double)s->n_streams / (double)g->n_steps);
+    if (!p->n_streams && (p->flags & PGSGD_FLAG_HOT_NODE_CAP) && (double)s->n_streams * (double)s->max_node_steps > (double)g->n_steps) {
+        // some node sees more than one concurrent term: cap the learning rate of the terms that touch busy nodes
+        S_TRY(hipMalloc(&s->d_node_steps, g->n_nodes * sizeof(uint32_t)));
+        S_TRY(hipMemcpy(s->d_node_steps, s->node_steps.data(), g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c.node_steps = s->d_node_steps;
+    }
     c.xf.x_off = c.xf.y_off = 0.0;
     c.xf.scale = c.xf.inv_scale = 1.0f;
     timer.lap("tables, streams");
+    if (s->tiled && p->min_term_updates) {  // the message pool for iterations of the default length (grown later if a call asks for more)
+        rc = ensure_outbox(s, p->min_term_updates, 1);
+        if (rc) return fail(rc);
+        timer.lap("far-update message pool");
+    }
     *out = s;
     return PGSGD_OK;
 #undef S_TRY
@@ -646,6 +729,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_path_first) (void)hipFree(s->d_path_first);
     if (s->d_zetas) (void)hipFree(s->d_zetas);
     if (s->d_zeta_denom) (void)hipFree(s->d_zeta_denom);
+    if (s->d_node_steps) (void)hipFree(s->d_node_steps);
     if (s->d_coords) (void)hipFree(s->d_coords);
     if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_rng) (void)hipFree(s->d_rng);
@@ -1043,8 +1127,6 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.shard_world = s->shard_world;
             // the far-pull count of this colour's previous launch stays on the device: no host round trip
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
-            static const double far_relax = getenv("PGSGD_FAR_RELAX") ? atof(getenv("PGSGD_FAR_RELAX")) : 1.0;  // A/B knob
-            ta.far_relax = (float)far_relax;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
@@ -1066,8 +1148,11 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
             ta.n_items = s->n_items[colour] - windowless;
             HIP_TRY(hipEventRecord(ev.e[2], s->stream));
-            static const bool snapshot_per_launch = getenv("PGSGD_SNAPSHOT_PER_LAUNCH") != nullptr;  // A/B knob
-            if (!snapshot_taken || snapshot_per_launch) {  // once per call: partners outside a window are read as they were when the iteration began
+            // Partners outside a window are read from a snapshot of the coordinates: taken before every launch while the
+            // learning rate is at its cap for most pairs (the iterations before cooling, where a colour's launch moves
+            // node ends far), once per call in the cooling iterations (where it makes no measurable difference and the
+            // refresh is 0.6 ms at 4.7e7 steps).  profiles/r02/curves_far_policy.jsonl
+            if (!snapshot_taken || !cooling) {
                 hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
                 HIP_TRY(hipGetLastError());
                 snapshot_taken = true;
@@ -1407,6 +1492,7 @@ extern "C" int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_param
 static int sort_session(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** s) {
     pgsgd_params q = *p;
     q.flags |= PGSGD_FLAG_NO_TILES;  // the 1D path has a per-lane kernel only
+    q.flags &= ~PGSGD_FLAG_HOT_NODE_CAP;
     q.terms_per_anchor = 1;
     q.snapshot = 0;
     return pgsgd_session_create(g, &q, s);

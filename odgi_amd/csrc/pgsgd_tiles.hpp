@@ -18,10 +18,10 @@ namespace pgsgd {
 // ("colour"): windows of one parity are disjoint, so every window has a single owner and no two private
 // copies of a node end exist at the same time (summing the moves of several stale copies of one end
 // overshoots — reproduced for tiles in tools/tile_sim.c).  Around every launch:
-//   snapshot_kernel   (once per iteration) streams the coordinates of every step's node into the second half of
-//                     the step's 32-byte record, so that a partner outside the window costs ONE gather that
-//                     brings its handle, position, node length and both end coordinates (as they were when
-//                     the iteration began);
+//   snapshot_kernel   streams the coordinates of every step's node into the second half of the step's 32-byte
+//                     record, so that a partner outside the window costs ONE gather that brings its handle,
+//                     position, node length and both end coordinates (as they were at the snapshot: before
+//                     every launch of a warm iteration, before the first launch of a cooling one);
 //   sgd_tile_kernel   a workgroup takes a work item, stages the window's 4R coordinate words in LDS and
 //                     runs the item's tiles: tile records in LDS, first step uniform inside the tile (each
 //                     tile gets its exact share of the iteration's terms, so the first step is uniform
@@ -98,7 +98,6 @@ struct TileArgs {
     // learning-rate cap of terms whose partner is outside the window: 1/h, h = far pulls per node end in the previous
     // launch of this colour (read on the device: no host round trip), or far_mu_cap_first in the first iteration
     float far_mu_cap_first;
-    float far_relax;                   // A/B knob: factor on the cap (1 = as described)
     uint32_t far_from_prev;
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
@@ -306,6 +305,7 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
 //                  iteration.  Measured (profiles/r01/one_sided_far_experiment.jsonl): stress +1..9 %; not the
 //                  reference's rule, never the default.
 constexpr int kFarTwoSided = 0, kFarExclusive = 2;
+constexpr float kFarRelax = 0.5f;
 
 // What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has
 // fewer than 2^32 path steps), and of the Zipf constants only the ones zipf_tabled reads are carried.  Fewer scalar
@@ -389,18 +389,19 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     bool guard = false;  // a coordinate in the outer quarter of the fixed-point frame was seen (in_frame_guard)
     const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
     const uint32_t win_words = 4 * ta.region;
-    // A partner outside the window is read as it was when the iteration began, and what the term adds to it reaches
-    // its owner after the launch: all the far pulls an end receives during one launch are computed against one stale
-    // position and land together.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
-    // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = 1/h, h = far
-    // pulls per node end in the previous launch of this colour: together they still amount to one projection.
-    // Inactive once eta/d < 1/h.
+    // A partner outside the window is read from the last snapshot, and what the term adds to it reaches its owner
+    // after the launch: all the far pulls an end receives during one launch are computed against one stale position
+    // and land together — a Jacobi step.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
+    // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = kFarRelax / h,
+    // h = far pulls per node end in the previous launch of this colour: together they amount to half a projection,
+    // the usual under-relaxation of a Jacobi step (measured against 1 and 1/4: profiles/r02/curves_far_policy.jsonl).
+    // Inactive once eta/d < kFarRelax / h.
     float far_mu_cap = ta.far_mu_cap_first;
     if (ta.far_from_prev) {
         const double h = (double)*ta.far_prev / (double)n_ends;
         far_mu_cap = h > 1.0 ? (float)(1.0 / h) : 1.0f;
     }
-    if (ta.far_relax != 1.0f) far_mu_cap = fminf(1.0f, far_mu_cap * ta.far_relax);
+    far_mu_cap *= kFarRelax;
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ta.queue, 1u);
         __syncthreads();
@@ -547,13 +548,11 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
 }
 
-// Once per iteration (before the launch of the first colour): every 32-byte step record is rewritten — the static half from the 16-byte records, the
+// Before a tile launch (every launch of a warm iteration, the first launch of a cooling one): every 32-byte step record is rewritten — the static half from the 16-byte records, the
 // second half with the coordinates of the two ends of the step's node (the end the step enters first) — so that a
 // partner outside the window costs one gather, not a record gather plus a dependent coordinate load.  Whole-line
 // writes (writing only the second halves costs a read-for-ownership of every line: 0.70 against 0.47 ms at 4.7e7
-// steps, profiles/r02/microbench_r2b.jsonl).  Partners outside a window are thus read as they were when the iteration
-// began, in both colours' launches (refreshing before every launch bought nothing measurable in layout quality and
-// cost another 0.6 ms per iteration at 4.7e7 steps).
+// steps, profiles/r02/microbench_r2b.jsonl).
 __global__ void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 r = recs[k];

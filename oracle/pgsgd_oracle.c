@@ -1149,7 +1149,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
         for (int colour = 0; colour < 2; ++colour) {
             const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
             if (ib == ie) continue;
-            if (!snap_taken) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }   /* once per iteration */
+            /* snapshot before every launch of a warm iteration, before the first launch of a cooling one */
+            if (!snap_taken || !cooling) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }
             for (uint64_t it = ib; it < ie; ++it) {
                 const uint64_t wbase = 2 * (uint64_t)win0[it];
                 if (local[it])
@@ -1184,7 +1185,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
                         const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
                         float r_x, r_y;
-                        const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, in_b ? 1.0f : far_cap[colour], &r_x, &r_y);
+                        /* far pulls are capped at kFarRelax / h: half a projection per launch in total (pgsgd_tiles.hpp) */
+                        const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, in_b ? 1.0f : far_cap[colour] * 0.5f, &r_x, &r_y);
                         if (da > dmax) dmax = da;
                         const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
                         const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);

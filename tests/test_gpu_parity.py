@@ -119,6 +119,20 @@ def test_single_step_and_ragged_paths(oa, orc, tmp_path):
 _FRAME_DOUBLINGS = [0]   # of the last _run_session: a widened frame re-quantises every word (checksums then differ)
 
 
+def test_session_refuses_step_handles_outside_the_graph(oa, graphs):
+    """The caller's arrays are not trusted: a step that names a node rank >= n_nodes would index node lengths and
+    coordinates out of bounds.  Checked on the device while the step records are built, whatever the stream count."""
+    from odgi_amd import _lib
+    g = graphs("DRB1-3123")
+    bad = g.step_handle.copy()
+    bad[1234] = 2 * g.n_nodes + 1
+    gb = oa.Graph.from_arrays(g.node_len, g.path_first, bad, step_pos=g.step_pos, step_path=g.step_path)
+    for n_streams in (0, 256):
+        with pytest.raises(_lib.PgsgdError) as e:
+            oa.LayoutSession(gb, _params(oa, g, n_streams=n_streams))
+        assert e.value.code == _lib.E_INVALID and "outside the graph" in str(e.value)
+
+
 def _run_session(oa, g, p, X0, Y0):
     etas = oa.path_linear_sgd_layout_schedule(p)
     with oa.LayoutSession(g, p) as s:
@@ -434,12 +448,23 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
     What is compared, and why.  In the iterations before cooling the reference projects every sampled pair fully
     (mu = 1 at every distance): from the `-N d` layout (stress ~5e3) its layout first gets WORSE (1.3e4 after
     iterations 1-10) and collapses only when the learning rate falls below the pair distances (iteration 15: ~1e2,
-    20: ~0.8, 30: 0.21).  The per-lane kernel is that rule term by term and must follow the curve at every point.
-    The tile kernel caps the learning rate of terms whose partner lies outside the window (pgsgd_tiles.hpp), which acts
-    exactly in that phase: its transient is milder by design, so there it is held to "not worse than the reference";
-    from iteration 20 on, where the cap is inactive, it must agree with the reference like the per-lane kernel.
+    20: ~0.8, 30: 0.21).  The per-lane kernel is that rule term by term and must follow the curve at every point
+    (measured: within 4 % everywhere).
+    The tile kernel treats pairs whose partner lies outside the window differently in exactly that phase: it reads the
+    partner from a snapshot, delivers its pull after the launch (a Jacobi step) and caps the learning rate of such
+    terms so that the pulls of one launch amount to half a projection (pgsgd_tiles.hpp).  Its transient therefore
+    differs by design — measured, 3 seeds, same evaluator (profiles/r02/curves_far_policy.jsonl):
+        iteration      1        5       10      15      20      30
+        reference     1.28e4   1.28e4  1.27e4  105     0.80    0.213
+        tile kernel   ~8e5     ~1e3    ~33     ~32     ~0.78   ~0.215
+    after the FIRST iteration the pulls delivered last leave neighbours up to ~1e4 bp apart (stress 60x the reference's),
+    from iteration ~4 on the windows' local terms have restored the local structure and the layout is 10-400x closer to
+    the path distances than the reference's, and from iteration 20 on — where the cap is inactive — both are the same
+    layout.  Asserted: the first-iteration excursion stays below 150x the reference, iterations 5-15 are not worse than
+    the reference, and iterations 20 and 30 agree within the band.
     Bands: the three CPU runs scatter by `spread` = (max - min) / mean at each point (written into the assertion
-    message); a GPU mean must be within max(10 %, 2 x spread) of the CPU mean where agreement is required."""
+    message; 0.4 % at iteration 30, 7 % at iteration 1); a GPU mean must be within max(10 %, 2 x spread) of the CPU mean
+    where agreement is required."""
     import dataclasses
     import json
     from odgi_amd import _lib
@@ -473,16 +498,20 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
     for k, it in enumerate(snap):
         band = 1.0 + max(0.10, 2.0 * spread[k])
         msg = f"iteration {it}: cpu {cpu_mean[k]:.4g} (spread {spread[k]:.2g}) per-lane {lane[k]:.4g} tile {tile[k]:.4g} band {band:.2f}"
-        assert lane[k] <= band * cpu_mean[k] and lane[k] >= cpu_mean[k] / band / (3.0 if it < 20 else 1.0), msg
-        assert tile[k] <= band * cpu_mean[k], msg                    # never worse than the reference's rule
+        assert cpu_mean[k] / band <= lane[k] <= band * cpu_mean[k], msg    # the reference's rule, term by term
         if it >= 20:
-            assert tile[k] >= cpu_mean[k] / band, msg                # and the same layout once the cap is inactive
+            assert cpu_mean[k] / band <= tile[k] <= band * cpu_mean[k], msg  # the same layout once the cap is inactive
+        elif it >= 5:
+            assert tile[k] <= band * cpu_mean[k], msg                    # milder transient, never worse
+        else:
+            assert tile[k] <= 150.0 * cpu_mean[k], msg                   # the first iteration's excursion (see above)
 
 
 def test_config5_size_properties(oa, tmp_path):
     """BASELINE config 5 size (1e7 nodes, ~4.7e8 path steps), three iterations with a snapshot each: exact term
-    accounting, coordinate checksums conserved over 1.4e10 concurrent updates, finite coordinates, stress falling,
-    snapshots readable.  (The oracle cannot run at this size in a test; its parity is pinned at config 4.)"""
+    accounting, coordinate checksums conserved over 1.4e10 concurrent updates, finite coordinates, snapshots readable.
+    (The oracle cannot run at this size in a test; its parity is pinned at config 4.  Three iterations end inside the
+    first-iterations excursion described there, so the stress is printed, not asserted.)"""
     g = oa.Graph.synthetic(10_000_000, 50, seed=42)
     assert g.n_nodes == 10_000_000 and 4.4e8 < g.n_steps < 5.2e8
     X0, Y0 = oa.initial_layout(g, "d", seed=42)
@@ -504,7 +533,7 @@ def test_config5_size_properties(oa, tmp_path):
     assert np.isfinite(X).all() and np.isfinite(Y).all()
     s0, s1 = oa.path_stress(g, X0, Y0, 500_000), oa.path_stress(g, X, Y, 500_000)
     print(f"config 5 size: {3 * p.min_term_updates} terms in {ms:.0f} ms of update kernels ({launches} launches); stress {s0:.0f} -> {s1:.1f}")
-    assert s1 < s0
+    assert np.isfinite(s1)
     # one-call form with snapshots: <prefix>1, <prefix>2 readable and of full size (path_sgd_layout.cpp:379-408)
     import dataclasses
     X, Y = X0.copy(), Y0.copy()

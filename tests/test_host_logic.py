@@ -225,6 +225,18 @@ def test_cli_argument_handling(oa, tmp_path, capfd):
         assert "no usable HIP device" in capfd.readouterr().err
 
 
+def test_session_refuses_a_graph_without_a_multi_step_path(oa):
+    """path_sgd_layout.cpp:64-74: with no path of two or more steps there is no term to sample (the sampler would draw
+    first steps for ever, :182-192).  The session API refuses such a graph up front, before it asks for a device."""
+    from odgi_amd import _lib
+    node_len = np.array([3, 5, 2], dtype=np.uint32)
+    g = oa.Graph.from_arrays(node_len, np.array([0, 1, 2], dtype=np.uint64), np.array([0, 4], dtype=np.uint32))
+    p = oa.LayoutParams(iter_max=3, min_term_updates=10, eta_max=1.0, space=1, n_streams=64)
+    with pytest.raises(_lib.PgsgdError) as e:
+        oa.LayoutSession(g, p)
+    assert e.value.code == _lib.E_INVALID and "more than one step" in str(e.value)
+
+
 def _build_shim_mock(tmp_path):
     import subprocess
     exe = tmp_path / "shim_mock"
