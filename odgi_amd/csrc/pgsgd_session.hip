@@ -484,6 +484,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
         // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (a second bucketing pass is the fix).
         uint32_t ob_shift = 13;
+        if (const char* e = getenv("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
         while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
         s->ob.shift = ob_shift;
         s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
@@ -999,10 +1000,10 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     if (s->ob.fill) { (void)hipFree(s->ob.fill); s->ob.fill = nullptr; }
     const uint32_t B = s->ob.n_buckets;
     double frac = 1.3 * s->ob_msgs_per_term;  // every partner far, and slack for buckets that draw more than their share
-    uint64_t open_chunks = s->tile_grid + 4;  // every resident workgroup may hold one partly filled chunk per bucket
+    uint64_t open_chunks = (uint64_t)pgsgd::kObGroup * (s->tile_grid + 4);  // every resident workgroup may hold one partly filled group of chunks per bucket
     if (const char* e = getenv("PGSGD_OUTBOX_FRACTION")) {  // test knob: a pool this small overflows into direct atomics
         frac = std::max(0.0, atof(e));
-        open_chunks = 1;
+        open_chunks = pgsgd::kObGroup;
     }
     uint64_t steps_total = 0;
     for (uint64_t v : s->ob_bucket_steps) steps_total += v;

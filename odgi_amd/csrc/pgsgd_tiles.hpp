@@ -58,6 +58,8 @@ struct WorkItem {
 constexpr uint32_t kObLine = 4;                      // messages per staged line (64 bytes)
 constexpr uint32_t kObChunk = 64;                    // messages per chunk (1 KiB)
 constexpr uint32_t kObLinesPerChunk = kObChunk / kObLine;
+constexpr uint32_t kObGroup = 4;                     // chunks a workgroup takes from a bucket's share at a time (one returning global
+constexpr uint32_t kObLinesPerGroup = kObGroup * kObLinesPerChunk;  // atomic per 256 messages: the window's own bucket fills 64 in under two trips)
 constexpr uint32_t kObUsedBits = 10;                 // LDS line word per bucket: (chunk << 10) | lines claimed in the chunk
 constexpr uint32_t kObUsedMask = (1u << kObUsedBits) - 1;
 constexpr uint32_t kObNone = (1u << (32 - kObUsedBits)) - 1;   // no chunk yet
@@ -138,7 +140,7 @@ struct OutboxLds {
     uint32_t* head;   // [B + kObRings] slots claimed
     uint32_t* done;   // [B + kObRings * kObRingLines] slots written, per line
     uint32_t* gen;    // [B + kObRings * kObRingLines] rounds completed, per line
-    uint32_t* line;   // [B] (chunk << 10) | lines claimed in the chunk
+    uint32_t* line;   // [B] (first chunk of the open group << 10) | lines claimed in the group
     uint32_t* chunk0; // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
     uint2* list;      // [waves][64] lines completed in one round of one wave: {staged line, global line index}
     uint32_t n_buckets;
@@ -151,26 +153,27 @@ __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
            ((size_t)n_buckets + kObRings + 2 * lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
 }
 
-// The next line of bucket b in the workgroup's current chunk (a new chunk when that one is full).  Several lanes may
-// ask for lines of one bucket at once (two lines of a ring completed in the same round): lines are claimed with an LDS
-// atomic; the lane that claims line kObLinesPerChunk replaces the chunk, the others wait for it without adding to the
-// word (every lane strays at most once per replacement, so the 10-bit field cannot overflow).
+// The next line of bucket b in the workgroup's current group of chunks (a new group when that one is full).  Several
+// lanes may ask for lines of one bucket at once (two lines of a ring completed in the same round): lines are claimed
+// with an LDS atomic; the lane that claims line kObLinesPerGroup replaces the group, the others wait for it without
+// adding to the word (every lane strays at most once per replacement, so the 10-bit field cannot overflow).
 __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b) {
     for (;;) {
         const uint32_t cur = __hip_atomic_load(L.line + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((cur >> kObUsedBits) == kObOverflow) return kObNoLine;
-        if ((cur & kObUsedMask) > kObLinesPerChunk) {  // being replaced
+        if ((cur & kObUsedMask) > kObLinesPerGroup) {  // being replaced
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
         const uint32_t lp = atomicAdd(L.line + b, 1u);
-        const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;
+        const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // first chunk of the group, lines claimed in the group
         if (chunk == kObOverflow) continue;  // became so between the poll and the add
-        if (used < kObLinesPerChunk) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;
-        if (used == kObLinesPerChunk) {  // this lane replaces the full chunk and takes the new one's first line
-            if (chunk != kObNone) ob.fill[L.chunk0[b] + chunk] = kObChunk;
-            const uint32_t nc = atomicAdd(ob.next + b, 1u);
-            if (nc >= ob.cap[b]) {
+        if (used < kObLinesPerGroup) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
+        if (used == kObLinesPerGroup) {  // this lane replaces the full group and takes the new one's first line
+            if (chunk != kObNone)
+                for (uint32_t k = 0; k < kObGroup; ++k) ob.fill[L.chunk0[b] + chunk + k] = kObChunk;
+            const uint32_t nc = atomicAdd(ob.next + b, kObGroup);
+            if (nc + kObGroup > ob.cap[b]) {
                 atomicExch(L.line + b, kObOverflow << kObUsedBits);
                 return kObNoLine;
             }
@@ -346,11 +349,23 @@ __device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampl
     return (uint32_t)r;
 }
 
+// a term whose first step is picked, whose Zipf/uniform and direction coins are drawn (path_sgd_layout.cpp:205-206) and
+// whose Zipf table entry is on its way
+struct PickedTerm {
+    uint4 ra;          // first step's record
+    double2 zd;        // {zeta_n, 1 - zeta2/zeta_n} for the jump
+    uint32_t s_rank, jump;
+    bool valid, zipf, back;
+};
+
 // a term whose first step and partner are drawn and whose partner record is on its way
 struct PendingTerm {
     uint4 ra;    // first step's record {handle, len, pos}
-    uint4 rb;    // partner's record
-    uint4 snap;  // the partner's coordinate snapshot {w_first, w_second} when its record came from global memory
+    uint4 rb_l;  // partner's record from the tile's LDS copy (partner inside the tile) ...
+    uint4 rb_g;  // ... or from global memory, with
+    ulonglong2 snap;  // the partner's coordinate snapshot {w_first, w_second}, loaded as two 64-bit words (no repacking of a
+                      // value in flight).  Separate registers for the two sources of the record: a select of the two
+                      // ADDRESSES would become one flat load that waits for everything in flight
     uint32_t flips;   // bit 0: far end of the first step's node, bit 1: of the partner's
     uint32_t dither;
     bool valid, from_global;
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     L.ring_b0 = 0x7fffffffu;
     __shared__ uint32_t s_item;
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
-        L.line[b] = (kObNone << kObUsedBits) | kObLinesPerChunk;
+        L.line[b] = (kObNone << kObUsedBits) | kObLinesPerGroup;
         L.chunk0[b] = ta.ob.chunk0[b];
     }
     float dmax = 0.0f;
@@ -428,67 +443,103 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
             if (worker) rng.seed(tile_stream_seed(c.seed_base, a.epoch, ti, threadIdx.x));
-            // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and one trip more
-            // than the longest lane needs: every trip draws term j and finishes term j - 1, whose partner record was
-            // requested one trip earlier — the gather's latency hides behind the next term's sampling arithmetic.
+            // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and two trips more
+            // than the longest lane needs.  Every trip finishes term j - 2, draws the partner of term j - 1 (and requests
+            // its record) and picks the first step of term j (and requests its Zipf table entry): whatever a trip loads
+            // from global memory is consumed at the start of the next one.  (gfx9 counts loads and stores in one counter
+            // and cannot wait for a particular load while stores are pending: with a single consumption point per trip the
+            // one full wait falls where everything outstanding is a trip old.)  A lane's stream yields its terms' draws in
+            // term order.
             const uint32_t n_tile_terms = (uint32_t)(term_end - term_begin);
             const uint32_t trips = (n_tile_terms + lanes - 1) / lanes;
-            PendingTerm P;
-            P.valid = false;
-            for (uint32_t j = 0; j <= trips; ++j) {
-                PendingTerm N;
-                N.valid = false;
+            // Two sets of stage registers, used alternately: a trip WRITES one set and READS the other, so nothing that
+            // is still in flight has to be copied between registers at the end of a trip (a copy is a use: it would wait
+            // for the load right where it was issued).
+            PickedTerm K0, K1;
+            PendingTerm Q0, Q1;
+            K0.valid = K1.valid = false;
+            Q0.valid = Q1.valid = false;
+            // (stages take and return their registers BY VALUE: structs reached through references stay in memory, and a
+            // select between two members becomes a load from a selected address — scratch traffic and flat loads)
+            auto pick_stage = [&](uint32_t j) -> PickedTerm {
+                PickedTerm Kw;
+                Kw.valid = false;
                 if (worker && j < trips && threadIdx.x + j * lanes < n_tile_terms) {
-                    // first step: uniform inside the tile; partner by the reference's rule (path_sgd_layout.cpp:205-237), then
-                    // the two end choices (:253,262) — draw_partner() with 32-bit step indices
-                    N.valid = true;
+                    // first step: uniform inside the tile; then the reference's coins (path_sgd_layout.cpp:205-206)
+                    Kw.valid = true;
                     const uint32_t ka = uniform_below32(rng, t.n);  // offset inside the tile
-                    N.ra = trec[ka];
-                    const uint32_t s_rank = t0 + ka - pstart;
+                    Kw.ra = trec[ka];
+                    Kw.s_rank = t0 + ka - pstart;
+                    Kw.zipf = COOLING || coin(rng);
+                    Kw.back = false;
+                    Kw.jump = 0;
+                    if (Kw.zipf) {
+                        Kw.back = (Kw.s_rank > 0 && coin(rng)) || Kw.s_rank == cnt - 1;
+                        const uint32_t room = Kw.back ? Kw.s_rank : cnt - Kw.s_rank - 1;
+                        Kw.jump = ts.space < room ? ts.space : room;
+                        Kw.zd = ts.zeta_denom[Kw.jump > ts.space_max ? ts.space_max + (Kw.jump - ts.space_max) / ts.space_quant + 1 : Kw.jump];
+                    }
+                }
+                return Kw;
+            };
+            auto partner_stage = [&](const PickedTerm Kr) -> PendingTerm {
+                PendingTerm Qw;
+                Qw.valid = false;
+                if (Kr.valid) {
+                    // partner by the reference's rule (:207-237), then the two end choices (:253,262)
+                    Qw.valid = true;
+                    Qw.ra = Kr.ra;
                     uint32_t b_rank;
-                    if (COOLING || coin(rng)) {
-                        const bool back = (s_rank > 0 && coin(rng)) || s_rank == cnt - 1;
-                        const uint32_t room = back ? s_rank : cnt - s_rank - 1;
-                        const uint32_t jump = ts.space < room ? ts.space : room;
-                        const double2 zd = ts.zeta_denom[jump > ts.space_max ? ts.space_max + (jump - ts.space_max) / ts.space_quant + 1 : jump];
-                        const uint32_t z = zipf_tile(rng, ts, jump, zd.x, zd.y);
-                        b_rank = back ? s_rank - z : s_rank + z;
+                    if (Kr.zipf) {
+                        const uint32_t z = zipf_tile(rng, ts, Kr.jump, Kr.zd.x, Kr.zd.y);
+                        b_rank = Kr.back ? Kr.s_rank - z : Kr.s_rank + z;
                     } else {
                         b_rank = uniform_below32(rng, cnt);
                     }
                     const uint64_t draw_a = rng.next(), draw_b = rng.next();
-                    N.flips = (uint32_t)(draw_a >> 63) | ((uint32_t)(draw_b >> 63) << 1);
-                    N.dither = (uint32_t)draw_a;
+                    Qw.flips = (uint32_t)(draw_a >> 63) | ((uint32_t)(draw_b >> 63) << 1);
+                    Qw.dither = (uint32_t)draw_a;
                     // the partner's record: the tile's LDS copy when it is a step of the tile, otherwise ONE 32-byte gather
-                    // that also brings the coordinates both ends of its node had when this launch began
+                    // that also brings the coordinates both ends of its node had at the last snapshot
                     const uint32_t kb = pstart + b_rank;
-                    N.from_global = !(kb - t0 < t.n);
-                    if (N.from_global) {
-                        N.rb = ta.recs2[2 * (uint64_t)kb];
-                        N.snap = ta.recs2[2 * (uint64_t)kb + 1];
-                    } else {
-                        N.rb = trec[kb - t0];
+                    Qw.from_global = !(kb - t0 < t.n);
+                    if (!Qw.from_global) Qw.rb_l = trec[kb - t0];
+                    if (Qw.from_global) {
+                        Qw.rb_g = ta.recs2[2 * (uint64_t)kb];
+                        Qw.snap = reinterpret_cast<const ulonglong2*>(ta.recs2)[2 * (uint64_t)kb + 1];
                     }
                 }
+                return Qw;
+            };
+            struct FarMessages { uint64_t delta; uint32_t end_a, end_b; bool to_a, to_b; };
+            auto finish_stage = [&](const PendingTerm Qr) -> FarMessages {
                 bool msg_a = false, msg_b = false;
                 uint32_t end_a = 0, end_b = 0;
                 uint64_t delta = 0;
-                if (P.valid) {
+                if (Qr.valid) {
+                    // (component by component: a select between the two structs would be done on their ADDRESSES and force them into memory)
+                    const uint4 rb = make_uint4(Qr.from_global ? Qr.rb_g.x : Qr.rb_l.x, Qr.from_global ? Qr.rb_g.y : Qr.rb_l.y,
+                                                Qr.from_global ? Qr.rb_g.z : Qr.rb_l.z, Qr.from_global ? Qr.rb_g.w : Qr.rb_l.w);
                     // the path position moves to the chosen end of each node (:242-269)
-                    uint64_t pos_a = (uint64_t)P.ra.z | ((uint64_t)P.ra.w << 32), pos_b = (uint64_t)P.rb.z | ((uint64_t)P.rb.w << 32);
-                    if (P.flips & 1u) pos_a += P.ra.y;
-                    if (P.flips & 2u) pos_b += P.rb.y;
-                    end_a = P.ra.x ^ (P.flips & 1u);
-                    end_b = P.rb.x ^ (P.flips >> 1);
+                    uint64_t pos_a = (uint64_t)Qr.ra.z | ((uint64_t)Qr.ra.w << 32), pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+                    if (Qr.flips & 1u) pos_a += Qr.ra.y;
+                    if (Qr.flips & 2u) pos_b += rb.y;
+                    end_a = Qr.ra.x ^ (Qr.flips & 1u);
+                    end_b = rb.x ^ (Qr.flips >> 1);
                     // ends inside the staged window live in LDS (unsigned compare covers "below the window")
+                    // A tile with a window has all its nodes inside it (that is what binds it to the window): the first end is
+                    // always in LDS, and so is a partner that is a step of the tile.  Only window-less tiles read global words
+                    // here (no dead global loads in the windowed instance: the compiler could not count what is in flight).
                     const uint32_t la = end_a - wbase, lb = end_b - wbase;
-                    const bool in_a = LOCAL && la < win_words, in_b = LOCAL && lb < win_words;
-                    const uint64_t wa = in_a ? win[la] : load_word<COORD_LOAD>(c.coords, end_a);
-                    uint64_t wb;
-                    if (in_b) wb = win[lb];
-                    else if (P.from_global)  // the snapshot that came with the record; w_first belongs to end `handle`
-                        wb = (P.flips & 2u) ? ((uint64_t)P.snap.z | ((uint64_t)P.snap.w << 32)) : ((uint64_t)P.snap.x | ((uint64_t)P.snap.y << 32));
-                    else wb = load_word<COORD_LOAD>(c.coords, end_b);  // window-less tile, partner inside the tile
+                    const bool in_a = LOCAL, in_b = LOCAL && lb < win_words;
+                    uint64_t wa, wb;
+                    if (LOCAL) {
+                        wa = win[la];
+                        wb = in_b ? win[lb] : ((Qr.flips & 2u) ? Qr.snap.y : Qr.snap.x);  // live word, or the snapshot that came with the record
+                    } else {
+                        wa = load_word<COORD_LOAD>(c.coords, end_a);
+                        wb = Qr.from_global ? ((Qr.flips & 2u) ? Qr.snap.y : Qr.snap.x) : load_word<COORD_LOAD>(c.coords, end_b);
+                    }
                     const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                     const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
                     float r_x, r_y, abs_delta;
@@ -499,8 +550,8 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         r_y *= 2.0f;
                     }
                     dmax = fmaxf(dmax, abs_delta);
-                    const float ux = (float)(P.dither & 0xffffu) * (1.0f / 65536.0f);
-                    const float uy = (float)(P.dither >> 16) * (1.0f / 65536.0f);
+                    const float ux = (float)(Qr.dither & 0xffffu) * (1.0f / 65536.0f);
+                    const float uy = (float)(Qr.dither >> 16) * (1.0f / 65536.0f);
                     float fx = r_x * c.xf.scale;
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
@@ -518,9 +569,23 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     }
                 }
                 if (ta.experiment & 1u) msg_a = msg_b = false;
-                outbox_push(ta.ob, L, msg_b, end_b, delta, (ta.experiment & 2u) != 0);
-                if (!LOCAL) outbox_push(ta.ob, L, msg_a, end_a, 0ull - delta);
-                P = N;
+                return FarMessages{delta, end_a, end_b, msg_a, msg_b};
+            };
+            auto send = [&](const FarMessages m) {
+                outbox_push(ta.ob, L, m.to_b, m.end_b, m.delta, (ta.experiment & 2u) != 0);
+                if (!LOCAL) outbox_push(ta.ob, L, m.to_a, m.end_a, 0ull - m.delta);
+            };
+            for (uint32_t j = 0; j <= trips + 1; j += 2) {  // (a trip past the end finds nothing valid and does nothing)
+                // one trip: everything the previous trip requested is consumed FIRST (one wait, for loads that have been
+                // in flight for a whole trip), then this trip's requests go out, then its messages
+                FarMessages m = finish_stage(Q1);   // term j - 2
+                Q0 = partner_stage(K1);             // term j - 1: Zipf entry arrived; requests the partner's record
+                K0 = pick_stage(j);                 // term j: requests its Zipf entry
+                send(m);
+                m = finish_stage(Q0);
+                Q1 = partner_stage(K0);
+                K1 = pick_stage(j + 1);
+                send(m);
             }
         }
         __syncthreads();
@@ -538,8 +603,12 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     // write out the partly filled lines and close the chunks this workgroup still has open
     outbox_flush_rings(ta.ob, L, 0, L.n_buckets);
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
-        const uint32_t lp = L.line[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;
-        if (chunk < kObOverflow) ta.ob.fill[ta.ob.chunk0[b] + chunk] = used * kObLine;
+        const uint32_t lp = L.line[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // lines written into the open group
+        if (chunk < kObOverflow)
+            for (uint32_t k = 0; k < kObGroup; ++k) {
+                const uint32_t lines = used > k * kObLinesPerChunk ? (used - k * kObLinesPerChunk < kObLinesPerChunk ? used - k * kObLinesPerChunk : kObLinesPerChunk) : 0u;
+                ta.ob.fill[ta.ob.chunk0[b] + chunk + k] = lines * kObLine;
+            }
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
     if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(ta.far_count, (unsigned long long)n_far);

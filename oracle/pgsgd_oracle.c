@@ -205,6 +205,50 @@ static void orc_sample_partner(const orc_graph* g, const orc_params* p, const do
     t->pos_b = pos_b;
 }
 
+/* The tile kernel draws a term in two steps (pgsgd_tiles.hpp: pick_stage, partner_stage — a trip of its term loop
+ * apart, so that the Zipf table entry is on its way meanwhile): the first step with the Zipf/uniform and direction coins
+ * (:205-206), then the partner and the end choices.  A lane's stream yields its terms' draws in term order. */
+typedef struct orc_tile_pick { orc_anchor an; int zipf, back; uint64_t jump; } orc_tile_pick;
+
+static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int cooling, uint64_t t0, uint32_t tn, uint32_t path,
+                                uint64_t s[4], orc_tile_pick* pk) {
+    pk->an.pstart = g->path_first[path];
+    pk->an.cnt = g->path_first[path + 1] - pk->an.pstart;
+    pk->an.k = t0 + orc_uniform_u64(s, tn);
+    pk->an.s_rank = pk->an.k - pk->an.pstart;
+    pk->zipf = cooling || orc_flip(s);                                                       /* :205 */
+    pk->back = 0;
+    pk->jump = 0;
+    if (pk->zipf) {
+        pk->back = (pk->an.s_rank > 0 && orc_flip(s)) || pk->an.s_rank == pk->an.cnt - 1;      /* :206 */
+        const uint64_t room = pk->back ? pk->an.s_rank : pk->an.cnt - pk->an.s_rank - 1;
+        pk->jump = p->space < room ? p->space : room;
+    }
+}
+
+static void orc_tile_partner(const orc_graph* g, const orc_params* p, const double* zetas, const orc_tile_pick* pk, uint64_t s[4], orc_term* t) {
+    uint64_t b_rank;
+    if (pk->zipf) {
+        uint64_t space = pk->jump;
+        if (pk->jump > p->space_max) space = p->space_max + (pk->jump - p->space_max) / p->space_quantization_step + 1;
+        const uint64_t z_i = orc_zipf(s, pk->jump, p->theta, zetas[space]);
+        b_rank = pk->back ? pk->an.s_rank - z_i : pk->an.s_rank + z_i;
+    } else {
+        b_rank = orc_uniform_u64(s, pk->an.cnt);                                               /* :235-237 */
+    }
+    t->ka = pk->an.k;
+    t->kb = pk->an.pstart + b_rank;
+    const uint32_t h_a = g->step_handle[t->ka], h_b = g->step_handle[t->kb];
+    uint64_t pos_a = g->step_pos[t->ka], pos_b = g->step_pos[t->kb];
+    const uint32_t rev_a = h_a & 1u, rev_b = h_b & 1u;
+    const uint64_t draw_a = orc_rng_next(s);                                                 /* :253 */
+    t->dither = (uint32_t)draw_a;
+    if (draw_a >> 63) { pos_a += g->node_len[h_a >> 1]; t->off_a = !rev_a; } else { t->off_a = rev_a; }
+    if (orc_flip(s)) { pos_b += g->node_len[h_b >> 1]; t->off_b = !rev_b; } else { t->off_b = rev_b; }   /* :262 */
+    t->pos_a = pos_a;
+    t->pos_b = pos_b;
+}
+
 int orc_sample_term(const orc_graph* g, const orc_params* p, const double* zetas, int cooling,
                     uint64_t s[4], orc_term* t) {
     orc_anchor a;
@@ -409,13 +453,10 @@ uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_b
         uint64_t s[4];
         orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | lane), s);
         for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
-            orc_anchor an;
-            an.pstart = g->path_first[path];
-            an.cnt = g->path_first[path + 1] - an.pstart;
-            an.k = t0 + orc_uniform_u64(s, n);
-            an.s_rank = an.k - an.pstart;
+            orc_tile_pick cur;
+            orc_tile_pick_first(g, p, cooling, t0, n, path, s, &cur);
             orc_term t;
-            orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+            orc_tile_partner(g, p, zetas, &cur, s, &t);
             uint64_t* o = out + (q - term_begin) * 4;
             o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
         }
@@ -1166,13 +1207,10 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + (((uint64_t)ti << 10) | l), streams + 4 * (size_t)l);
                     for (uint64_t q = term_begin; q < term_end; ++q) {
                         uint64_t* s = streams + 4 * (size_t)((q - term_begin) % lanes);
-                        orc_anchor an;
-                        an.pstart = g->path_first[tpath[ti]];
-                        an.cnt = g->path_first[tpath[ti] + 1] - an.pstart;
-                        an.k = t0[ti] + orc_uniform_u64(s, tn[ti]);
-                        an.s_rank = an.k - an.pstart;
+                        orc_tile_pick cur;
+                        orc_tile_pick_first(g, p, cooling, t0[ti], tn[ti], tpath[ti], s, &cur);
                         orc_term t;
-                        orc_sample_partner(g, p, zetas, cooling, &an, s, &t);
+                        orc_tile_partner(g, p, zetas, &cur, s, &t);
                         const uint64_t ea = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
                         const uint64_t eb = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
                         const int in_a = local[it] && ea >= wbase && ea - wbase < win_words;
