@@ -263,6 +263,13 @@ extern "C" int pgsgd_graph_from_og(const char* path, int n_threads, pgsgd_graph*
 extern "C" int pgsgd_graph_load(const char* path, int n_threads, pgsgd_graph** out) {
     if (!path || !out) return PGSGD_E_INVALID;
     const size_t n = strlen(path);
+    // The reference also takes GFAz (utils.cpp:110-121: a magic word and a codec that both live in deps/GFAz, an empty
+    // directory in the reference tree; no fixture either): refused by name with a message instead of being read as .og.
+    if (n >= 5 && strcmp(path + n - 5, ".gfaz") == 0) {
+        pgsgd::set_error("GFAz input is not supported (the codec is a dependency absent from the reference tree and there is no fixture to pin a "
+                         "reader against): decompress to GFA or build an .og with `odgi build`");
+        return PGSGD_E_UNSUPPORTED;
+    }
     if (n >= 3 && strcmp(path + n - 3, "gfa") == 0) return pgsgd_graph_from_gfa(path, n_threads, out);
     return pgsgd_graph_from_og(path, n_threads, out);
 }

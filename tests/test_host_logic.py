@@ -219,6 +219,9 @@ def test_cli_argument_handling(oa, tmp_path, capfd):
     assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "x.lay"), "-X", str(tmp_path / "no.xp")]) == 1
     err = capfd.readouterr().err
     assert "-X/--path-index is not supported" in err and "Leave -X out" in err
+    # GFAz (utils.cpp:110-121) likewise: codec and magic word live in an absent dependency; refused by name
+    assert oa.main_layout(["-i", str(tmp_path / "graph.gfaz"), "-o", str(tmp_path / "x.lay")]) == 1
+    assert "GFAz input is not supported" in capfd.readouterr().err
     import torch
     if not torch.cuda.is_available():  # a valid command line still ends in a loud device error
         assert oa.main_layout(["-i", os.path.join(GOLDEN, "t.gfa"), "-o", str(tmp_path / "t.lay")]) == 1
