@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
             if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
                 dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                 dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
-                guard |= in_frame_guard(wa) | in_frame_guard(wb);
+                guard |= in_frame_guard(wa) || in_frame_guard(wb);
             } else {
                 dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
             if (FMT == kFmtQ32) {  // integer differences are exact: no cancellation at large coordinates
                 dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
                 dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
-                guard |= in_frame_guard(wa) | in_frame_guard(wb);
+                guard |= in_frame_guard(wa) || in_frame_guard(wb);
             } else {
                 dx = __uint_as_float((uint32_t)wa) - __uint_as_float((uint32_t)wb);
                 dy = __uint_as_float((uint32_t)(wa >> 32)) - __uint_as_float((uint32_t)(wb >> 32));

@@ -487,6 +487,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = getenv("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
         while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
         s->ob.shift = ob_shift;
+        s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
         s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
         s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
         s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
@@ -1019,9 +1020,9 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
         cap[b] = (uint32_t)c;
         total += c;
     }
-    hipError_t e = hipMalloc(&s->ob.pool, total * pgsgd::kObChunk * sizeof(uint4));
+    hipError_t e = hipMalloc(&s->ob.pool, total * pgsgd::kObChunk * sizeof(unsigned long long));
     if (e != hipSuccess) {
-        set_error("outbox pool of %.1f GB: %s", (double)total * pgsgd::kObChunk * 16 / 1e9, hipGetErrorString(e));
+        set_error("outbox pool of %.1f GB: %s", (double)total * pgsgd::kObChunk * 8 / 1e9, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP;
     }
     HIP_TRY(hipMalloc(&s->ob.fill, total * sizeof(uint32_t)));
@@ -1046,7 +1047,7 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     s->ob_total_chunks = total;
     if (s->params.progress)
         fprintf(stderr, "[odgi::path_linear_sgd_layout] far-update outbox: %u buckets of %u node ends, %.2f GB message pool\n", B, 1u << s->ob.shift,
-                (double)total * pgsgd::kObChunk * 16 / 1e9);
+                (double)total * pgsgd::kObChunk * 8 / 1e9);
     return PGSGD_OK;
 }
 

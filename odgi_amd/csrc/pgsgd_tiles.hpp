@@ -49,17 +49,20 @@ struct WorkItem {
     uint32_t local;  // 1 = window staged in LDS, 0 = every end in global memory
 };
 
-// The far-update outbox.  Messages {node end, 0, delta lo, delta hi} are grouped by bucket = end >> shift.  A
-// workgroup stages kObLine messages per bucket in LDS and writes a full line with kObLine lanes of one store
-// instruction: a write that covers a whole 64-byte unit needs no read-for-ownership (55 G such writes/s against
-// 23 G 16-byte ones, profiles/r02/microbench_r2b.jsonl).  Lines go to chunks of kObChunk messages that the
-// workgroup owns (one returning global atomic on the bucket's chunk counter per chunk); `fill` says how many
-// messages a chunk holds (lines fill in order, only a workgroup's last line of a bucket can be partial).
-constexpr uint32_t kObLine = 4;                      // messages per staged line (64 bytes)
-constexpr uint32_t kObChunk = 64;                    // messages per chunk (1 KiB)
+// The far-update outbox.  Messages are grouped by bucket = end >> shift and packed into 8 bytes: the end's offset
+// inside its bucket (shift bits) and the two coordinate steps as signed qbits-bit quanta (25 bits each with the
+// default 8192-end buckets; a far step is capped at a fraction of a projection and is far below 2^24 quanta — one
+// that is not goes to the spill words directly, outbox_pack).  A workgroup stages kObLine messages per bucket in LDS
+// and writes a full line with kObLine lanes of one store instruction: a write that covers a whole 64-byte unit needs
+// no read-for-ownership (55 G such writes/s against 23 G 16-byte ones, profiles/r02/microbench_r2b.jsonl).  Lines go
+// to chunks of kObChunk messages that the workgroup owns (one returning global atomic on the bucket's chunk counter
+// per group of chunks); `fill` says how many messages a chunk holds (lines fill in order, only a workgroup's last
+// line of a bucket can be partial).
+constexpr uint32_t kObLine = 8;                      // messages per staged line (64 bytes)
+constexpr uint32_t kObChunk = 128;                   // messages per chunk (1 KiB)
 constexpr uint32_t kObLinesPerChunk = kObChunk / kObLine;
 constexpr uint32_t kObGroup = 4;                     // chunks a workgroup takes from a bucket's share at a time (one returning global
-constexpr uint32_t kObLinesPerGroup = kObGroup * kObLinesPerChunk;  // atomic per 256 messages: the window's own bucket fills 64 in under two trips)
+constexpr uint32_t kObLinesPerGroup = kObGroup * kObLinesPerChunk;  // atomic per 512 messages: the window's own bucket fills 64 in under two trips)
 constexpr uint32_t kObUsedBits = 10;                 // LDS line word per bucket: (chunk << 10) | lines claimed in the chunk
 constexpr uint32_t kObUsedMask = (1u << kObUsedBits) - 1;
 constexpr uint32_t kObNone = (1u << (32 - kObUsedBits)) - 1;   // no chunk yet
@@ -71,9 +74,9 @@ constexpr uint32_t kObNoLine = 0xffffffffu;
 // 64 claims are outstanding.  (With one line per bucket a wave whose lanes hold 19 messages for the same bucket needs
 // five claim-write-flush rounds per trip: measured, the cooling iterations ran 45 % slower than with direct atomics.)
 constexpr uint32_t kObRings = 2;        // the window's bucket and the next one (a window can straddle a bucket border)
-constexpr uint32_t kObRingLines = 32;   // 128 slots: the waves of a workgroup drift apart by a trip or two
+constexpr uint32_t kObRingLines = 16;   // 128 slots: the waves of a workgroup drift apart by a trip or two
 struct Outbox {
-    uint4* pool;               // [total chunks][kObChunk] messages
+    unsigned long long* pool;  // [total chunks][kObChunk] packed messages
     const uint32_t* chunk0;    // [B] first chunk of the bucket's share of the pool
     const uint32_t* cap;       // [B] chunks in that share
     uint32_t* next;            // [B] chunks handed out this launch
@@ -82,7 +85,27 @@ struct Outbox {
     unsigned long long* overflow;  // their number (0 in normal operation)
     uint32_t n_buckets;
     uint32_t shift;            // bucket = node end >> shift
+    uint32_t qbits;            // bits of one packed coordinate step: min(25, (64 - shift) / 2)
 };
+
+__host__ __device__ inline uint32_t outbox_qbits(uint32_t shift) { return (64u - shift) / 2u < 25u ? (64u - shift) / 2u : 25u; }
+
+// message = end offset in the bucket | x step << shift | y step << (shift + qbits), steps in two's complement.
+// `delta` is the 64-bit word the per-lane kernel would add atomically: qx + (qy << 32) with signed 32-bit qx, qy.
+__device__ __forceinline__ bool outbox_pack(const Outbox& ob, uint32_t end, uint64_t delta, uint64_t& msg) {
+    const int32_t qx = (int32_t)(uint32_t)delta;
+    const int32_t qy = (int32_t)(uint32_t)((delta - (uint64_t)(int64_t)qx) >> 32);
+    const int32_t lim = 1 << (ob.qbits - 1);
+    const uint64_t mask = (1ull << ob.qbits) - 1ull;
+    msg = (uint64_t)(end & ((1u << ob.shift) - 1u)) | (((uint64_t)(int64_t)qx & mask) << ob.shift) | (((uint64_t)(int64_t)qy & mask) << (ob.shift + ob.qbits));
+    return qx >= -lim && qx < lim && qy >= -lim && qy < lim;
+}
+__device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg, uint32_t& end_off) {
+    end_off = (uint32_t)msg & ((1u << ob.shift) - 1u);
+    const int64_t qx = (int64_t)(msg << (64u - ob.shift - ob.qbits)) >> (64u - ob.qbits);
+    const int64_t qy = (int64_t)(msg << (64u - ob.shift - 2u * ob.qbits)) >> (64u - ob.qbits);
+    return (uint64_t)qx + ((uint64_t)qy << 32);
+}
 
 constexpr int kTileBlock = 256;
 constexpr int kTileWaves = kTileBlock / 64;
@@ -136,7 +159,7 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 // lane may write it once the line is back from its previous round (gen), and the writer that completes a line
 // (done == kObLine) writes it out and reopens it.
 struct OutboxLds {
-    uint4* stage;     // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
+    uint64_t* stage;  // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
     uint32_t* head;   // [B + kObRings] slots claimed
     uint32_t* done;   // [B + kObRings * kObRingLines] slots written, per line
     uint32_t* gen;    // [B + kObRings * kObRingLines] rounds completed, per line
@@ -149,7 +172,7 @@ struct OutboxLds {
 
 __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
     const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
-    return lines * kObLine * sizeof(uint4) + (size_t)kTileWaves * 64 * sizeof(uint2) +
+    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * 64 * sizeof(uint2) +
            ((size_t)n_buckets + kObRings + 2 * lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
 }
 
@@ -187,6 +210,11 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
 __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, uint64_t delta, bool dry = false) {
     if (!__ballot(has)) return;
     const uint32_t b = end >> ob.shift;
+    uint64_t packed = 0;
+    if (has && !outbox_pack(ob, end, delta, packed)) {  // a step too wide for the packed form (never seen with the far cap): the
+        atomicAdd(ob.spill + end, (unsigned long long)delta);  // spill words, which the drain adds with the messages
+        has = false;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     const uint32_t r = b - L.ring_b0;  // hot ring of the bucket, if it has one
@@ -214,7 +242,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
         bool completes = false;
         // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out)
         if (pending && __hip_atomic_load(L.gen + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == round) {
-            L.stage[src * kObLine + slot % kObLine] = make_uint4(end, 0u, (uint32_t)delta, (uint32_t)(delta >> 32));
+            L.stage[src * kObLine + slot % kObLine] = packed;
             pending = false;
             completes = atomicAdd(L.done + src, 1u) + 1 == kObLine;  // the last of the line's writers writes it out
         } else if (pending) {
@@ -233,13 +261,16 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
                 const uint32_t e = base + lane / kObLine, piece = lane % kObLine;
                 if (e < n) {
                     const uint2 it = list[e];
-                    const uint4 m = L.stage[it.x * kObLine + piece];
+                    const uint64_t m = L.stage[it.x * kObLine + piece];
                     if (dry) {
-                        asm volatile("" ::"v"(m.x), "v"(m.w));
+                        asm volatile("" ::"v"((uint32_t)m), "v"((uint32_t)(m >> 32)));
                     } else if (it.y != kObNoLine) {
                         ob.pool[(uint64_t)it.y * kObLine + piece] = m;
                     } else {  // no room left in the pool: the spill words, added to the coordinates by the drain
-                        atomicAdd(ob.spill + m.x, (unsigned long long)m.z | ((unsigned long long)m.w << 32));
+                        const uint32_t mb = it.x < L.n_buckets ? it.x : L.ring_b0 + (it.x - L.n_buckets) / kObRingLines;  // the staged line's bucket
+                        uint32_t off;
+                        const uint64_t d = outbox_unpack(ob, m, off);
+                        atomicAdd(ob.spill + (((uint64_t)mb << ob.shift) | off), (unsigned long long)d);
                         atomicAdd(ob.overflow, 1ull);
                     }
                 }
@@ -258,7 +289,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
 // Write out the partly filled line of every ring in [first, first + count) (ring index: bucket, or n_buckets + r for a
 // hot ring), padded to a whole line with messages that add zero (so every line in the pool is full and is written as
 // one 64-byte unit), and put the rings back to their initial state.  Called by the whole workgroup, between barriers,
-// when no push is in flight: four consecutive lanes per ring.
+// when no push is in flight: kObLine consecutive lanes per ring.
 __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const OutboxLds& L, uint32_t first, uint32_t count) {
     const uint32_t piece = threadIdx.x % kObLine;
     for (uint32_t base = 0; base < count; base += blockDim.x / kObLine) {
@@ -275,11 +306,13 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
         if (n && piece == 0) dst = outbox_next_line(ob, L, b);
         dst = __shfl(dst, (int)((threadIdx.x & 63u) & ~(kObLine - 1u)));
         if (n) {
-            const uint4 m = piece < n ? L.stage[src * kObLine + piece] : make_uint4(b << ob.shift, 0u, 0u, 0u);
+            const uint64_t m = piece < n ? L.stage[src * kObLine + piece] : 0ull;  // (0 = add nothing to the bucket's first end)
             if (dst != kObNoLine) {
                 ob.pool[(uint64_t)dst * kObLine + piece] = m;
             } else if (piece < n) {
-                atomicAdd(ob.spill + m.x, (unsigned long long)m.z | ((unsigned long long)m.w << 32));
+                uint32_t off;
+                const uint64_t d = outbox_unpack(ob, m, off);
+                atomicAdd(ob.spill + (((uint64_t)b << ob.shift) | off), (unsigned long long)d);
                 atomicAdd(ob.overflow, 1ull);
             }
         }
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
     L.n_buckets = ta.ob.n_buckets;
     {
         const size_t lines = (size_t)L.n_buckets + kObRings * kObRingLines;
-        L.stage = trec + ta.tile_steps;
+        L.stage = reinterpret_cast<uint64_t*>(trec + ta.tile_steps);
         L.list = reinterpret_cast<uint2*>(L.stage + lines * kObLine);
         L.head = reinterpret_cast<uint32_t*>(L.list + kTileWaves * 64);
         L.done = L.head + L.n_buckets + kObRings;
@@ -645,21 +678,27 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     const uint64_t n_slots = (uint64_t)(handed < cap ? handed : cap) * kObChunk;
     const uint64_t first = (uint64_t)ob.chunk0[b] * kObChunk;
     const uint64_t base = ((uint64_t)b << ob.shift) + ((uint64_t)part << part_shift);
-    // four independent message loads per lane in flight before the LDS adds (one workgroup streams ~12 MB)
-    for (uint64_t i0 = threadIdx.x; i0 < n_slots; i0 += 4ull * blockDim.x) {
-        uint4 m[4];
+    // four independent 16-byte loads (two messages each) per lane in flight before the LDS adds (one workgroup streams ~6 MB)
+    const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(ob.pool);
+    const uint64_t n_pairs = n_slots / 2, first_pair = first / 2;
+    const uint32_t part_off = part << part_shift;
+    for (uint64_t i0 = threadIdx.x; i0 < n_pairs; i0 += 4ull * blockDim.x) {
+        ulonglong2 m[4];
         bool ok[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint64_t i = i0 + (uint64_t)k * blockDim.x;
-            ok[k] = i < n_slots && (uint32_t)(i % kObChunk) < ob.fill[ob.chunk0[b] + (uint32_t)(i / kObChunk)];
-            if (ok[k]) m[k] = ob.pool[first + i];
+            ok[k] = i < n_pairs && (uint32_t)((2 * i) % kObChunk) < ob.fill[ob.chunk0[b] + (uint32_t)((2 * i) / kObChunk)];  // fill is a whole number of lines
+            if (ok[k]) m[k] = pairs[first_pair + i];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!ok[k]) continue;
-            const uint64_t off = (uint64_t)m[k].x - base;
-            if (off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + off), (unsigned long long)m[k].z | ((unsigned long long)m[k].w << 32));
+            uint32_t off;
+            uint64_t d = outbox_unpack(ob, m[k].x, off);
+            if (d && off - part_off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + (off - part_off)), (unsigned long long)d);
+            d = outbox_unpack(ob, m[k].y, off);
+            if (d && off - part_off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + (off - part_off)), (unsigned long long)d);
         }
     }
     __syncthreads();
