@@ -211,10 +211,15 @@ __device__ __forceinline__ Term sample_partner(const DevConst& c, const Anchor& 
 }
 
 // The displacement of one term in bp, fp32 (path_sgd_layout.cpp:280-352); dx,dy = p_a - p_b.
+// BELOW_2_52: path positions are below 2^52 (checked when a tiled session is created), so the distance converts to
+// fp64 exactly from its two halves and is rounded once on the way to fp32 — the bits of (float)(uint64_t), in a
+// third of the instructions
+template <bool BELOW_2_52 = false>
 __device__ __forceinline__ void term_displacement(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy,
                                                   float& r_x, float& r_y, float& abs_delta, float mu_cap = 1.0f) {
     const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
-    float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+    const uint64_t ad = (uint64_t)(diff < 0 ? -diff : diff);
+    float d = BELOW_2_52 ? (float)((double)(uint32_t)(ad >> 32) * 4294967296.0 + (double)(uint32_t)ad) : (float)ad;
     if (d == 0.0f) d = 1e-9f;
     const float w = 1.0f / d;
     float mu = eta * w;

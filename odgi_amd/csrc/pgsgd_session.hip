@@ -48,6 +48,7 @@ struct pgsgd_session {
     uint64_t* d_path_first = nullptr;
     double* d_zetas = nullptr;
     double2* d_zeta_denom = nullptr;
+    double2* d_zipf_tab = nullptr;  // tile kernel: {zeta_n, eta_n} per jump length (zipf_tab_kernel)
     uint64_t* d_coords = nullptr;         // [2N] coordinate words
     uint64_t* d_base = nullptr;           // coordinates at the last exchange (multi-GPU only)
     uint64_t* d_rng = nullptr;
@@ -710,6 +711,17 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     }
     c.xf.x_off = c.xf.y_off = 0.0;
     c.xf.scale = c.xf.inv_scale = 1.0f;
+    if (s->tiled) {  // the tile kernel's Zipf table: one entry per jump length
+        uint64_t longest = 0;
+        for (uint64_t q = 0; q < g->n_paths; ++q) longest = std::max(longest, g->path_first[q + 1] - g->path_first[q]);
+        const uint64_t n_entries = std::min<uint64_t>(p->space, longest) + 1;  // a jump is min(space, steps to the path's end)
+        S_TRY(hipMalloc(&s->d_zipf_tab, n_entries * sizeof(double2)));
+        hipLaunchKernelGGL(pgsgd::zipf_tab_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s->stream, s->d_zeta_denom,
+                           (uint32_t)std::min<uint64_t>(p->space_max, 0xffffffffull), (uint32_t)std::min<uint64_t>(p->space_quantization_step, 0xffffffffull),
+                           c.zc.omt_e, c.zc.omt_frac, (uint32_t)n_entries, s->d_zipf_tab);
+        S_TRY(hipGetLastError());
+        S_TRY(hipStreamSynchronize(s->stream));
+    }
     timer.lap("tables, streams");
     if (s->tiled && p->min_term_updates) {  // the message pool for iterations of the default length (grown later if a call asks for more)
         rc = ensure_outbox(s, p->min_term_updates, 1);
@@ -731,6 +743,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_path_first) (void)hipFree(s->d_path_first);
     if (s->d_zetas) (void)hipFree(s->d_zetas);
     if (s->d_zeta_denom) (void)hipFree(s->d_zeta_denom);
+    if (s->d_zipf_tab) (void)hipFree(s->d_zipf_tab);
     if (s->d_node_steps) (void)hipFree(s->d_node_steps);
     if (s->d_coords) (void)hipFree(s->d_coords);
     if (s->d_base) (void)hipFree(s->d_base);
@@ -1137,13 +1150,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.experiment = getenv("PGSGD_TILE_EXP") ? (uint32_t)atoi(getenv("PGSGD_TILE_EXP")) : 0u;
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
-            ts.zeta_denom = s->d_zeta_denom;
+            ts.zipf_tab = s->d_zipf_tab;
             ts.space = (uint32_t)std::min<uint64_t>(s->params.space, 0xffffffffull);
-            ts.space_max = (uint32_t)std::min<uint64_t>(s->params.space_max, 0xffffffffull);
-            ts.space_quant = (uint32_t)std::min<uint64_t>(s->params.space_quantization_step, 0xffffffffull);
-            ts.omt_e = s->dc.zc.omt_e;
             ts.alpha_e = s->dc.zc.alpha_e;
-            ts.omt_frac = s->dc.zc.omt_frac;
             ts.alpha_frac = s->dc.zc.alpha_frac;
             ts.one_plus_half_pow = s->dc.zc.one_plus_half_pow;
             // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own

@@ -58,7 +58,7 @@ struct WorkItem {
 // to chunks of kObChunk messages that the workgroup owns (one returning global atomic on the bucket's chunk counter
 // per group of chunks); `fill` says how many messages a chunk holds (lines fill in order, only a workgroup's last
 // line of a bucket can be partial).
-constexpr uint32_t kObLine = 8;                      // messages per staged line (64 bytes)
+constexpr uint32_t kObLine = 8;                      // messages per staged line (64 bytes) = 1 << kObLineLog2
 constexpr uint32_t kObChunk = 128;                   // messages per chunk (1 KiB)
 constexpr uint32_t kObLinesPerChunk = kObChunk / kObLine;
 constexpr uint32_t kObGroup = 4;                     // chunks a workgroup takes from a bucket's share at a time (one returning global
@@ -74,7 +74,9 @@ constexpr uint32_t kObNoLine = 0xffffffffu;
 // 64 claims are outstanding.  (With one line per bucket a wave whose lanes hold 19 messages for the same bucket needs
 // five claim-write-flush rounds per trip: measured, the cooling iterations ran 45 % slower than with direct atomics.)
 constexpr uint32_t kObRings = 2;        // the window's bucket and the next one (a window can straddle a bucket border)
-constexpr uint32_t kObRingLines = 16;   // 128 slots: the waves of a workgroup drift apart by a trip or two
+constexpr uint32_t kObRingLinesLog2 = 4;
+constexpr uint32_t kObRingLines = 1u << kObRingLinesLog2;   // 128 slots: the waves of a workgroup drift apart by a trip or two
+constexpr uint32_t kObLineLog2 = 3;
 struct Outbox {
     unsigned long long* pool;  // [total chunks][kObChunk] packed messages
     const uint32_t* chunk0;    // [B] first chunk of the bucket's share of the pool
@@ -233,9 +235,9 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
         }
     }
     if (has && !hot) slot = atomicAdd(L.head + b, 1u);
-    const uint32_t lines = hot ? kObRingLines : 1u;
-    const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + (slot / kObLine) % lines;  // staged line of the slot
-    const uint32_t round = slot / (kObLine * lines);
+    const uint32_t lines_log2 = hot ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
+    const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + ((slot >> kObLineLog2) & ((1u << lines_log2) - 1u));  // staged line of the slot
+    const uint32_t round = slot >> (kObLineLog2 + lines_log2);
     uint2* list = L.list + (threadIdx.x >> 6) * 64;
     bool pending = has;
     do {
@@ -344,14 +346,27 @@ constexpr int kFarTwoSided = 0, kFarExclusive = 2;
 constexpr float kFarRelax = 0.5f;
 
 // What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has
-// fewer than 2^32 path steps), and of the Zipf constants only the ones zipf_tabled reads are carried.  Fewer scalar
-// registers in the hot loop (the full DevConst + TileArgs do not fit the SGPR file and were spilled around the loop).
+// fewer than 2^32 path steps), and everything about a Zipf draw that depends on the jump length n alone comes from a
+// table: zipf_tab[n] = {zeta_n, eta_n}.  The steps of a tile have consecutive ranks, so their jump lengths are two
+// runs of consecutive n: the tile's 7 KB of the table stay in L2 while it runs, and the draw loses two fp64
+// divisions, one exponent loop and the 32-bit division of the zeta cache index (a third of its instructions; the
+// kernel is bound by VALU issue).
 struct TileSampler {
-    const double2* zeta_denom;
-    uint32_t space, space_max, space_quant;
-    int omt_e, alpha_e;
-    double omt_frac, alpha_frac, one_plus_half_pow;
+    const double2* zipf_tab;  // [min(space, longest path) + 1]
+    uint32_t space;
+    int alpha_e;
+    double alpha_frac, one_plus_half_pow;
 };
+
+// zipf_tab[n] for every jump length: the zeta cache entry the reference would look up (path_sgd_layout.cpp:208-212)
+// and eta of dirty_zipfian_int_distribution, by the operations of zipf_tabled() in the same order — the same bits
+__global__ void zipf_tab_kernel(const double2* zeta_denom, uint32_t space_max, uint32_t space_quant, int omt_e, double omt_frac, uint32_t n_entries, double2* out) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_entries) return;
+    const double2 zd = zeta_denom[n > space_max ? space_max + (n - space_max) / space_quant + 1 : n];
+    const double eta = (1.0 - pow_split(2.0 / (double)n, omt_e, omt_frac)) / zd.y;
+    out[n] = make_double2(zd.x, eta);
+}
 
 // uniform_below for a range below 2^32: the same Lemire draw as pgsgd_math.hpp (same draws, same result), with the
 // 64 x 32-bit products written out
@@ -368,25 +383,25 @@ __device__ __forceinline__ uint32_t uniform_below32(Xoshiro256Plus& g, uint32_t 
     return (uint32_t)(((x >> 32) * range + (((x & 0xffffffffull) * range) >> 32)) >> 32);
 }
 
-// dirty-Zipf draw of zipf_tabled() from the trimmed constants: the same operations in the same order
-__device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampler& ts, uint32_t n, double zeta_n, double denom) {
-    const double eta = (1.0 - pow_split(2.0 / (double)n, ts.omt_e, ts.omt_frac)) / denom;
+// dirty-Zipf draw of zipf_tabled() with eta from the table: the same operations in the same order
+__device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampler& ts, uint32_t n, double zeta_n, double eta) {
     const double u = canonical(g);
     const double uz = u * zeta_n;
     if (uz < 1.0) return 1;
     if (uz < ts.one_plus_half_pow) return 2;
     const double v = 1.0 + (double)n * pow_split(eta * u - eta + 1.0, ts.alpha_e, ts.alpha_frac);
-    uint64_t r = (v >= 1.0 && v < 1.8446744073709552e19) ? (uint64_t)v : 1;
+    // (uint64_t)v clamped to [1, n] with n < 2^32: whatever does not fit 32 bits is clamped to n either way
+    uint32_t r = v >= 1.0 ? (v < 4294967296.0 ? (uint32_t)v : 0xffffffffu) : 1u;  // (NaN -> 1, as in zipf_tabled)
     if (r < 1) r = 1;
     if (r > n) r = n;
-    return (uint32_t)r;
+    return r;
 }
 
 // a term whose first step is picked, whose Zipf/uniform and direction coins are drawn (path_sgd_layout.cpp:205-206) and
 // whose Zipf table entry is on its way
 struct PickedTerm {
     uint4 ra;          // first step's record
-    double2 zd;        // {zeta_n, 1 - zeta2/zeta_n} for the jump
+    double2 zd;        // {zeta_n, eta_n} for the jump
     uint32_t s_rank, jump;
     bool valid, zipf, back;
 };
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         Kw.back = (Kw.s_rank > 0 && coin(rng)) || Kw.s_rank == cnt - 1;
                         const uint32_t room = Kw.back ? Kw.s_rank : cnt - Kw.s_rank - 1;
                         Kw.jump = ts.space < room ? ts.space : room;
-                        Kw.zd = ts.zeta_denom[Kw.jump > ts.space_max ? ts.space_max + (Kw.jump - ts.space_max) / ts.space_quant + 1 : Kw.jump];
+                        Kw.zd = ts.zipf_tab[Kw.jump];
                     }
                 }
                 return Kw;
@@ -573,11 +588,13 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         wa = load_word<COORD_LOAD>(c.coords, end_a);
                         wb = Qr.from_global ? ((Qr.flips & 2u) ? Qr.snap.y : Qr.snap.x) : load_word<COORD_LOAD>(c.coords, end_b);
                     }
-                    const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;
-                    const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+                    // (float)(a - b) of two 32-bit fields, through fp64: the difference is exact there and is rounded once, as
+                    // the conversion from a 64-bit integer is — four instructions instead of fifteen
+                    const float dx = (float)((double)(uint32_t)wa - (double)(uint32_t)wb) * c.xf.inv_scale;
+                    const float dy = (float)((double)(uint32_t)(wa >> 32) - (double)(uint32_t)(wb >> 32)) * c.xf.inv_scale;
                     float r_x, r_y, abs_delta;
                     const bool one_sided = FAR == kFarExclusive && !in_b;
-                    term_displacement(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : far_mu_cap);
+                    term_displacement<true>(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : far_mu_cap);
                     if (one_sided) {
                         r_x *= 2.0f;
                         r_y *= 2.0f;
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
                     fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
-                    const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                    const int64_t qx = (int64_t)(int32_t)floorf(fx), qy = (int64_t)(int32_t)floorf(fy);  // (clamped to the 32-bit range above)
                     // a step that rounds to no quantum adds zero: nothing to send, in particular no message
                     // for a far partner (most far terms of the late iterations, where eta / d^2 is tiny)
                     if ((qx | qy) != 0) {
