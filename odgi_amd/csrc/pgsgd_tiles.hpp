@@ -221,18 +221,19 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
     const uint64_t below = (1ull << lane) - 1ull;
     const uint32_t r = b - L.ring_b0;  // hot ring of the bucket, if it has one
     const bool hot = has && r < kObRings;
-    // claim a slot: hot rings with one LDS atomic per wave and ring, ordinary buckets with one per lane
+    // claim a slot: the hot rings with one LDS instruction per wave (lane rr claims for ring rr what the wave's lanes
+    // need of it), ordinary buckets with one atomic per lane
+    static_assert(kObRings == 2, "the claim below is written for two hot rings");
     uint32_t slot = 0;
-#pragma unroll
-    for (uint32_t rr = 0; rr < kObRings; ++rr) {
-        const uint64_t m = __ballot(hot && r == rr);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(L.head + L.n_buckets + rr, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (hot && r == rr) slot = base + (uint32_t)__popcll(m & below);
-        }
+    const uint64_t m0 = __ballot(hot && r == 0), m1 = __ballot(hot && r == 1);
+    if (m0 | m1) {  // wave-uniform
+        const uint32_t want = lane == 0 ? (uint32_t)__popcll(m0) : (uint32_t)__popcll(m1);
+        uint32_t base = 0;
+        if (lane < kObRings && want) base = atomicAdd(L.head + L.n_buckets + lane, want);
+        const uint32_t base0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), base1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
+        const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));  // lanes below this one in the mask
+        const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        slot = r == 0 ? base0 + rank0 : base1 + rank1;
     }
     if (has && !hot) slot = atomicAdd(L.head + b, 1u);
     const uint32_t lines_log2 = hot ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
@@ -368,19 +369,34 @@ __global__ void zipf_tab_kernel(const double2* zeta_denom, uint32_t space_max, u
     out[n] = make_double2(zd.x, eta);
 }
 
-// uniform_below for a range below 2^32: the same Lemire draw as pgsgd_math.hpp (same draws, same result), with the
-// 64 x 32-bit products written out
-__device__ __forceinline__ uint32_t uniform_below32(Xoshiro256Plus& g, uint32_t range) {
-    uint64_t x = g.next();
-    uint64_t low = x * range;
-    if (low < range) {
-        const uint64_t threshold = (0 - (uint64_t)range) % range;
-        while (low < threshold) {
-            x = g.next();
-            low = x * range;
+// The tile kernel's draws.  A lane's stream yields TWO 64-bit words per term (the per-lane kernel and the reference
+// worker draw five or six: one per coin).  Same distributions, fewer generator steps — the kernel is bound by VALU
+// issue, and a Xoshiro256+ step is 15 instructions on 32-bit lanes:
+//   word 1  bits 63..32  the first step, uniform in the tile: Lemire's multiply-and-reject on 32 bits (a rejected word
+//                        is redrawn whole)
+//           bit 31       Zipf or uniform partner (path_sgd_layout.cpp:205; ignored in a cooling iteration)
+//           bit 30       direction of the Zipf jump (:206)
+//           bit 29, 28   which end of the first step's node, of the partner's (:253, :262)
+//           bits 27..14, 13..0   rounding dither of the x and y steps, 14 bits each
+//   word 2  Zipf partner: the variate of generate_canonical, as in the reference's distribution;
+//           uniform partner (:235-237): Lemire on bits 63..32 over the path's step count (< 2^32 in a tiled session)
+// All fields are disjoint bits of one equidistributed 64-bit output, hence independent fair coins / uniforms; the
+// generator's weak lowest bits only reach the low end of the y dither.  The oracle draws the same words
+// (orc_tile_pick_first / orc_tile_partner) and tests/test_oracle.py compares the term distribution with the
+// reference-order sampler's.
+constexpr uint32_t kDitherBits = 14;
+__device__ __forceinline__ uint32_t below32_hi(Xoshiro256Plus& g, uint32_t range, uint32_t& low_half) {
+    uint64_t w = g.next();
+    uint64_t m = (uint64_t)(uint32_t)(w >> 32) * range;
+    if ((uint32_t)m < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while ((uint32_t)m < threshold) {
+            w = g.next();
+            m = (uint64_t)(uint32_t)(w >> 32) * range;
         }
     }
-    return (uint32_t)(((x >> 32) * range + (((x & 0xffffffffull) * range) >> 32)) >> 32);
+    low_half = (uint32_t)w;
+    return (uint32_t)(m >> 32);
 }
 
 // dirty-Zipf draw of zipf_tabled() with eta from the table: the same operations in the same order
@@ -403,6 +419,7 @@ struct PickedTerm {
     uint4 ra;          // first step's record
     double2 zd;        // {zeta_n, eta_n} for the jump
     uint32_t s_rank, jump;
+    uint32_t flags;    // low half of the term's first word: coins and dither
     bool valid, zipf, back;
 };
 
@@ -513,16 +530,16 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 PickedTerm Kw;
                 Kw.valid = false;
                 if (worker && j < trips && threadIdx.x + j * lanes < n_tile_terms) {
-                    // first step: uniform inside the tile; then the reference's coins (path_sgd_layout.cpp:205-206)
+                    // first step: uniform inside the tile; the reference's coins (path_sgd_layout.cpp:205-206) from the same word
                     Kw.valid = true;
-                    const uint32_t ka = uniform_below32(rng, t.n);  // offset inside the tile
+                    const uint32_t ka = below32_hi(rng, t.n, Kw.flags);  // offset inside the tile
                     Kw.ra = trec[ka];
                     Kw.s_rank = t0 + ka - pstart;
-                    Kw.zipf = COOLING || coin(rng);
+                    Kw.zipf = COOLING || (Kw.flags >> 31);
                     Kw.back = false;
                     Kw.jump = 0;
                     if (Kw.zipf) {
-                        Kw.back = (Kw.s_rank > 0 && coin(rng)) || Kw.s_rank == cnt - 1;
+                        Kw.back = (Kw.s_rank > 0 && ((Kw.flags >> 30) & 1u)) || Kw.s_rank == cnt - 1;
                         const uint32_t room = Kw.back ? Kw.s_rank : cnt - Kw.s_rank - 1;
                         Kw.jump = ts.space < room ? ts.space : room;
                         Kw.zd = ts.zipf_tab[Kw.jump];
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 PendingTerm Qw;
                 Qw.valid = false;
                 if (Kr.valid) {
-                    // partner by the reference's rule (:207-237), then the two end choices (:253,262)
+                    // partner by the reference's rule (:207-237) from the term's second word; the two end choices (:253,262)
                     Qw.valid = true;
                     Qw.ra = Kr.ra;
                     uint32_t b_rank;
@@ -542,11 +559,11 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         const uint32_t z = zipf_tile(rng, ts, Kr.jump, Kr.zd.x, Kr.zd.y);
                         b_rank = Kr.back ? Kr.s_rank - z : Kr.s_rank + z;
                     } else {
-                        b_rank = uniform_below32(rng, cnt);
+                        uint32_t unused;
+                        b_rank = below32_hi(rng, cnt, unused);
                     }
-                    const uint64_t draw_a = rng.next(), draw_b = rng.next();
-                    Qw.flips = (uint32_t)(draw_a >> 63) | ((uint32_t)(draw_b >> 63) << 1);
-                    Qw.dither = (uint32_t)draw_a;
+                    Qw.flips = ((Kr.flags >> 29) & 1u) | (((Kr.flags >> 28) & 1u) << 1);
+                    Qw.dither = Kr.flags & ((1u << 2 * kDitherBits) - 1u);
                     // the partner's record: the tile's LDS copy when it is a step of the tile, otherwise ONE 32-byte gather
                     // that also brings the coordinates both ends of its node had at the last snapshot
                     const uint32_t kb = pstart + b_rank;
@@ -600,8 +617,8 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         r_y *= 2.0f;
                     }
                     dmax = fmaxf(dmax, abs_delta);
-                    const float ux = (float)(Qr.dither & 0xffffu) * (1.0f / 65536.0f);
-                    const float uy = (float)(Qr.dither >> 16) * (1.0f / 65536.0f);
+                    const float ux = (float)(Qr.dither >> kDitherBits) * (1.0f / (float)(1u << kDitherBits));
+                    const float uy = (float)(Qr.dither & ((1u << kDitherBits) - 1u)) * (1.0f / (float)(1u << kDitherBits));
                     float fx = r_x * c.xf.scale;
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
@@ -752,18 +769,27 @@ __global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile
     Xoshiro256Plus rng;
     rng.seed(tile_stream_seed(c.seed_base, a.epoch, tile_index, lane));
     for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
-        Anchor an;
-        an.k = t.t0 + uniform_below(rng, t.n);
-        an.pstart = pstart;
-        an.cnt = cnt;
-        an.s_rank = an.k - pstart;
-        an.rec = c.recs[an.k];
-        const Term tm = sample_partner(c, an, a.cooling, rng, GlobalRecs{c.recs});
+        uint32_t flags;
+        const uint64_t k = t.t0 + below32_hi(rng, t.n, flags);
+        const uint64_t s_rank = k - pstart;
+        uint64_t b_rank;
+        if (a.cooling || (flags >> 31)) {
+            const bool back = (s_rank > 0 && ((flags >> 30) & 1u)) || s_rank == cnt - 1;
+            const uint64_t room = back ? s_rank : cnt - s_rank - 1;
+            const uint64_t jump = c.space < room ? c.space : room;
+            const double2 zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
+            const uint64_t z = zipf_tabled(rng, c.zc, jump, zd.x, zd.y);
+            b_rank = back ? s_rank - z : s_rank + z;
+        } else {
+            uint32_t unused;
+            b_rank = below32_hi(rng, (uint32_t)cnt, unused);
+        }
+        const uint64_t kb = pstart + b_rank;
         uint64_t* o = out + (q - term_begin) * 4;
-        o[0] = an.k;
-        o[1] = tm.kb;
-        o[2] = tm.end_a & 1u;
-        o[3] = tm.end_b & 1u;
+        o[0] = k;
+        o[1] = kb;
+        o[2] = (c.recs[k].x ^ (flags >> 29)) & 1u;   // end offsets of the two node ends the term moves
+        o[3] = (c.recs[kb].x ^ (flags >> 28)) & 1u;
     }
 }
 

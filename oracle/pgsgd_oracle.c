@@ -205,22 +205,42 @@ static void orc_sample_partner(const orc_graph* g, const orc_params* p, const do
     t->pos_b = pos_b;
 }
 
-/* The tile kernel draws a term in two steps (pgsgd_tiles.hpp: pick_stage, partner_stage — a trip of its term loop
- * apart, so that the Zipf table entry is on its way meanwhile): the first step with the Zipf/uniform and direction coins
- * (:205-206), then the partner and the end choices.  A lane's stream yields its terms' draws in term order. */
-typedef struct orc_tile_pick { orc_anchor an; int zipf, back; uint64_t jump; } orc_tile_pick;
+/* The tile kernel's sampler (pgsgd_tiles.hpp: below32_hi, pick_stage, partner_stage).  Same term distribution as the
+ * reference worker's (:182-270), from TWO 64-bit words per term instead of one word per coin:
+ *   word 1  bits 63..32  first step, uniform in the tile (Lemire's method on 32 bits; a rejected word is redrawn whole)
+ *           bit 31 Zipf/uniform coin (:205), bit 30 direction coin (:206), bits 29/28 end choices (:253,262),
+ *           bits 27..14 / 13..0 rounding dither of the x / y step
+ *   word 2  Zipf: the generate_canonical variate; uniform partner (:235-237): Lemire on bits 63..32 over the path's
+ *           step count
+ * A lane's stream yields its terms' words in term order.  tests/test_oracle.py compares the distribution of these
+ * terms with orc_sample_partner's. */
+typedef struct orc_tile_pick { orc_anchor an; int zipf, back; uint64_t jump; uint32_t flags; } orc_tile_pick;
+
+static uint32_t orc_below32_hi(uint64_t s[4], uint32_t range, uint32_t* low_half) {
+    uint64_t w = orc_rng_next(s);
+    uint64_t m = (uint64_t)(uint32_t)(w >> 32) * range;
+    if ((uint32_t)m < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while ((uint32_t)m < threshold) {
+            w = orc_rng_next(s);
+            m = (uint64_t)(uint32_t)(w >> 32) * range;
+        }
+    }
+    *low_half = (uint32_t)w;
+    return (uint32_t)(m >> 32);
+}
 
 static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int cooling, uint64_t t0, uint32_t tn, uint32_t path,
                                 uint64_t s[4], orc_tile_pick* pk) {
     pk->an.pstart = g->path_first[path];
     pk->an.cnt = g->path_first[path + 1] - pk->an.pstart;
-    pk->an.k = t0 + orc_uniform_u64(s, tn);
+    pk->an.k = t0 + orc_below32_hi(s, tn, &pk->flags);
     pk->an.s_rank = pk->an.k - pk->an.pstart;
-    pk->zipf = cooling || orc_flip(s);                                                       /* :205 */
+    pk->zipf = cooling || (pk->flags >> 31);                                                  /* :205 */
     pk->back = 0;
     pk->jump = 0;
     if (pk->zipf) {
-        pk->back = (pk->an.s_rank > 0 && orc_flip(s)) || pk->an.s_rank == pk->an.cnt - 1;      /* :206 */
+        pk->back = (pk->an.s_rank > 0 && ((pk->flags >> 30) & 1u)) || pk->an.s_rank == pk->an.cnt - 1;   /* :206 */
         const uint64_t room = pk->back ? pk->an.s_rank : pk->an.cnt - pk->an.s_rank - 1;
         pk->jump = p->space < room ? p->space : room;
     }
@@ -234,17 +254,17 @@ static void orc_tile_partner(const orc_graph* g, const orc_params* p, const doub
         const uint64_t z_i = orc_zipf(s, pk->jump, p->theta, zetas[space]);
         b_rank = pk->back ? pk->an.s_rank - z_i : pk->an.s_rank + z_i;
     } else {
-        b_rank = orc_uniform_u64(s, pk->an.cnt);                                               /* :235-237 */
+        uint32_t unused;
+        b_rank = orc_below32_hi(s, (uint32_t)pk->an.cnt, &unused);                             /* :235-237 */
     }
     t->ka = pk->an.k;
     t->kb = pk->an.pstart + b_rank;
     const uint32_t h_a = g->step_handle[t->ka], h_b = g->step_handle[t->kb];
     uint64_t pos_a = g->step_pos[t->ka], pos_b = g->step_pos[t->kb];
     const uint32_t rev_a = h_a & 1u, rev_b = h_b & 1u;
-    const uint64_t draw_a = orc_rng_next(s);                                                 /* :253 */
-    t->dither = (uint32_t)draw_a;
-    if (draw_a >> 63) { pos_a += g->node_len[h_a >> 1]; t->off_a = !rev_a; } else { t->off_a = rev_a; }
-    if (orc_flip(s)) { pos_b += g->node_len[h_b >> 1]; t->off_b = !rev_b; } else { t->off_b = rev_b; }   /* :262 */
+    t->dither = pk->flags & 0x0fffffffu;   /* 14 + 14 bits */
+    if ((pk->flags >> 29) & 1u) { pos_a += g->node_len[h_a >> 1]; t->off_a = !rev_a; } else { t->off_a = rev_a; }   /* :253 */
+    if ((pk->flags >> 28) & 1u) { pos_b += g->node_len[h_b >> 1]; t->off_b = !rev_b; } else { t->off_b = rev_b; }   /* :262 */
     t->pos_a = pos_a;
     t->pos_b = pos_b;
 }
@@ -1226,8 +1246,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         /* far pulls are capped at kFarRelax / h: half a projection per launch in total (pgsgd_tiles.hpp) */
                         const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, in_b ? 1.0f : far_cap[colour] * 0.5f, &r_x, &r_y);
                         if (da > dmax) dmax = da;
-                        const float ux = (float)(t.dither & 0xffffu) * (1.0f / 65536.0f);
-                        const float uy = (float)(t.dither >> 16) * (1.0f / 65536.0f);
+                        const float ux = (float)(t.dither >> 14) * (1.0f / 16384.0f);
+                        const float uy = (float)(t.dither & 0x3fffu) * (1.0f / 16384.0f);
                         float fx = r_x * scale;
                         float fy = r_y * scale;
                         fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);

@@ -224,3 +224,41 @@ def test_tile_mirror_golden_regression(orc):
         assert np.array_equal(v, gv[f"tile_mirror/{k}"]), k
     ck = got["checksum"]
     assert (ck[0], ck[1]) == (ck[2], ck[3]) and got["far"][0] > 0 and got["n_windowless"][0] > 0
+
+
+def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
+    """The tile kernel's sampler takes its coins from the bits of one word (two words per term) where the reference
+    worker draws a word per coin.  Same distribution: partner offsets and end choices of the tile sampler's terms
+    against the reference-order sampler's (path_sgd_layout.cpp:182-270) on the same path, warm and cooling."""
+    from scipy.stats import chi2_contingency
+    g = ographs("DRB1-3123")  # 12 paths of ~3000 steps
+    lens = np.diff(g.path_first)
+    path = int(np.argmax(lens))
+    first, L = int(g.path_first[path]), int(lens[path])
+    p = orc.params(iter_max=30, min_term_updates=1, eps=0.01, eta_max=1.0, theta=0.99, space=3100, space_max=1000,
+                   space_quantization_step=100, cooling_start=0.5)
+    edges = np.array([1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 513, 1025, 1 << 20])
+    for cooling in (False, True):
+        ref = orc.trace_terms(g, p, 77, 256, 0, cooling, 6000).reshape(-1, 4).astype(np.int64)
+        ref = ref[g.step_path[ref[:, 0]] == path]                      # first step uniform over this path's steps
+        M = 400000
+        til = orc.tile_terms(g, p, 12345, 3, M, L, 0, 64, first, 0, L, path, cooling, capacity=M).astype(np.int64)
+        assert len(til) == M and len(ref) > 50000
+        assert til[:, 0].min() >= first and til[:, 0].max() < first + L and np.array_equal(g.step_path[til[:, 1]], g.step_path[til[:, 0]])
+
+        def table(t):
+            d = t[:, 1] - t[:, 0]
+            mag = np.digitize(np.abs(d), edges)                        # 0: the same step (uniform partner only)
+            return np.bincount(mag * 2 + (d < 0), minlength=2 * (len(edges) + 1))
+        counts = np.stack([table(ref), table(til)])
+        counts = counts[:, counts.sum(axis=0) >= 20]
+        chi2, pval, dof, _ = chi2_contingency(counts)
+        assert pval > 1e-3, (cooling, chi2, dof, pval)
+        # first steps: uniform over the path in both
+        pos = np.stack([np.bincount((t[:, 0] - first) * 16 // L, minlength=16) for t in (ref, til)])
+        assert chi2_contingency(pos)[1] > 1e-3
+        # end choices: two independent fair coins (offset = orientation xor coin; the orientation is a step property)
+        rev_a, rev_b = g.step_handle[til[:, 0]] & 1, g.step_handle[til[:, 1]] & 1
+        ca, cb = til[:, 2] ^ rev_a, til[:, 3] ^ rev_b
+        joint = np.bincount(ca * 2 + cb, minlength=4)
+        assert np.all(np.abs(joint - M / 4) < 5 * np.sqrt(M * 3 / 16)), joint
