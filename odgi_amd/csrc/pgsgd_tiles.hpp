@@ -93,14 +93,14 @@ struct Outbox {
 __host__ __device__ inline uint32_t outbox_qbits(uint32_t shift) { return (64u - shift) / 2u < 25u ? (64u - shift) / 2u : 25u; }
 
 // message = end offset in the bucket | x step << shift | y step << (shift + qbits), steps in two's complement.
-// `delta` is the 64-bit word the per-lane kernel would add atomically: qx + (qy << 32) with signed 32-bit qx, qy.
-__device__ __forceinline__ bool outbox_pack(const Outbox& ob, uint32_t end, uint64_t delta, uint64_t& msg) {
-    const int32_t qx = (int32_t)(uint32_t)delta;
-    const int32_t qy = (int32_t)(uint32_t)((delta - (uint64_t)(int64_t)qx) >> 32);
-    const int32_t lim = 1 << (ob.qbits - 1);
-    const uint64_t mask = (1ull << ob.qbits) - 1ull;
-    msg = (uint64_t)(end & ((1u << ob.shift) - 1u)) | (((uint64_t)(int64_t)qx & mask) << ob.shift) | (((uint64_t)(int64_t)qy & mask) << (ob.shift + ob.qbits));
-    return qx >= -lim && qx < lim && qy >= -lim && qy < lim;
+// (qx, qy) are the signed 32-bit steps of the two fields; the word the per-lane kernel would add atomically is
+// outbox_delta(qx, qy) = qx + (qy << 32) in 64-bit arithmetic.
+__device__ __forceinline__ uint64_t outbox_delta(int32_t qx, int32_t qy) { return (uint64_t)(int64_t)qx + ((uint64_t)(int64_t)qy << 32); }
+__device__ __forceinline__ bool outbox_pack(const Outbox& ob, uint32_t end, int32_t qx, int32_t qy, uint64_t& msg) {
+    const uint32_t lim = 1u << (ob.qbits - 1);
+    const uint32_t mask = (1u << ob.qbits) - 1u;  // qbits <= 25
+    msg = (uint64_t)(end & ((1u << ob.shift) - 1u)) | ((uint64_t)((uint32_t)qx & mask) << ob.shift) | ((uint64_t)((uint32_t)qy & mask) << (ob.shift + ob.qbits));
+    return (((uint32_t)qx + lim) | ((uint32_t)qy + lim)) >> ob.qbits == 0;  // both in [-lim, lim)
 }
 __device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg, uint32_t& end_off) {
     end_off = (uint32_t)msg & ((1u << ob.shift) - 1u);
@@ -129,8 +129,7 @@ struct TileArgs {
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
     const uint4* recs2;                // [2S] step records with the coordinate snapshot: {handle,len,pos}, {w_first, w_second}
-    uint32_t experiment;               // PGSGD_TILE_EXP (profiling only, results invalid): 1 = far updates are dropped,
-                                       // 2 = staged but never written out
+    uint32_t experiment;               // PGSGD_TILE_EXP (profiling only, results invalid): 1 = far updates are dropped
     Outbox ob;
 };
 
@@ -183,17 +182,23 @@ __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
 // with an LDS atomic; the lane that claims line kObLinesPerGroup replaces the group, the others wait for it without
 // adding to the word (every lane strays at most once per replacement, so the 10-bit field cannot overflow).
 __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b) {
+    // (No spin loop of its own for a lane that finds the group being replaced: the replacing lane may be in the same
+    // wave, and a wave runs the two sides of a branch one after the other — a lane spinning in an inner loop would
+    // wait for a lane that is not running.  The poll sits at the top of the one loop instead: every lane still in it
+    // reaches the loop's end before any starts the next pass, and the replacing lane finishes within its pass.)
+    bool strayed = false;
     for (;;) {
-        const uint32_t cur = __hip_atomic_load(L.line + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((cur >> kObUsedBits) == kObOverflow) return kObNoLine;
-        if ((cur & kObUsedMask) > kObLinesPerGroup) {  // being replaced
-            __builtin_amdgcn_s_sleep(1);
+        if (strayed && (__hip_atomic_load(L.line + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
+            __builtin_amdgcn_s_sleep(1);  // still being replaced (by a lane of another wave)
             continue;
         }
         const uint32_t lp = atomicAdd(L.line + b, 1u);
         const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // first chunk of the group, lines claimed in the group
-        if (chunk == kObOverflow) continue;  // became so between the poll and the add
-        if (used < kObLinesPerGroup) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
+        if (used < kObLinesPerGroup && chunk < kObOverflow) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
+        if (chunk == kObOverflow) {  // the bucket's share of the pool is used up (sticky; the count field is put back so that it cannot run over)
+            atomicExch(L.line + b, kObOverflow << kObUsedBits);
+            return kObNoLine;
+        }
         if (used == kObLinesPerGroup) {  // this lane replaces the full group and takes the new one's first line
             if (chunk != kObNone)
                 for (uint32_t k = 0; k < kObGroup; ++k) ob.fill[L.chunk0[b] + chunk + k] = kObChunk;
@@ -205,16 +210,17 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
             atomicExch(L.line + b, (nc << kObUsedBits) | 1u);
             return (L.chunk0[b] + nc) * kObLinesPerChunk;
         }
+        strayed = true;  // the group is being replaced: every lane adds to the word at most once per replacement, so the 10-bit field holds
     }
 }
 
 // Append one message per lane that has one.  Called by all 64 lanes of a wave together (converged).
-__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, uint64_t delta, bool dry = false) {
+__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, int32_t qx, int32_t qy) {
     if (!__ballot(has)) return;
     const uint32_t b = end >> ob.shift;
     uint64_t packed = 0;
-    if (has && !outbox_pack(ob, end, delta, packed)) {  // a step too wide for the packed form (never seen with the far cap): the
-        atomicAdd(ob.spill + end, (unsigned long long)delta);  // spill words, which the drain adds with the messages
+    if (has && !outbox_pack(ob, end, qx, qy, packed)) {  // a step too wide for the packed form (never seen with the far cap): the
+        atomicAdd(ob.spill + end, (unsigned long long)outbox_delta(qx, qy));  // spill words, which the drain adds with the messages
         has = false;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -253,7 +259,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
         }
         const uint64_t mask = __ballot(completes);
         if (mask) {  // wave-uniform: the lines completed in this round, kObLine lanes per line
-            const uint32_t dst = (completes && !dry) ? outbox_next_line(ob, L, b) : 0u;
+            const uint32_t dst = completes ? outbox_next_line(ob, L, b) : 0u;
             if (completes) list[__popcll(mask & below)] = make_uint2(src, dst);
             // the wave's LDS operations execute in order; keep the compiler from moving the reads below above the writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -265,9 +271,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
                 if (e < n) {
                     const uint2 it = list[e];
                     const uint64_t m = L.stage[it.x * kObLine + piece];
-                    if (dry) {
-                        asm volatile("" ::"v"((uint32_t)m), "v"((uint32_t)(m >> 32)));
-                    } else if (it.y != kObNoLine) {
+                    if (it.y != kObNoLine) {
                         ob.pool[(uint64_t)it.y * kObLine + piece] = m;
                     } else {  // no room left in the pool: the spill words, added to the coordinates by the drain
                         const uint32_t mb = it.x < L.n_buckets ? it.x : L.ring_b0 + (it.x - L.n_buckets) / kObRingLines;  // the staged line's bucket
@@ -576,11 +580,11 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 }
                 return Qw;
             };
-            struct FarMessages { uint64_t delta; uint32_t end_a, end_b; bool to_a, to_b; };
+            struct FarMessages { int32_t qx, qy; uint32_t end_a, end_b; bool to_a, to_b; };
             auto finish_stage = [&](const PendingTerm Qr) -> FarMessages {
                 bool msg_a = false, msg_b = false;
                 uint32_t end_a = 0, end_b = 0;
-                uint64_t delta = 0;
+                int32_t mqx = 0, mqy = 0;
                 if (Qr.valid) {
                     // (component by component: a select between the two structs would be done on their ADDRESSES and force them into memory)
                     const uint4 rb = make_uint4(Qr.from_global ? Qr.rb_g.x : Qr.rb_l.x, Qr.from_global ? Qr.rb_g.y : Qr.rb_l.y,
@@ -623,12 +627,14 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
                     fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
-                    const int64_t qx = (int64_t)(int32_t)floorf(fx), qy = (int64_t)(int32_t)floorf(fy);  // (clamped to the 32-bit range above)
+                    const int32_t qx = (int32_t)floorf(fx), qy = (int32_t)floorf(fy);  // (clamped to the 32-bit range above)
                     // a step that rounds to no quantum adds zero: nothing to send, in particular no message
                     // for a far partner (most far terms of the late iterations, where eta / d^2 is tiny)
                     if ((qx | qy) != 0) {
                         n_far += (in_b || one_sided) ? 0u : 1u;
-                        delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                        mqx = qx;
+                        mqy = qy;
+                        const uint64_t delta = outbox_delta(qx, qy);
                         if (in_b) atomicAdd(reinterpret_cast<unsigned long long*>(win + lb), (unsigned long long)delta);
                         else msg_b = !one_sided;
                         if (in_a) atomicAdd(reinterpret_cast<unsigned long long*>(win + la), (unsigned long long)(0ull - delta));
@@ -636,11 +642,11 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     }
                 }
                 if (ta.experiment & 1u) msg_a = msg_b = false;
-                return FarMessages{delta, end_a, end_b, msg_a, msg_b};
+                return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
             };
             auto send = [&](const FarMessages m) {
-                outbox_push(ta.ob, L, m.to_b, m.end_b, m.delta, (ta.experiment & 2u) != 0);
-                if (!LOCAL) outbox_push(ta.ob, L, m.to_a, m.end_a, 0ull - m.delta);
+                outbox_push(ta.ob, L, m.to_b, m.end_b, m.qx, m.qy);
+                if (!LOCAL) outbox_push(ta.ob, L, m.to_a, m.end_a, -m.qx, -m.qy);
             };
             for (uint32_t j = 0; j <= trips + 1; j += 2) {  // (a trip past the end finds nothing valid and does nothing)
                 // one trip: everything the previous trip requested is consumed FIRST (one wait, for loads that have been
@@ -709,21 +715,24 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) acc[i] = 0;
     __syncthreads();
     const uint32_t handed = ob.next[b], cap = ob.cap[b];
-    const uint64_t n_slots = (uint64_t)(handed < cap ? handed : cap) * kObChunk;
     const uint64_t first = (uint64_t)ob.chunk0[b] * kObChunk;
     const uint64_t base = ((uint64_t)b << ob.shift) + ((uint64_t)part << part_shift);
-    // four independent 16-byte loads (two messages each) per lane in flight before the LDS adds (one workgroup streams ~6 MB)
-    const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(ob.pool);
-    const uint64_t n_pairs = n_slots / 2, first_pair = first / 2;
+    // One wave per chunk and pass: a chunk is 64 pairs of messages, one 16-byte load per lane, and how much of it is
+    // filled is a single (wave-uniform) word.  Four chunks per wave in flight before the LDS adds.
+    const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(ob.pool) + first / 2;
+    const uint32_t n_chunks = handed < cap ? handed : cap;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint32_t part_off = part << part_shift;
-    for (uint64_t i0 = threadIdx.x; i0 < n_pairs; i0 += 4ull * blockDim.x) {
+    const uint32_t* fill = ob.fill + ob.chunk0[b];
+    static_assert(kObChunk == 128, "one chunk = 64 lanes x 2 messages");
+    for (uint32_t c0 = wave; c0 < n_chunks; c0 += 4 * waves) {
         ulonglong2 m[4];
         bool ok[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint64_t i = i0 + (uint64_t)k * blockDim.x;
-            ok[k] = i < n_pairs && (uint32_t)((2 * i) % kObChunk) < ob.fill[ob.chunk0[b] + (uint32_t)((2 * i) / kObChunk)];  // fill is a whole number of lines
-            if (ok[k]) m[k] = pairs[first_pair + i];
+            const uint32_t c = c0 + (uint32_t)k * waves;
+            ok[k] = c < n_chunks && 2 * lane < fill[c < n_chunks ? c : 0];  // (fill is a whole number of 8-message lines)
+            if (ok[k]) m[k] = pairs[(uint64_t)c * (kObChunk / 2) + lane];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
