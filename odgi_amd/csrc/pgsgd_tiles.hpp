@@ -718,24 +718,37 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     const uint64_t first = (uint64_t)ob.chunk0[b] * kObChunk;
     const uint64_t base = ((uint64_t)b << ob.shift) + ((uint64_t)part << part_shift);
     // One wave per chunk and pass: a chunk is 64 pairs of messages, one 16-byte load per lane, and how much of it is
-    // filled is a single (wave-uniform) word.  Four chunks per wave in flight before the LDS adds.
+    // filled is a single (wave-uniform) word.  Eight chunks per wave in flight before the LDS adds.
     const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(ob.pool) + first / 2;
     const uint32_t n_chunks = handed < cap ? handed : cap;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint32_t part_off = part << part_shift;
     const uint32_t* fill = ob.fill + ob.chunk0[b];
     static_assert(kObChunk == 128, "one chunk = 64 lanes x 2 messages");
-    for (uint32_t c0 = wave; c0 < n_chunks; c0 += 4 * waves) {
-        ulonglong2 m[4];
-        bool ok[4];
+    // (the fill words of a pass are loaded during the pass before: a pass then waits for memory once, not twice)
+    constexpr int kU = 8;  // chunks per wave and pass
+    uint32_t f[kU];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kU; ++k) {
+        const uint32_t c = wave + (uint32_t)k * waves;
+        f[k] = c < n_chunks ? fill[c] : 0u;
+    }
+    for (uint32_t c0 = wave; c0 < n_chunks; c0 += kU * waves) {
+        ulonglong2 m[kU];
+        bool ok[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
             const uint32_t c = c0 + (uint32_t)k * waves;
-            ok[k] = c < n_chunks && 2 * lane < fill[c < n_chunks ? c : 0];  // (fill is a whole number of 8-message lines)
+            ok[k] = 2 * lane < f[k];  // (0 past the end; fill is a whole number of 8-message lines)
             if (ok[k]) m[k] = pairs[(uint64_t)c * (kObChunk / 2) + lane];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kU; ++k) {
+            const uint32_t c = c0 + (uint32_t)(kU + k) * waves;
+            f[k] = c < n_chunks ? fill[c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
             if (!ok[k]) continue;
             uint32_t off;
             uint64_t d = outbox_unpack(ob, m[k].x, off);
