@@ -695,12 +695,24 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
 // partner outside the window costs one gather, not a record gather plus a dependent coordinate load.  Whole-line
 // writes (writing only the second halves costs a read-for-ownership of every line: 0.70 against 0.47 ms at 4.7e7
 // steps, profiles/r02/microbench_r2b.jsonl).
-__global__ void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 r = recs[k];
-        const uint4 pr = *reinterpret_cast<const uint4*>(coords + (r.x & ~1u));  // both ends of the node, 16-byte aligned
-        recs2[2 * k] = r;
-        recs2[2 * k + 1] = (r.x & 1u) ? make_uint4(pr.z, pr.w, pr.x, pr.y) : pr;
+__global__ __launch_bounds__(256) void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
+    // A lane builds the record of one step; the 8 KiB a workgroup builds go out through LDS so that one store
+    // instruction writes 64 consecutive 16-byte pieces — whole 64-byte units.  (A lane storing its own two halves
+    // writes half of every unit per instruction.)
+    __shared__ uint4 stage[512];
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_steps; k0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = k0 + threadIdx.x;
+        if (k < n_steps) {
+            const uint4 r = recs[k];
+            const uint4 pr = *reinterpret_cast<const uint4*>(coords + (r.x & ~1u));  // both ends of the node, 16-byte aligned
+            stage[2 * threadIdx.x] = r;
+            stage[2 * threadIdx.x + 1] = (r.x & 1u) ? make_uint4(pr.z, pr.w, pr.x, pr.y) : pr;
+        }
+        __syncthreads();
+        const uint64_t left = n_steps - k0, pieces = left < 256 ? 2 * left : 512;
+        if (threadIdx.x < pieces) recs2[2 * k0 + threadIdx.x] = stage[threadIdx.x];
+        if (threadIdx.x + 256 < pieces) recs2[2 * k0 + 256 + threadIdx.x] = stage[256 + threadIdx.x];
+        __syncthreads();
     }
 }
 
