@@ -554,7 +554,14 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
         const bool force = getenv("PGSGD_TILE_FORCE") != nullptr;
-        if ((force || cap >= 4 * cu_lanes) && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
+        // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
+        bool short_paths = true;
+        for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
+            if (g->path_first[q + 1] > g->path_first[q]) {
+                const uint64_t last = g->path_first[q + 1] - 1;
+                short_paths = g->step_pos[last] + g->node_len[g->step_handle[last] >> 1] < (1ull << 52);
+            }
+        if ((force || cap >= 4 * cu_lanes) && short_paths && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
             std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
