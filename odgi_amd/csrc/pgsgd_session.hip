@@ -489,6 +489,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
         s->ob.shift = ob_shift;
         s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
+        if (const char* e = getenv("PGSGD_OUTBOX_QBITS"))  // test knob: narrow packed steps, so that most messages take the path of a step too wide for the packed form
+            s->ob.qbits = (uint32_t)std::min<int>((int)s->ob.qbits, std::max(2, atoi(e)));
         s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
         s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
         s->ob_bucket_steps.assign(s->ob.n_buckets, 0);

@@ -840,13 +840,18 @@ def _ragged_graph(oa):
     return oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
 
 
-@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged"])
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
     staging, private-copy reads, the far-partner learning-rate cap and its pull counts, steps that round to
     no quantum, the flush.  `synthetic` is a sorted graph (every tile has a window), DRB1-3123 has stretches
-    whose tiles do not fit a window (every end in global memory)."""
+    whose tiles do not fit a window (every end in global memory).  `synthetic-narrow-messages` packs the steps of an
+    outbox message into 6 bits each: most far updates are then too wide for a message and take the spill words, which
+    the drain adds with the messages — the same sums."""
+    if graph_name == "synthetic-narrow-messages":
+        monkeypatch.setenv("PGSGD_OUTBOX_QBITS", "6")
+        graph_name = "synthetic"
     monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
     monkeypatch.setenv("PGSGD_TILE_REGION", "64")
     monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")

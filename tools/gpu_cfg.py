@@ -25,10 +25,11 @@ for cfg in sys.argv[4:]:
                 s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             s.sync()
             ms, _ = s.kernel_time()
+            aux = s.aux_time() if R else (0.0, 0.0)
             X, Y = s.download()
             lanes = s.n_streams
         rows.append((1e3 * p.min_term_updates * p.iter_max / ms, oa.path_stress(g, X, Y, 2_000_000, seed=1)))
         os.environ.pop("PGSGD_TILE_REGION", None); os.environ.pop("PGSGD_TILE_BLOCK", None)
     a = np.array(rows)
     print(json.dumps(dict(exp="tile_cfg", nodes=nodes, paths=paths, region=R, block=B, tiled=info["tiled"], work_items=info["n_work_items"], lanes=lanes,
-                          terms_per_s=float(a[:, 0].mean()), stress=[round(x, 4) for x in a[:, 1]], stress_mean=float(a[:, 1].mean()))), flush=True)
+                          terms_per_s=float(a[:, 0].mean()), stress=[round(x, 4) for x in a[:, 1]], stress_mean=float(a[:, 1].mean()), update_kernel_ms=ms, snapshot_ms=aux[0], drain_ms=aux[1])), flush=True)
