@@ -16,6 +16,11 @@
 #include <thread>
 #include <tuple>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "pgsgd_internal.hpp"
 
 namespace {
@@ -48,16 +53,39 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     if (!path || !out) return PGSGD_E_INVALID;
     *out = nullptr;
     pgsgd::PhaseTimer timer;
-    std::ifstream in(path, std::ios::binary | std::ios::ate);
-    if (!in) { set_error("cannot open '%s'", path); return PGSGD_E_IO; }
-    const std::streamoff size = in.tellg();
-    std::string buf;
-    try {
-        buf.resize((size_t)size);
-    } catch (...) { return PGSGD_E_NOMEM; }
-    in.seekg(0);
-    if (size > 0 && !in.read(&buf[0], size)) { set_error("cannot read '%s'", path); return PGSGD_E_IO; }
-    in.close();
+    // The file is mapped, not copied: the parse below reads every byte once or twice, from the page cache.
+    struct Mapping {
+        const char* p = nullptr;
+        size_t n = 0;
+        std::string fallback;  // pipes and other things that cannot be mapped are read
+        ~Mapping() { if (p && fallback.empty() && n) munmap(const_cast<char*>(p), n); }
+    } file;
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { set_error("cannot open '%s'", path); return PGSGD_E_IO; }
+        struct stat st;
+        void* m = MAP_FAILED;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m != MAP_FAILED) {
+                file.p = (const char*)m;
+                file.n = (size_t)st.st_size;
+                (void)madvise(m, file.n, MADV_SEQUENTIAL);
+            }
+        }
+        if (m == MAP_FAILED) {
+            try {
+                char chunk[1 << 16];
+                ssize_t r;
+                while ((r = read(fd, chunk, sizeof chunk)) > 0) file.fallback.append(chunk, (size_t)r);
+                if (r < 0) { close(fd); set_error("cannot read '%s'", path); return PGSGD_E_IO; }
+            } catch (...) { close(fd); return PGSGD_E_NOMEM; }
+            file.p = file.fallback.data();
+            file.n = file.fallback.size();
+        }
+        close(fd);
+    }
+    struct { const char* p; size_t n; const char* data() const { return p; } size_t size() const { return n; } } buf{file.p, file.n};
 
     timer.lap("gfa: read file");
     std::vector<Line> s_lines, l_lines, p_lines;
@@ -205,20 +233,24 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         for (auto& t : th) t.join();
     };
     // a token is what lies between commas; empty tokens and the placeholder "*" are not steps
-    auto for_each_token = [](const Chunk& c, auto&& fn) {
-        const char* p = c.b;
-        while (p < c.e) {
-            const char* cm = (const char*)memchr(p, ',', (size_t)(c.e - p));
-            const char* te = cm ? cm : c.e;
-            if (te > p && !(te - p == 1 && *p == '*'))
-                if (!fn(p, te)) return;
-            p = cm ? cm + 1 : c.e;
-        }
-    };
+    // pass 1: steps = tokens - empty tokens - "*" tokens, each counted by a loop without carried state (the compiler
+    // vectorises them; a memchr per 7-byte token costs more than the token)
     for_each_chunk([&](Chunk& c) {
-        uint64_t n = 0;
-        for_each_token(c, [&](const char*, const char*) { ++n; return true; });
-        c.steps = n;
+        const char* b = c.b;
+        const size_t n = (size_t)(c.e - c.b);
+        if (n == 0) { c.steps = 0; return; }
+        uint64_t commas = 0, empty = (b[0] == ',') + (b[n - 1] == ','), star = 0;
+        commas += (b[0] == ',') + (n > 1 && b[n - 1] == ',');
+        for (size_t i = 1; i + 1 < n; ++i) {  // one sweep: a comma, a comma after a comma, a "*" between commas
+            const bool cm = b[i] == ',', after = b[i - 1] == ',';
+            commas += cm;
+            empty += cm & after;
+            star += (b[i] == '*') & after & (b[i + 1] == ',');
+        }
+        if (n > 1) empty += (b[n - 1] == ',') & (b[n - 2] == ',');
+        star += (b[0] == '*') & (n == 1 || b[1] == ',');
+        if (n > 1) star += (b[n - 1] == '*') & (b[n - 2] == ',');
+        c.steps = commas + 1 - empty - star;
     });
     g->path_first.assign(P + 1, 0);
     {
@@ -236,7 +268,8 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     for_each_chunk([&](Chunk& c) {
         uint64_t k = c.first, bp = 0;
         const std::string& name = g->path_names[c.path];
-        for_each_token(c, [&](const char* p, const char* te) {
+        // the general form of a token, with the reference's error cases (gfa_to_handle.cpp:150-170)
+        auto slow_token = [&](const char* p, const char* te) {
             const char orient = te[-1];
             uint64_t id;
             if ((orient != '+' && orient != '-') || !parse_uint(p, te - 1, &id)) {
@@ -254,7 +287,28 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
             bp += g->node_len[id - 1];
             ++k;
             return true;
-        });
+        };
+        // the usual form — up to 18 digits, an orientation, a comma or the end — is parsed in one sweep over its bytes;
+        // anything else (empty tokens, "*", errors) goes through slow_token
+        const char* p = c.b;
+        while (p < c.e) {
+            const char* t = p;
+            uint64_t id = 0;
+            while (p < c.e && (unsigned)(*p - '0') < 10u && p - t < 18) id = id * 10 + (uint64_t)(*p++ - '0');
+            if (p > t && p < c.e && (*p == '+' || *p == '-') && (p + 1 == c.e || p[1] == ',') && id >= 1 && id <= N) {
+                g->step_path[k] = (uint32_t)c.path;
+                g->step_handle[k] = (uint32_t)(2 * (id - 1) + (*p == '-' ? 1 : 0));
+                bp += g->node_len[id - 1];
+                ++k;
+                p += 2;  // past the orientation and the comma
+                continue;
+            }
+            const char* cm = (const char*)memchr(t, ',', (size_t)(c.e - t));
+            const char* te = cm ? cm : c.e;
+            if (te > t && !(te - t == 1 && *t == '*'))
+                if (!slow_token(t, te)) return;
+            p = cm ? cm + 1 : c.e;
+        }
         c.bp = bp;
     });
     timer.lap("gfa: P lines (threads)");

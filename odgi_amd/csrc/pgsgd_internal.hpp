@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pgsgd.h"
@@ -32,13 +35,28 @@ struct PhaseTimer {
 }  // namespace pgsgd
 
 // The owning counterpart of pgsgd_graph_view: what `graph_t` + `XP` are lowered to.
+namespace pgsgd {
+// std::vector whose resize() leaves new elements uninitialised: the per-step arrays (hundreds of MB) are written once,
+// by threads, right after they are sized — zero-filling them first is a serial pass over memory of the same length
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using raw_vector = std::vector<T, default_init_allocator<T>>;
+}  // namespace pgsgd
+
 struct pgsgd_graph {
     uint64_t n_nodes = 0;
     std::vector<uint32_t> node_len;     // [N]
     std::vector<uint64_t> path_first;   // [P+1]
-    std::vector<uint32_t> step_path;    // [S]
-    std::vector<uint32_t> step_handle;  // [S]
-    std::vector<uint64_t> step_pos;     // [S]
+    pgsgd::raw_vector<uint32_t> step_path;    // [S]
+    pgsgd::raw_vector<uint32_t> step_handle;  // [S]
+    pgsgd::raw_vector<uint64_t> step_pos;     // [S]
     std::vector<uint64_t> edges;        // [2E] handle pairs
     std::vector<std::string> path_names;
     uint64_t n_paths() const { return path_first.empty() ? 0 : path_first.size() - 1; }

@@ -393,3 +393,38 @@ def test_readers_under_sanitizers(tmp_path):
             files.append(str(f))
         r = subprocess.run([str(exe), kind] + files, capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_gfa_path_lines_with_empty_tokens_placeholders_and_chunk_borders(oa, tmp_path):
+    """P lines are parsed in chunks by threads: a count sweep (tokens - empty tokens - "*" placeholders), then a
+    one-sweep parse with a general path for unusual tokens.  Random small graphs with empty tokens and placeholders, and
+    one path long enough to be cut into several chunks, against a plain Python parse."""
+    rs = np.random.RandomState(7)
+    for trial in range(40):
+        N, P = int(rs.randint(1, 30)), int(rs.randint(1, 5))
+        lines = ["H\tVN:Z:1.0"] + [f"S\t{i + 1}\t{'A' * int(rs.randint(1, 5))}" for i in range(N)]
+        want = []
+        for p in range(P):
+            toks, steps = [], []
+            n_tok = 120000 if (trial == 0 and p == 0) else int(rs.randint(0, 12))   # 120k tokens: ~0.5 MB, three chunks
+            for _ in range(n_tok):
+                r = rs.rand()
+                if r < 0.1:
+                    toks.append("")
+                elif r < 0.2:
+                    toks.append("*")
+                else:
+                    i, o = int(rs.randint(1, N + 1)), "+-"[int(rs.randint(2))]
+                    toks.append(f"{i}{o}")
+                    steps.append(2 * (i - 1) + (o == "-"))
+            lines.append(f"P\tp{p}\t" + ",".join(toks) + "\t*")
+            want.append(steps)
+        fn = tmp_path / "t.gfa"
+        fn.write_text("\n".join(lines) + "\n")
+        g = oa.Graph.from_gfa(str(fn), 3)
+        node_len = np.array([len(l.split("\t")[2]) for l in lines[1:N + 1]])
+        for p in range(P):
+            a, b = int(g.path_first[p]), int(g.path_first[p + 1])
+            assert list(g.step_handle[a:b]) == want[p], (trial, p)
+            pos = np.concatenate([[0], np.cumsum(node_len[np.array(want[p], dtype=np.int64) >> 1])])[:-1] if want[p] else np.zeros(0)
+            assert np.array_equal(g.step_pos[a:b], pos.astype(np.uint64))
