@@ -104,16 +104,37 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
         memcpy(&vals[2 * i], &x, 8);
         memcpy(&vals[2 * i + 1], &y, 8);
     }
+    // enc_vector: every dens-th value is a sample (stored with the bit offset of what follows it), the others are
+    // Elias-delta codes of differences.  The blocks between samples are independent once their bit offsets are known:
+    // pass 1 sizes them (threads), a prefix sum places them, pass 2 encodes ranges of blocks on threads into private
+    // word arrays that start at a word boundary of the final bit string and are OR-ed into it afterwards (neighbouring
+    // ranges share a word).
     const uint64_t dens = 128;
-    uint64_t samples = 0, z_size = 0, max_sample = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (i % dens == 0) {
-            if (max_sample < vals[i]) max_sample = vals[i];
-            ++samples;
-        } else {
-            z_size += delta_len(vals[i] - vals[i - 1]);
+    const uint64_t samples = (n + dens - 1) / dens;
+    uint64_t z_size = 0, max_sample = 0;
+    std::vector<uint64_t> block_bits((size_t)samples + 1, 0);
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({32, std::thread::hardware_concurrency(), samples / 64 + 1}));
+    auto on_threads = [&](auto&& body) {  // body(thread index): contiguous ranges of blocks
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(body, t);
+        body(0u);
+        for (auto& t : th) t.join();
+    };
+    auto range = [&](unsigned t) { return std::make_pair(samples * t / nt, samples * (t + 1) / nt); };
+    on_threads([&](unsigned t) {
+        const auto [b0, b1] = range(t);
+        for (uint64_t b = b0; b < b1; ++b) {
+            uint64_t bits = 0;
+            const uint64_t e = std::min(n, (b + 1) * dens);
+            for (uint64_t i = b * dens + 1; i < e; ++i) bits += delta_len(vals[i] - vals[i - 1]);
+            block_bits[(size_t)b + 1] = bits;
         }
+    });
+    for (uint64_t b = 0; b < samples; ++b) {
+        if (max_sample < vals[b * dens]) max_sample = vals[b * dens];
+        block_bits[(size_t)b + 1] += block_bits[(size_t)b];  // -> bit offset of block b + 1
     }
+    z_size = block_bits[(size_t)samples];
     PackedInts sv;
     BitWriter z;
     uint64_t z_bits_total = z_size;
@@ -122,16 +143,32 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
         sv.init(2 * samples + 2, width);
         z.reserve_bits(z_size);
         uint64_t si = 0;
-        for (uint64_t i = 0; i < n; ++i) {
-            if (i % dens == 0) {
-                sv.set(si++, vals[i]);
-                sv.set(si++, z.nbits);
-            } else {
-                delta_put(z, vals[i] - vals[i - 1]);
-            }
+        for (uint64_t b = 0; b < samples; ++b) {
+            sv.set(si++, vals[b * dens]);
+            sv.set(si++, block_bits[(size_t)b]);
         }
         sv.set(si++, 0);
         sv.set(si++, z_bits_total + 1);
+        std::vector<BitWriter> part(nt);
+        on_threads([&](unsigned t) {
+            const auto [b0, b1] = range(t);
+            if (b0 == b1) return;
+            BitWriter& w = part[t];
+            const uint64_t first_bit = block_bits[(size_t)b0], last_bit = block_bits[(size_t)b1];
+            w.reserve_bits((first_bit & 63) + (last_bit - first_bit));
+            w.nbits = first_bit & 63;  // bit 0 of the private array is a word boundary of the final string
+            for (uint64_t b = b0; b < b1; ++b) {
+                const uint64_t e = std::min(n, (b + 1) * dens);
+                for (uint64_t i = b * dens + 1; i < e; ++i) delta_put(w, vals[i] - vals[i - 1]);
+            }
+        });
+        for (unsigned t = 0; t < nt; ++t) {
+            const auto [b0, b1] = range(t);
+            if (b0 == b1) continue;
+            const size_t w0 = (size_t)(block_bits[(size_t)b0] >> 6);
+            for (size_t k = 0; k < part[t].w.size(); ++k) z.w[w0 + k] |= part[t].w[k];
+        }
+        z.nbits = z_size;
     } else {
         sv.init(0, 64);  // empty int_vector<0> keeps its default width of 64
     }
@@ -407,7 +444,7 @@ extern "C" int pgsgd_write_tsv(const char* path, uint64_t n_nodes, const uint32_
         }
     };
     {
-        const unsigned nt = n_chunks > 1 ? std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), (unsigned)n_chunks})) : 1u;
+        const unsigned nt = n_chunks > 1 ? std::max(1u, std::min<unsigned>({64u, std::thread::hardware_concurrency(), (unsigned)n_chunks})) : 1u;
         std::vector<std::thread> th;
         for (unsigned t = 1; t < nt; ++t) th.emplace_back(format);
         format();
