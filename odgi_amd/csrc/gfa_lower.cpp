@@ -88,21 +88,50 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     struct { const char* p; size_t n; const char* data() const { return p; } size_t size() const { return n; } } buf{file.p, file.n};
 
     timer.lap("gfa: read file");
+    const int nt_lines = std::max(1, std::min(n_threads, 64));
+    // fn(t, begin, end) on contiguous slices of [0, n): on threads when there is enough to split
+    auto parallel_slices = [&](uint64_t n, uint64_t min_per_thread, auto&& fn) {
+        const unsigned k = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt_lines, n / std::max<uint64_t>(1, min_per_thread)));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < k; ++t) th.emplace_back(fn, t, n * t / k, n * (t + 1) / k);
+        fn(0u, (uint64_t)0, n / k);
+        for (auto& x : th) x.join();
+        return k;
+    };
+    // lines: the file is cut at newlines into one range per thread, every range lists its S, L and P lines, the lists
+    // are joined in file order
     std::vector<Line> s_lines, l_lines, p_lines;
     {
-        const char* p = buf.data();
-        const char* end = p + buf.size();
-        while (p < end) {
-            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-            const char* le = nl ? nl : end;
-            const char* e = le;
-            if (e > p && e[-1] == '\r') --e;
-            if (e - p >= 2 && p[1] == '\t') {
-                if (p[0] == 'S') s_lines.push_back({p, e});
-                else if (p[0] == 'L') l_lines.push_back({p, e});
-                else if (p[0] == 'P') p_lines.push_back({p, e});
+        const char* base = buf.data();
+        const char* end = base + buf.size();
+        struct Lists { std::vector<Line> s, l, p; };
+        std::vector<Lists> part((size_t)nt_lines);
+        const unsigned k = parallel_slices(buf.size(), 1 << 22, [&](unsigned t, uint64_t b0, uint64_t b1) {
+            // a range starts at the first line that begins inside it
+            const char* p = base + b0;
+            if (b0 > 0) {
+                const char* nl = (const char*)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+                p = nl ? nl + 1 : end;
             }
-            p = nl ? nl + 1 : end;
+            const char* stop = base + b1;  // lines that BEGIN before stop belong to this range
+            Lists& L = part[t];
+            while (p < end && p < stop) {
+                const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+                const char* le = nl ? nl : end;
+                const char* e = le;
+                if (e > p && e[-1] == '\r') --e;
+                if (e - p >= 2 && p[1] == '\t') {
+                    if (p[0] == 'S') L.s.push_back({p, e});
+                    else if (p[0] == 'L') L.l.push_back({p, e});
+                    else if (p[0] == 'P') L.p.push_back({p, e});
+                }
+                p = nl ? nl + 1 : end;
+            }
+        });
+        for (unsigned t = 0; t < k; ++t) {
+            s_lines.insert(s_lines.end(), part[t].s.begin(), part[t].s.end());
+            l_lines.insert(l_lines.end(), part[t].l.begin(), part[t].l.end());
+            p_lines.insert(p_lines.end(), part[t].p.begin(), part[t].p.end());
         }
     }
     if (s_lines.empty()) { set_error("'%s' has no S lines", path); return PGSGD_E_FORMAT; }
@@ -112,58 +141,106 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
     const uint64_t N = s_lines.size();
     g->n_nodes = N;
     g->node_len.assign(N, 0);
-    std::vector<uint8_t> seen(N, 0);
-    uint64_t min_id = UINT64_MAX, max_id = 0;
-    // nodes
-    for (const Line& ln : s_lines) {
-        const char* nb = ln.b + 2;
-        const char* ne = next_tab(nb, ln.e);
-        uint64_t id;
-        if (!parse_uint(nb, ne, &id)) {
-            set_error("segment name '%.*s' is not a non-negative integer node id", (int)(ne - nb), nb);
+    // nodes and edges: slices of the line lists on threads; the error reported is the first in file order
+    struct LineError { uint64_t line = UINT64_MAX; int code = 0; std::string msg; };
+    auto first_error = [](const std::vector<LineError>& errs) {
+        const LineError* best = nullptr;
+        for (const LineError& e : errs)
+            if (e.code && (!best || e.line < best->line)) best = &e;
+        return best;
+    };
+    {
+        std::vector<uint8_t> seen(N, 0);
+        std::vector<LineError> errs((size_t)nt_lines);
+        std::vector<uint64_t> lo((size_t)nt_lines, UINT64_MAX), hi((size_t)nt_lines, 0);
+        const unsigned k = parallel_slices(N, 1 << 16, [&](unsigned t, uint64_t b0, uint64_t b1) {
+            uint64_t min_id = UINT64_MAX, max_id = 0;
+            for (uint64_t i = b0; i < b1; ++i) {
+                const Line& ln = s_lines[i];
+                const char* nb = ln.b + 2;
+                const char* ne = next_tab(nb, ln.e);
+                uint64_t id;
+                if (!parse_uint(nb, ne, &id)) {
+                    errs[t].line = i;
+                    errs[t].code = PGSGD_E_FORMAT;
+                    errs[t].msg = "segment name '" + std::string(nb, ne) + "' is not a non-negative integer node id";
+                    break;
+                }
+                min_id = std::min(min_id, id);
+                max_id = std::max(max_id, id);
+                const char* sb = ne < ln.e ? ne + 1 : ln.e;
+                const char* se = next_tab(sb, ln.e);
+                if (id >= 1 && id <= N) {
+                    if (__atomic_exchange_n(&seen[id - 1], (uint8_t)1, __ATOMIC_RELAXED)) {
+                        errs[t].line = i;
+                        errs[t].code = PGSGD_E_FORMAT;
+                        errs[t].msg = "duplicate node id " + std::to_string(id);
+                        break;
+                    }
+                    g->node_len[id - 1] = (uint32_t)(se - sb);
+                }
+            }
+            lo[t] = min_id;
+            hi[t] = max_id;
+        });
+        if (const LineError* e = first_error(errs)) {
+            set_error("%s", e->msg.c_str());
+            const int code = e->code;
             delete g;
-            return PGSGD_E_FORMAT;
+            return code;
         }
-        min_id = std::min(min_id, id);
-        max_id = std::max(max_id, id);
-        const char* sb = ne < ln.e ? ne + 1 : ln.e;
-        const char* se = next_tab(sb, ln.e);
-        if (id >= 1 && id <= N) {
-            if (seen[id - 1]) { set_error("duplicate node id %llu", (unsigned long long)id); delete g; return PGSGD_E_FORMAT; }
-            seen[id - 1] = 1;
-            g->node_len[id - 1] = (uint32_t)(se - sb);
+        uint64_t min_id = UINT64_MAX, max_id = 0;
+        for (unsigned t = 0; t < k; ++t) { min_id = std::min(min_id, lo[t]); max_id = std::max(max_id, hi[t]); }
+        if (!(min_id == 1 && max_id == N)) {
+            set_error("the graph is not optimized: node ids span [%llu, %llu] for %llu nodes", (unsigned long long)min_id,
+                      (unsigned long long)max_id, (unsigned long long)N);
+            delete g;
+            return PGSGD_E_NOTOPTIMIZED;
         }
-    }
-    if (!(min_id == 1 && max_id == N)) {
-        set_error("the graph is not optimized: node ids span [%llu, %llu] for %llu nodes", (unsigned long long)min_id,
-                  (unsigned long long)max_id, (unsigned long long)N);
-        delete g;
-        return PGSGD_E_NOTOPTIMIZED;
     }
     timer.lap("gfa: S lines");
     // edges (only needed for the weakly-connected-component post step)
-    g->edges.reserve(l_lines.size() * 2);
-    for (const Line& ln : l_lines) {
-        const char* f[5];
-        const char* fe[5];
-        const char* p = ln.b + 2;
-        int nf = 0;
-        while (nf < 4 && p <= ln.e) {
-            const char* t = next_tab(p, ln.e);
-            f[nf] = p; fe[nf] = t; ++nf;
-            p = t + 1;
-        }
-        if (nf < 4 || fe[0] == f[0]) continue;  // gfa_to_handle.cpp:111 skips empty sources
-        uint64_t a, b;
-        if (!parse_uint(f[0], fe[0], &a) || !parse_uint(f[2], fe[2], &b) || a < 1 || a > N || b < 1 || b > N) {
-            set_error("edge '%.*s <--> %.*s' names a missing node", (int)(fe[0] - f[0]), f[0], (int)(fe[2] - f[2]), f[2]);
+    {
+        std::vector<std::vector<uint64_t>> part((size_t)nt_lines);
+        std::vector<LineError> errs((size_t)nt_lines);
+        const unsigned k = parallel_slices(l_lines.size(), 1 << 16, [&](unsigned t, uint64_t b0, uint64_t b1) {
+            std::vector<uint64_t>& out = part[t];
+            out.reserve((size_t)(b1 - b0) * 2);
+            for (uint64_t i = b0; i < b1; ++i) {
+                const Line& ln = l_lines[i];
+                const char* f[5];
+                const char* fe[5];
+                const char* p = ln.b + 2;
+                int nf = 0;
+                while (nf < 4 && p <= ln.e) {
+                    const char* tb = next_tab(p, ln.e);
+                    f[nf] = p; fe[nf] = tb; ++nf;
+                    p = tb + 1;
+                }
+                if (nf < 4 || fe[0] == f[0]) continue;  // gfa_to_handle.cpp:111 skips empty sources
+                uint64_t a, b;
+                if (!parse_uint(f[0], fe[0], &a) || !parse_uint(f[2], fe[2], &b) || a < 1 || a > N || b < 1 || b > N) {
+                    errs[t].line = i;
+                    errs[t].code = PGSGD_E_FORMAT;
+                    errs[t].msg = "edge '" + std::string(f[0], fe[0]) + " <--> " + std::string(f[2], fe[2]) + "' names a missing node";
+                    break;
+                }
+                const uint64_t ra = (fe[1] > f[1] && f[1][0] == '-') ? 1 : 0;
+                const uint64_t rb = (fe[3] > f[3] && f[3][0] == '-') ? 1 : 0;
+                out.push_back(2 * (a - 1) + ra);
+                out.push_back(2 * (b - 1) + rb);
+            }
+        });
+        if (const LineError* e = first_error(errs)) {
+            set_error("%s", e->msg.c_str());
+            const int code = e->code;
             delete g;
-            return PGSGD_E_FORMAT;
+            return code;
         }
-        const uint64_t ra = (fe[1] > f[1] && f[1][0] == '-') ? 1 : 0;
-        const uint64_t rb = (fe[3] > f[3] && f[3][0] == '-') ? 1 : 0;
-        g->edges.push_back(2 * (a - 1) + ra);
-        g->edges.push_back(2 * (b - 1) + rb);
+        size_t total = 0;
+        for (unsigned t = 0; t < k; ++t) total += part[t].size();
+        g->edges.reserve(total);
+        for (unsigned t = 0; t < k; ++t) g->edges.insert(g->edges.end(), part[t].begin(), part[t].end());
     }
     timer.lap("gfa: L lines");
     // graph_t::create_edge ignores an edge that exists (odgi.cpp:611-631), and a -> b is the same edge as

@@ -428,3 +428,30 @@ def test_gfa_path_lines_with_empty_tokens_placeholders_and_chunk_borders(oa, tmp
             assert list(g.step_handle[a:b]) == want[p], (trial, p)
             pos = np.concatenate([[0], np.cumsum(node_len[np.array(want[p], dtype=np.int64) >> 1])])[:-1] if want[p] else np.zeros(0)
             assert np.array_equal(g.step_pos[a:b], pos.astype(np.uint64))
+
+
+def test_gfa_lowering_is_the_same_on_one_thread_and_on_many(oa, tmp_path):
+    """The file is cut at newlines into one range per thread (from 4 MB per range on), S and L lines are parsed on
+    slices: a 10 MB GFA with CRLF line ends in places, lowered with 1 and with 5 threads."""
+    rs = np.random.RandomState(11)
+    N, P = 150000, 6
+    lens = rs.randint(1, 30, size=N)
+    with open(tmp_path / "big.gfa", "w", newline="") as f:
+        f.write("H\tVN:Z:1.0\n")
+        for i in range(N):
+            f.write(f"S\t{i + 1}\t{'C' * int(lens[i])}" + ("\r\n" if i % 1000 == 7 else "\n"))
+        for i in range(N - 1):
+            f.write(f"L\t{i + 1}\t+\t{i + 2}\t{'-' if i % 97 == 0 else '+'}\t0M\n")
+        f.write("# a comment line\n")
+        for p in range(P):
+            ids = np.nonzero(rs.rand(N) < 0.9)[0] + 1
+            f.write(f"P\tq{p}\t" + ",".join(f"{i}{'-' if i % 13 == 0 else '+'}" for i in ids) + "\t*\n")
+    assert os.path.getsize(tmp_path / "big.gfa") > 9_000_000
+    a = oa.Graph.from_gfa(str(tmp_path / "big.gfa"), 1)
+    b = oa.Graph.from_gfa(str(tmp_path / "big.gfa"), 5)
+    assert a.n_nodes == b.n_nodes == N and a.n_steps == b.n_steps
+    for k in ("node_len", "path_first", "step_path", "step_handle", "step_pos"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert np.array_equal(a.node_len, lens)
+    assert a.edges.shape == (N - 1, 2) and np.array_equal(a.edges, b.edges)
+    assert np.array_equal(a.edges[:3], [[0, 3], [2, 4], [4, 6]])   # 1+ -> 2- (every 97th edge), 2+ -> 3+, 3+ -> 4+
