@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stress", action="store_true", help="also report sampled path stress of the final layout")
     ap.add_argument("--no-tiles", action="store_true", help="force the per-lane kernel (PGSGD_FLAG_NO_TILES)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-rank exchange (prepare, all-reduce, merge) even at world size 1: under "
+                         "`torchrun --nproc-per-node 1` this executes the RCCL path on a single-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -62,7 +65,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or (args.force_exchange and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -87,16 +90,17 @@ def main():
     p.stream_offset = rank * (1 << 20)   # disjoint sampler stream ids per rank (a GPU runs < 2^20 streams)
     eng = HipEngine(g, p, X0, Y0)
     p.n_streams = eng.session.n_streams
-    drv = DistributedLayout(p, eng)
+    drv = DistributedLayout(p, eng, force_exchange=args.force_exchange)
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
     for it in range(args.warmup):
         drv.step(it)
     eng.session.kernel_time(reset=True)
+    counts0 = eng.session.launch_counts()
     fence()
     per_iter = []          # (iteration, update-kernel ms, launches, snapshot ms, drain ms) — host bookkeeping after each
     k_prev = (0.0, 0, 0.0, 0.0)   # step's own sync (the product's run loop syncs every iteration for delta_max too)
@@ -114,6 +118,7 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches = eng.session.kernel_time()
     snapshot_ms, drain_ms = eng.session.aux_time()
+    n_kernels, n_copies = (a - b for a, b in zip(eng.session.launch_counts(), counts0))
 
     total_terms = float(p.min_term_updates) * args.steps
     value = total_terms / elapsed
@@ -138,9 +143,14 @@ def main():
         "config": {"workload": f"synthetic linearised pangenome N={g.n_nodes} S={g.n_steps} P={g.n_paths} seed 42 "
                                f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
                                f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
-                   "streams_per_gpu": int(p.n_streams), "kernel_launches_per_step": launches / args.steps,
-                   "parallelism": f"{'tile' if drv.engine_sharded else 'term'}-sharded x{world}, graph replicated, "
-                                  f"{drv.blocks} delta all-reduce(s) per eta step"},
+                   "streams_per_gpu": int(p.n_streams),
+                   # everything a step puts on the stream, and the launches of the dominant kernel among them
+                   "kernel_launches_per_step": n_kernels / args.steps, "memset_and_copy_ops_per_step": n_copies / args.steps,
+                   "update_kernel_launches_per_step": launches / args.steps,
+                   "parallelism": f"{getattr(eng, 'shard_mode', 'terms') if drv.engine_sharded else 'terms'}-sharded x{world}, graph replicated, "
+                                  f"{drv.blocks} fused delta all-reduce(s) per eta step",
+                   "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+                   "collective_backend": dist.get_backend() if dist.is_initialized() else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "pgsgd::sgd_tile_kernel" if eng.session.tile_info()["tiled"] else "pgsgd::sgd_iteration_kernel",
@@ -171,7 +181,8 @@ def main():
     out["config"]["kernel_plan"] = ("per-lane kernel" if not info["tiled"] else
                                     "per-lane kernel until cooling, tile kernel after" if info["warm_per_lane"] else
                                     "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present
+    # HBM bytes per launch: NOT measured in this run — read from the committed rocprofv3 PMC passes of this same
+    # command (tools/profile_pmc.sh -> profiles/pmc_traffic.json), labelled as such
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
     if os.path.exists(prof) and same_workload:
@@ -181,7 +192,7 @@ def main():
             out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
             out["roofline"]["traffic_raw"] = pj.get("hbm_bytes_per_launch_raw")   # FETCH_SIZE + WRITE_SIZE as reported
             out["roofline"]["traffic_note"] = pj.get("note")
-            out["roofline"]["traffic_source"] = pj.get("source")
+            out["roofline"]["traffic_source"] = "profiled offline, not in this run: " + str(pj.get("source"))
         except Exception as e:  # noqa: BLE001
             log(f"[bench] could not read {prof}: {e}")
 
@@ -189,9 +200,6 @@ def main():
         X, Y = eng.result()
         out["stress_sampled"] = oa.path_stress(g, X, Y, 2_000_000)
         out["stress_initial"] = oa.path_stress(g, X0, Y0, 2_000_000)
-    if world > 1:
-        out["config"]["collective_backend"] = backend
-
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # CPU baseline: the oracle's Hogwild restatement of path_sgd_layout.cpp:165-377 (fp64, 1 ms
         # controller), reference Release flags minus -march=native, on a time-bounded sample of the
@@ -218,7 +226,7 @@ def main():
             "cpu_model": cpu_model,
         }
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

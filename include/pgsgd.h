@@ -184,6 +184,11 @@ int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t 
 int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint64_t n_terms, uint32_t part, uint32_t n_parts);
 /* Wait for the stream; returns max |Delta| of the last iteration in *delta_max (may be NULL). */
 int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
+/* Tile kernel only (a no-op otherwise): what a tile launch adds to node ends outside its windows is delivered right
+ * before the NEXT launch, so between iterations the coordinates lack the far pulls of the last launch.  A caller that
+ * drives iterations itself calls this before it reads the final coordinates (pgsgd_layout_run does); per-iteration
+ * snapshots (path_sgd_layout.cpp:379-408) are taken without it. */
+int pgsgd_session_flush(pgsgd_session* s);
 /* The fixed-point coordinate frame (2^32 quanta per axis, 8x the layout's extent at upload).  Kernels flag any
  * coordinate they see in the outer quarter of the frame; pgsgd_session_sync then doubles the frame (same centre, half
  * the resolution) before the next iteration, so a node end never wraps around.  A session that is part of a multi-GPU
@@ -196,6 +201,9 @@ int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uint64_t* laun
 /* Tile kernel only: time spent in the two streaming kernels around every tile launch (coordinate snapshot into the
  * step records before it, far-update drain after it), same clock and reset as pgsgd_session_kernel_time. */
 int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, double* drain_ms);
+/* kernel launches and memset/copy operations the iteration calls have put on the stream so far (what a step costs
+ * besides its dominant kernel: bench.py reports them per step) */
+int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launches, uint64_t* copies);
 /* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
  * direct atomic adds instead (0 in normal operation; the pool is sized from the tile table). */
 int64_t pgsgd_session_outbox_overflow(pgsgd_session* s);
@@ -206,8 +214,10 @@ uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
  *                  visited tile with its whole share of terms: no short term loops);
  *   by_region = 1: this device runs work items (node regions with all their tiles) rank, rank+world, ...
  *                  (disjoint windows across devices; needs >= ~1000 regions per device and launch).
- * Returns 1 when the session is tiled (the shard is in effect), 0 when it runs the per-lane kernel
- * (shard the term count instead), < 0 on error. */
+ *   by_region -1: by region when that leaves every launch at least a thousand work items per device, by tile otherwise.
+ * Returns 1 (sharded by tile) or 2 (by region) when the session is tiled, 0 when it runs the per-lane kernel
+ * (shard the term count instead), < 0 on error.  The tile streams of a sharded session are keyed on (seed, iteration,
+ * tile, lane) — stream_offset, which the devices' per-lane streams need to differ, does not enter them. */
 int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region);
 /* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel, 2 (known
  * after pgsgd_session_upload_coords) when the initial layout has no global structure — long-range stress above
@@ -222,6 +232,11 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
 int pgsgd_session_exchange_mark(pgsgd_session* s);
 int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6N_floats);
 int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_floats, int world_size);
+/* begin, with a tail of 2*world floats behind the 6N: slot 6N + rank = this device's max |Delta| of the last iteration
+ * call, slot 6N + world + rank = 1 if it saw a coordinate in the guard band of the fixed-point frame; the other
+ * devices' slots are written as zero, so after the SUM all-reduce of all 6N + 2*world floats every device holds every
+ * device's values: the reference's stop rule (path_sgd_layout.cpp:142) and the frame widening need no second collective. */
+int pgsgd_session_exchange_begin_stats(pgsgd_session* s, void* device_buf_6N_plus_2world_floats, uint32_t rank, uint32_t world);
 /* Parity hooks of the tile kernel.  Every term of a tiled iteration is a pure function of (seed +
  * stream_offset, iteration number, tile, lane of the tile, position in the lane's stream); tile_table copies up to `capacity` tiles (in work order:
  * first step, steps before the tile, steps, path) and returns their number; trace_tile_terms replays the

@@ -13,6 +13,9 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpgsgd.so")
+if os.environ.get("PGSGD_DEBUG", "")[:1] == "1" and os.environ.get("PGSGD_LIB"):
+    # experiment knob (tools/): another build of the same sources, e.g. a different register budget of the tile kernel
+    LIB_PATH = os.path.join(_HERE, "lib", os.environ["PGSGD_LIB"])
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -79,15 +82,18 @@ SIGNATURES = [
     ("pgsgd_session_iteration", C.c_int, [C.c_void_p, f64, C.c_int, u64]),
     ("pgsgd_session_iteration_part", C.c_int, [C.c_void_p, f64, C.c_int, u64, u32, u32]),
     ("pgsgd_session_sync", C.c_int, [C.c_void_p, P(f64)]),
+    ("pgsgd_session_flush", C.c_int, [C.c_void_p]),
     ("pgsgd_session_frame_status", C.c_int, [C.c_void_p, P(C.c_int), P(u32)]),
     ("pgsgd_session_reframe", C.c_int, [C.c_void_p]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
     ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
+    ("pgsgd_session_launch_counts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),
     ("pgsgd_session_exchange_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pgsgd_session_exchange_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("pgsgd_session_exchange_begin_stats", C.c_int, [C.c_void_p, C.c_void_p, u32, u32]),
     ("pgsgd_session_tile_table", i64, [C.c_void_p, P(u64), P(u64), P(u32), P(u32), u64, P(u64)]),
     ("pgsgd_session_tile_lanes", i64, [C.c_void_p, P(u32), u64]),
     ("pgsgd_session_tile_items", i64, [C.c_void_p, P(u32), P(u32), P(u32), P(u32), u64, P(u64)]),

@@ -19,6 +19,16 @@ namespace pgsgd {
 void set_error(const char* fmt, ...);
 void clear_error();
 
+// Experiment and test knobs (PGSGD_TILE_*, PGSGD_OUTBOX_*, PGSGD_FRAME_SPAN, PGSGD_MULTI_*): environment variables that
+// change what the library computes or how it is laid out.  They are read when a session (or a multi-GPU run) is set up,
+// never on a launch path, and ONLY in a process that also sets PGSGD_DEBUG=1 — a stray variable in a user's environment
+// cannot change a layout.  tests/ and tools/ set PGSGD_DEBUG=1.
+inline const char* debug_env(const char* name) {
+    const char* dbg = getenv("PGSGD_DEBUG");
+    if (!dbg || dbg[0] != '1') return nullptr;
+    return getenv(name);
+}
+
 // PGSGD_TIMING=1: wall-clock of the set-up phases on stderr (where the time of a run goes besides the kernels)
 struct PhaseTimer {
     const bool on = getenv("PGSGD_TIMING") != nullptr;

@@ -763,6 +763,17 @@ __global__ void exchange_prepare_kernel(const uint64_t* coords, const uint64_t* 
     }
 }
 
+// the tail of the fused buffer: a slot per rank for its max |Delta| and one for its frame-guard flag (zero in the other
+// ranks' slots: the SUM all-reduce then hands every rank all of them)
+__global__ void exchange_stats_kernel(const unsigned int* delta_max_bits, uint32_t rank, uint32_t world, float* tail) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * world) return;
+    float v = 0.0f;
+    if (i == rank) v = __uint_as_float(delta_max_bits[0]);
+    if (i == world + rank) v = delta_max_bits[1] ? 1.0f : 0.0f;
+    tail[i] = v;
+}
+
 // step 2, after the all-reduce (SUM) over G ranks: S = sum of the ranks' moves, Q = sum of their
 // squared lengths.  Each node end moves by S * f with f = clamp(Q / |S|^2, 1/G, 1): ranks that
 // pulled the end the same way (coherent moves, |S|^2 = G*Q: every rank already made the full

@@ -4,20 +4,27 @@
 // split 1/G per GPU, and the coordinates are merged with an RCCL all-reduce over xGMI at every step.  One host thread
 // drives each device (one session each: graph upload, kernels and exchange on that device's stream); the merge is the
 // one of odgi_amd/distributed.py (begin: what this rank moved since the last exchange and its squared length, SUM
-// all-reduce of the fused 6N-float buffer, end: base + S * clamp(Q / |S|^2, 1/G, 1)), so a C or C++ caller gets the
-// same run the one-process-per-GPU Python driver gives.  The reference has no multi-device path (src/cuda/layout.cu
-// is single-GPU; its NCCLCHECK macro is unused).
+// all-reduce of the fused buffer, end: base + S * clamp(Q / |S|^2, 1/G, 1)), so a C or C++ caller gets the same run
+// the one-process-per-GPU Python driver gives.  The reference has no multi-device path (src/cuda/layout.cu is
+// single-GPU; its NCCLCHECK macro is unused).
 //
-// RCCL is bound at run time (dlopen "librccl.so"): the library must not pull a second HIP runtime into a process
-// that already has one (PyTorch ships its own), and single-GPU users need no RCCL at all.  PGSGD_MULTI_HOST_REDUCE=1
-// replaces the collective by a sum through pinned host memory — what the single-GPU test box runs, with several
-// "devices" mapped to the one GPU it has (RCCL refuses two ranks on one device).
+// One collective per exchange and nothing else between the ranks inside an iteration: the tail of the fused buffer
+// carries every rank's max |Delta| (the reference's stop rule, path_sgd_layout.cpp:142) and frame-guard flag in a slot
+// of its own, so the SUM hands all of them to everybody; the host threads meet once per iteration, where the ranks'
+// error states are OR-ed inside the barrier and every rank acts on the same value.
+//
+// RCCL is bound at run time (dlopen "librccl.so"; types and enumerators from <rccl/rccl.h>): the library must not
+// pull a second HIP runtime into a process that already has one (PyTorch ships its own), and single-GPU users need no
+// RCCL at all.  Test knobs (PGSGD_DEBUG=1 only): PGSGD_MULTI_HOST_REDUCE=1 replaces the collective by a sum through
+// pinned host memory, with several "devices" mapped to the one GPU of the test box (RCCL refuses two ranks on one
+// device); PGSGD_MULTI_FORCE=1 sends an n_devices = 1 run through this driver — one rank, a one-rank communicator, the
+// same ncclAllReduce calls — which is how the RCCL binding is executed on a single-GPU box.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -31,51 +38,55 @@
 
 using pgsgd::set_error;
 
+int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);  // pgsgd_session.hip
+
 namespace {
 
-// the few RCCL entry points the exchange needs (rccl.h: ncclFloat32 = 7, ncclSum = 0)
-typedef void* ncclComm_t;
-typedef int (*ncclCommInitAll_t)(ncclComm_t*, int, const int*);
-typedef int (*ncclCommDestroy_t)(ncclComm_t);
-typedef int (*ncclAllReduce_t)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
-typedef const char* (*ncclGetErrorString_t)(int);
+// the few RCCL entry points the exchange needs, with the signatures rccl.h declares
 struct Rccl {
     void* lib = nullptr;
-    ncclCommInitAll_t init_all = nullptr;
-    ncclCommDestroy_t destroy = nullptr;
-    ncclAllReduce_t all_reduce = nullptr;
-    ncclGetErrorString_t error_string = nullptr;
+    decltype(&ncclCommInitAll) init_all = nullptr;
+    decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
     bool load() {
         for (const char* name : {"librccl.so", "librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
         if (!lib) return false;
-        init_all = (ncclCommInitAll_t)dlsym(lib, "ncclCommInitAll");
-        destroy = (ncclCommDestroy_t)dlsym(lib, "ncclCommDestroy");
-        all_reduce = (ncclAllReduce_t)dlsym(lib, "ncclAllReduce");
-        error_string = (ncclGetErrorString_t)dlsym(lib, "ncclGetErrorString");
+        init_all = (decltype(init_all))dlsym(lib, "ncclCommInitAll");
+        destroy = (decltype(destroy))dlsym(lib, "ncclCommDestroy");
+        all_reduce = (decltype(all_reduce))dlsym(lib, "ncclAllReduce");
+        error_string = (decltype(error_string))dlsym(lib, "ncclGetErrorString");
         return init_all && destroy && all_reduce;
     }
 };
 
-// a reusable barrier for the G driver threads
+// A reusable barrier for the G driver threads that also agrees on a flag: wait(f) returns the OR of the f of every rank
+// in this round — computed by the last arriver under the lock, so every rank leaves with the same value and acts on it
+// (a rank that reads a shared "failed" word on its own after a barrier can see a later failure the others did not).
 struct Barrier {
     std::mutex m;
     std::condition_variable cv;
     int n, waiting = 0;
     uint64_t round = 0;
+    bool acc = false, result = false;
     explicit Barrier(int n_) : n(n_) {}
-    void wait() {
+    bool wait(bool flag = false) {
         std::unique_lock<std::mutex> lk(m);
+        acc = acc || flag;
         const uint64_t r = round;
         if (++waiting == n) {
+            result = acc;
+            acc = false;
             waiting = 0;
             ++round;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return round != r; });
+            return result;
         }
+        cv.wait(lk, [&] { return round != r; });
+        return result;  // (the next round cannot complete before this rank has returned and arrived again)
     }
 };
 
@@ -87,14 +98,19 @@ struct Shared {
     std::vector<double> etas;
     uint64_t first_cooling;
     Barrier barrier;
+    // the host threads are all created before any of them starts: a thread that cannot be created must not leave the
+    // others waiting at a barrier for it
+    std::mutex start_m;
+    std::condition_variable start_cv;
+    int start = 0;                      // 0: wait, 1: go, 2: give up
     Rccl* rccl = nullptr;               // null: host-staged sum
     std::vector<ncclComm_t> comms;
-    std::vector<float*> host_buf;       // [G] pinned, host-staged sum only
-    std::vector<double> dmax;           // [G] per iteration
-    std::vector<int> guard;             // [G]
+    std::vector<float*> host_buf;       // [2G] pinned, host-staged sum only
     std::vector<int> rc;                // [G] first error of each rank
     std::vector<std::string> err;       // [G]
-    std::atomic<int> failed{0};
+    // what rank 0 found when it set its session up; the ranks' sessions are built from the same graph and layout, so
+    // it holds for all of them (and a rank whose set-up failed never uses it: everybody leaves after the first barrier)
+    bool tiled = false, warm_per_lane = false;
     const float* X0;
     const float* Y0;
     float* X;
@@ -111,7 +127,6 @@ struct Shared {
         if (_rc != PGSGD_OK && !sh.rc[r]) {                                         \
             sh.rc[r] = _rc;                                                         \
             sh.err[r] = pgsgd_last_error();                                         \
-            sh.failed.store(1);                                                     \
         }                                                                           \
     } while (0)
 #define R_HIP(expr)                                                                 \
@@ -120,99 +135,123 @@ struct Shared {
         if (_e != hipSuccess && !sh.rc[r]) {                                        \
             sh.rc[r] = PGSGD_E_HIP;                                                 \
             sh.err[r] = std::string(#expr) + ": " + hipGetErrorString(_e);          \
-            sh.failed.store(1);                                                     \
         }                                                                           \
     } while (0)
 
-// One rank = one device.  Every rank runs the same control flow and meets the others at the same barriers whatever
-// happens (a rank that failed keeps walking through the barriers and skips the work), so nobody waits for ever.
+// One rank = one device.  Every rank runs the same control flow; whether to go on is decided at barriers, from the OR
+// of the ranks' error states, so all of them leave a loop in the same place and nobody waits for ever.
 void rank_main(Shared& sh, int r) {
+    if (r != 0) {
+        std::unique_lock<std::mutex> lk(sh.start_m);
+        sh.start_cv.wait(lk, [&] { return sh.start != 0; });
+        if (sh.start == 2) return;
+    }
     const int G = sh.G;
     const pgsgd_params& p0 = *sh.p;
     const uint64_t N = sh.g->n_nodes;
+    const size_t buf_floats = 6 * N + 2 * (size_t)G;  // S (4N), Q (2N), then every rank's max |Delta| and frame-guard flag
     pgsgd_params p = p0;
     p.device = sh.devices[r];
-    p.stream_offset = p0.stream_offset + (uint32_t)r * (1u << 20);  // disjoint sampler stream ids per rank (a GPU runs < 2^20 streams)
+    // Sampler streams: the per-lane kernel's lane l draws from seed + stream_offset + l, so ranks take disjoint blocks of
+    // 2^20 ids (a GPU runs < 2^20 lanes).  The tile kernel seeds by (seed + stream_offset, iteration, tile, lane) and
+    // every tile belongs to exactly one rank: there the offset must NOT depend on the rank, or rank r's tile t would
+    // draw the stream of rank 0's tile t + 1024 r (the tile index enters as tile << 10) — pgsgd_session_set_shard
+    // takes the rank's offset out of a sharded session's tile seeds.
+    p.stream_offset = p0.stream_offset + (uint32_t)r * (1u << 20);
     p.n_devices = 1;
-    p.snapshot = 0;
+    p.snapshot = 0;  // snapshots are written by rank 0 below, from the merged coordinates
     p.progress = r == 0 ? p0.progress : 0;
     pgsgd_session* s = nullptr;
     float* buf = nullptr;
+    float* h_tail = nullptr;  // pinned: the tails of the exchanges of one iteration (up to four)
     R_HIP(hipSetDevice(sh.devices[r]));
     R_TRY(pgsgd_session_create(sh.g, &p, &s));
     if (s) R_TRY(pgsgd_session_upload_coords(s, sh.X0, sh.Y0));
     if (s) R_TRY(pgsgd_session_exchange_mark(s));
-    bool engine_sharded = false, warm_per_lane = false, tiled = false;
+    bool engine_sharded = false;
     if (s && !sh.rc[r]) {
-        const int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, 0);
-        if (rcs < 0) R_TRY(rcs);
-        engine_sharded = rcs == 1;
         const int info = pgsgd_session_tile_info(s, nullptr, nullptr, nullptr, nullptr, nullptr);
-        tiled = info > 0;
-        warm_per_lane = info == 2;
-        R_HIP(hipMalloc((void**)&buf, 6 * N * sizeof(float)));
+        // by tile, or by node region when that leaves every launch enough work items (decided by the session: -1)
+        const int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, -1);
+        if (rcs < 0) R_TRY(rcs);
+        engine_sharded = rcs > 0;
+        if (r == 0) {
+            sh.tiled = info > 0;
+            sh.warm_per_lane = info == 2;
+        }
+        R_HIP(hipMalloc((void**)&buf, buf_floats * sizeof(float)));
+        R_HIP(hipHostMalloc((void**)&h_tail, 4 * 2 * (size_t)G * sizeof(float)));
     }
     hipStream_t stream = s ? (hipStream_t)pgsgd_session_stream(s) : nullptr;
-    sh.barrier.wait();  // everybody is set up (or has failed)
+    auto cleanup = [&] {
+        if (buf) (void)hipFree(buf);
+        if (h_tail) (void)hipHostFree(h_tail);
+        if (s) pgsgd_session_destroy(s);
+    };
+    if (sh.barrier.wait(sh.rc[r] != 0)) {  // somebody's set-up failed: everybody leaves here
+        cleanup();
+        return;
+    }
     const uint64_t M = p0.min_term_updates;
     const uint64_t my_terms = engine_sharded ? M : M / G + ((uint64_t)r < M % G ? 1 : 0);
+    // one exchange: what this rank moved, every rank's statistics in the tail, SUM over the ranks, merge
+    auto exchange = [&](float* tail_out) -> bool {  // false: the run cannot go on (decided together)
+        if (!sh.rc[r]) R_TRY(pgsgd_session_exchange_begin_stats(s, buf, (uint32_t)r, (uint32_t)G));
+        if (sh.rccl) {
+            // (no barrier: a rank in trouble still issues its collective — the buffer and the communicator exist — and the
+            // ranks decide together at the end of the iteration)
+            const ncclResult_t e = sh.rccl->all_reduce(buf, buf, buf_floats, ncclFloat32, ncclSum, sh.comms[r], stream);
+            if (e != ncclSuccess && !sh.rc[r]) {
+                sh.rc[r] = PGSGD_E_HIP;
+                sh.err[r] = std::string("ncclAllReduce: ") + (sh.rccl->error_string ? sh.rccl->error_string(e) : "error");
+            }
+        } else {  // sum through pinned host memory (tests on a single GPU)
+            if (!sh.rc[r]) R_HIP(hipMemcpyAsync(sh.host_buf[r], buf, buf_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+            if (!sh.rc[r]) R_HIP(hipStreamSynchronize(stream));
+            if (sh.barrier.wait(sh.rc[r] != 0)) return false;
+            float* mine = sh.host_buf[G + r];  // a second slot per rank for the sum
+            for (size_t i = 0; i < buf_floats; ++i) {
+                float acc = 0;
+                for (int q = 0; q < G; ++q) acc += sh.host_buf[q][i];
+                mine[i] = acc;
+            }
+            sh.barrier.wait();  // everybody has read the ranks' buffers
+            R_HIP(hipMemcpyAsync(buf, mine, buf_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+        }
+        if (!sh.rc[r]) R_TRY(pgsgd_session_exchange_end(s, buf, G));
+        if (!sh.rc[r]) R_HIP(hipMemcpyAsync(tail_out, buf + 6 * N, 2 * (size_t)G * sizeof(float), hipMemcpyDeviceToHost, stream));
+        return true;
+    };
     uint64_t iters = 0;
     uint32_t early = 0;
     double dmax_all = 0;
+    bool broken = false;
+    std::vector<float> sx, sy;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t it = 0; it < p0.iter_max; ++it) {
+    for (uint64_t it = 0; it < p0.iter_max && !broken; ++it) {
         const bool cooling = it >= sh.first_cooling;
         // the per-lane kernel needs four exchanges per iteration to keep the one-GPU quality, the tile kernel one
         // (measured with virtual ranks)
-        const uint32_t blocks = (!tiled || (warm_per_lane && !cooling)) ? 4u : 1u;
-        double dmax = 0;
-        for (uint32_t b = 0; b < blocks; ++b) {
-            const bool ok = !sh.failed.load();
-            if (ok) R_TRY(pgsgd_session_iteration_part(s, sh.etas[it], cooling ? 1 : 0, my_terms, b, blocks));
-            if (ok) R_TRY(pgsgd_session_exchange_begin(s, buf));
-            if (sh.rccl) {
-                // every rank must issue the collective or none: decide together
-                sh.barrier.wait();
-                if (!sh.failed.load()) {
-                    const int e = sh.rccl->all_reduce(buf, buf, 6 * N, 7 /* ncclFloat32 */, 0 /* ncclSum */, sh.comms[r], stream);
-                    if (e != 0 && !sh.rc[r]) {
-                        sh.rc[r] = PGSGD_E_HIP;
-                        sh.err[r] = std::string("ncclAllReduce: ") + (sh.rccl->error_string ? sh.rccl->error_string(e) : "error");
-                        sh.failed.store(1);
-                    }
-                }
-            } else {  // sum through pinned host memory (tests on a single GPU)
-                if (ok) R_HIP(hipMemcpyAsync(sh.host_buf[r], buf, 6 * N * sizeof(float), hipMemcpyDeviceToHost, stream));
-                if (ok) R_HIP(hipStreamSynchronize(stream));
-                sh.barrier.wait();
-                if (!sh.failed.load()) {
-                    float* mine = sh.host_buf[G + r];  // a second slot per rank for the sum
-                    const uint64_t n = 6 * N;
-                    for (uint64_t i = 0; i < n; ++i) {
-                        float acc = 0;
-                        for (int q = 0; q < G; ++q) acc += sh.host_buf[q][i];
-                        mine[i] = acc;
-                    }
-                }
-                sh.barrier.wait();  // everybody has read the ranks' buffers
-                if (!sh.failed.load()) R_HIP(hipMemcpyAsync(buf, sh.host_buf[G + r], 6 * N * sizeof(float), hipMemcpyHostToDevice, stream));
-            }
-            if (!sh.failed.load()) R_TRY(pgsgd_session_exchange_end(s, buf, G));
-            double d = 0;
-            if (!sh.failed.load()) R_TRY(pgsgd_session_sync(s, &d));
-            dmax = std::max(dmax, d);
+        const uint32_t blocks = (!sh.tiled || (sh.warm_per_lane && !cooling)) ? 4u : 1u;
+        for (uint32_t b = 0; b < blocks && !broken; ++b) {
+            if (!sh.rc[r]) R_TRY(pgsgd_session_iteration_part(s, sh.etas[it], cooling ? 1 : 0, my_terms, b, blocks));
+            broken = !exchange(h_tail + (size_t)b * 2 * G);
         }
-        // max |Delta| over the ranks (the reference's stop rule) and their frame-guard flags, through host memory
-        int hit = 0;
-        if (s && !sh.failed.load()) (void)pgsgd_session_frame_status(s, &hit, nullptr);
-        sh.dmax[r] = dmax;
-        sh.guard[r] = hit;
-        sh.barrier.wait();
-        dmax_all = *std::max_element(sh.dmax.begin(), sh.dmax.end());
-        const bool any_guard = std::any_of(sh.guard.begin(), sh.guard.end(), [](int v) { return v != 0; });
-        const bool failed = sh.failed.load() != 0;
-        sh.barrier.wait();  // everybody has read dmax / guard / failed before anyone writes them again
-        if (failed) break;
+        if (!broken && !sh.rc[r]) R_TRY(pgsgd_session_sync(s, nullptr));
+        // the one meeting of the iteration: did anybody fail?
+        if (sh.barrier.wait(broken || sh.rc[r] != 0)) {
+            broken = true;
+            break;
+        }
+        // every rank holds every rank's max |Delta| and frame-guard flag of every exchange: the same decisions everywhere
+        double dmax = 0;
+        bool any_guard = false;
+        for (uint32_t b = 0; b < blocks; ++b)
+            for (int q = 0; q < G; ++q) {
+                dmax = std::max(dmax, (double)h_tail[(size_t)b * 2 * G + q]);
+                any_guard = any_guard || h_tail[(size_t)b * 2 * G + G + q] != 0.0f;
+            }
+        dmax_all = dmax;
         if (any_guard) R_TRY(pgsgd_session_reframe(s));
         ++iters;
         if (r == 0 && p0.progress)
@@ -223,9 +262,26 @@ void rank_main(Shared& sh, int r) {
             early = 1;
             break;
         }
+        if (r == 0 && p0.snapshot && p0.snapshot_prefix && !sh.rc[r]) {  // :379-408: snapshot k after iteration k, k = 1..iter_max-1
+            sx.resize(2 * N);
+            sy.resize(2 * N);
+            R_TRY(pgsgd_session_download_coords(s, sx.data(), sy.data()));  // rank 0's copy = the merged coordinates
+            const std::string name = std::string(p0.snapshot_prefix) + std::to_string(it + 1);
+            fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");
+            if (!sh.rc[r]) R_TRY(pgsgd_write_lay_f32(name.c_str(), 2 * N, sx.data(), sy.data()));
+        }
     }
     if (r == 0 && p0.progress) fprintf(stderr, "\n");
-    if (r == 0 && s && !sh.failed.load()) {
+    // the far pulls of every rank's last tile launch: delivered, then merged like any other move
+    bool failed = broken;  // (a rank that left the loop on a barrier's verdict left it with every other rank)
+    if (!failed) failed = sh.barrier.wait(sh.rc[r] != 0);
+    if (!failed && sh.tiled) {
+        R_TRY(pgsgd_session_flush(s));
+        failed = !exchange(h_tail);
+        if (!failed && !sh.rc[r]) R_TRY(pgsgd_session_sync(s, nullptr));
+        if (!failed) failed = sh.barrier.wait(sh.rc[r] != 0);
+    }
+    if (r == 0 && !failed) {
         if (sh.Xd) R_TRY(pgsgd_session_download_coords_f64(s, sh.Xd, sh.Yd));
         else R_TRY(pgsgd_session_download_coords(s, sh.X, sh.Y));
         sh.stats.iterations = iters;
@@ -239,8 +295,7 @@ void rank_main(Shared& sh, int r) {
         (void)pgsgd_session_kernel_time(s, &sh.stats.kernel_ms, nullptr, 0);
         sh.stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    if (buf) (void)hipFree(buf);
-    if (s) pgsgd_session_destroy(s);
+    cleanup();
 }
 
 }  // namespace
@@ -249,14 +304,15 @@ void rank_main(Shared& sh, int r) {
 int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
     pgsgd::clear_error();
     if (stats) memset(stats, 0, sizeof *stats);
-    if (!g || !p || !X || !Y || p->n_devices < 2) return PGSGD_E_INVALID;
+    const bool forced_single = p && p->n_devices == 1 && pgsgd::debug_env("PGSGD_MULTI_FORCE") != nullptr;
+    if (!g || !p || !X || !Y || (p->n_devices < 2 && !forced_single)) return PGSGD_E_INVALID;
     const int G = (int)p->n_devices;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         set_error("no HIP device available; the layout kernels run on MI355X only, there is no CPU fallback");
         return PGSGD_E_NODEVICE;
     }
-    const bool host_reduce = getenv("PGSGD_MULTI_HOST_REDUCE") != nullptr;
+    const bool host_reduce = pgsgd::debug_env("PGSGD_MULTI_HOST_REDUCE") != nullptr;
     if (G > count && !host_reduce) {
         set_error("%d GPUs requested, %d present", G, count);
         return PGSGD_E_NODEVICE;
@@ -271,29 +327,54 @@ int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     sh.etas.resize(p->iter_max + 1);
     if (pgsgd_schedule(p, sh.etas.data(), sh.etas.size()) < 0) return PGSGD_E_INVALID;
     sh.first_cooling = (uint64_t)std::floor(p->cooling_start * (double)p->iter_max);
-    sh.dmax.assign(G, 0);
-    sh.guard.assign(G, 0);
     sh.rc.assign(G, 0);
     sh.err.assign(G, "");
     sh.X0 = X; sh.Y0 = Y; sh.X = X; sh.Y = Y; sh.Xd = Xd; sh.Yd = Yd;
     Rccl rccl;
+    auto release = [&] {
+        if (sh.rccl) for (ncclComm_t c : sh.comms) if (c) (void)rccl.destroy(c);
+        for (float* b : sh.host_buf) if (b) (void)hipHostFree(b);
+    };
     if (!host_reduce) {
         if (!rccl.load()) { set_error("n_devices = %d needs RCCL: librccl.so could not be loaded (%s)", G, dlerror()); return PGSGD_E_UNSUPPORTED; }
-        sh.comms.resize(G);
-        const int e = rccl.init_all(sh.comms.data(), G, sh.devices.data());
-        if (e != 0) { set_error("ncclCommInitAll on %d devices: %s", G, rccl.error_string ? rccl.error_string(e) : "error"); return PGSGD_E_HIP; }
+        sh.comms.assign(G, nullptr);
+        const ncclResult_t e = rccl.init_all(sh.comms.data(), G, sh.devices.data());
+        if (e != ncclSuccess) {
+            set_error("ncclCommInitAll on %d devices: %s", G, rccl.error_string ? rccl.error_string(e) : "error");
+            return PGSGD_E_HIP;
+        }
         sh.rccl = &rccl;
     } else {
-        sh.host_buf.assign(2 * G, nullptr);
-        for (int i = 0; i < 2 * G; ++i)
-            if (hipHostMalloc((void**)&sh.host_buf[i], 6 * g->n_nodes * sizeof(float)) != hipSuccess) { set_error("pinned exchange buffers"); return PGSGD_E_NOMEM; }
+        sh.host_buf.assign(2 * (size_t)G, nullptr);
+        for (size_t i = 0; i < sh.host_buf.size(); ++i)
+            if (hipHostMalloc((void**)&sh.host_buf[i], (6 * g->n_nodes + 2 * (size_t)G) * sizeof(float)) != hipSuccess) {
+                set_error("pinned exchange buffers");
+                release();
+                return PGSGD_E_NOMEM;
+            }
     }
-    std::vector<std::thread> th;
-    for (int r = 1; r < G; ++r) th.emplace_back(rank_main, std::ref(sh), r);
-    rank_main(sh, 0);
-    for (auto& t : th) t.join();
-    if (sh.rccl) for (ncclComm_t c : sh.comms) (void)rccl.destroy(c);
-    for (float* b : sh.host_buf) if (b) (void)hipHostFree(b);
+    {
+        std::vector<std::thread> th;
+        bool all_started = true;
+        try {
+            for (int r = 1; r < G; ++r) th.emplace_back(rank_main, std::ref(sh), r);
+        } catch (...) {
+            all_started = false;
+        }
+        {
+            std::lock_guard<std::mutex> lk(sh.start_m);
+            sh.start = all_started ? 1 : 2;
+        }
+        sh.start_cv.notify_all();
+        if (all_started) rank_main(sh, 0);
+        for (auto& t : th) t.join();
+        if (!all_started) {
+            release();
+            set_error("could not start %d host threads for the GPU ranks", G - 1);
+            return PGSGD_E_NOMEM;
+        }
+    }
+    release();
     for (int r = 0; r < G; ++r)
         if (sh.rc[r]) {
             set_error("GPU rank %d: %s", r, sh.err[r].c_str());

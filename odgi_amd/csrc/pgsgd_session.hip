@@ -67,6 +67,7 @@ struct pgsgd_session {
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
+    uint64_t tile_seed_base = 0;          // seed + stream_offset; a sharded session: seed alone (pgsgd_session_set_shard)
     unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
     uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
@@ -81,6 +82,8 @@ struct pgsgd_session {
     unsigned long long* d_ob_overflow = nullptr;  // messages that found their bucket's pool share used up (sent as atomics)
     uint64_t ob_total_chunks = 0;
     double aux_ms[2] = {0, 0};            // snapshot_kernel, far_drain_kernel (HIP events)
+    bool ob_pending = false;              // the last tile launch's far pulls wait in the outbox (drained before the next launch)
+    bool tile_forced = false;             // PGSGD_TILE_FORCE (parity knob) was set when the session was created
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
     uint64_t term0_terms = 0;
     uint32_t ob_part_shift = 13;          // log2 of the node ends one drain workgroup accumulates in LDS
@@ -97,12 +100,13 @@ struct pgsgd_session {
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_grid = 0;
-    // kernel timing: e[0..1] bracket the update kernel; a tile launch also has e[2] (before its snapshot kernel)
-    // and e[3] (after its drain kernel)
+    // kernel timing: e[0..1] bracket the update kernel; a tile launch also has e[2] (before the drain of the launch
+    // before it) and e[3] (after that drain, before its snapshot kernel)
     struct EvSet { hipEvent_t e[4]; int n; };
     std::vector<EvSet> free_events, pending_events;
     double kernel_ms = 0;
     uint64_t launches = 0;
+    uint64_t n_kernels = 0, n_copies = 0;  // everything the iteration calls put on the stream (pgsgd_session_launch_counts)
 };
 
 static int pick_device(int requested, int* out) {
@@ -128,10 +132,10 @@ static int collect_events(pgsgd_session* s) {
         HIP_TRY(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
         s->kernel_ms += ms;
         s->launches++;
-        if (ev.n == 4) {
-            HIP_TRY(hipEventElapsedTime(&ms, ev.e[2], ev.e[0]));
+        if (ev.n == 4) {  // e[2] .. drain of the launch before .. e[3] .. snapshot .. e[0] .. tile kernel .. e[1]
+            HIP_TRY(hipEventElapsedTime(&ms, ev.e[3], ev.e[0]));
             s->aux_ms[0] += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, ev.e[1], ev.e[3]));
+            HIP_TRY(hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
             s->aux_ms[1] += ms;
         }
         s->free_events.push_back(ev);
@@ -402,6 +406,7 @@ static double check_pairs_stress(const pgsgd_session* s, const float* X, const f
 }
 
 static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts);
+static int drain_outbox(pgsgd_session* s, unsigned long long* far_next);
 
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
     pgsgd::clear_error();
@@ -481,17 +486,21 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         (void)hipFree(d_counts);
         (void)hipFree(d_bad);
         if (h_bad) { set_error("a step names a node rank outside the graph"); return fail(PGSGD_E_INVALID); }
-        // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
-        // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
-        // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (a second bucketing pass is the fix).
+        // Outbox buckets: power-of-two ranges of node ends.  A tile workgroup stages a 64-byte line per bucket in LDS (and
+        // a few words of bookkeeping: 84 bytes a bucket), and LDS is what bounds the workgroups per CU once the kernel's
+        // registers allow five or six: at most 128 buckets while one drain workgroup can still accumulate a whole bucket
+        // (2^14 ends, 128 KiB of LDS: graphs up to 2^20 nodes), at most 256 beyond, where a bucket is read by
+        // 2^(shift - 14) drain workgroups (a second bucketing pass is the fix for very large graphs).
         uint32_t ob_shift = 13;
-        if (const char* e = getenv("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
+        if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
+        else if (((2 * g->n_nodes - 1) >> 14) + 1 <= 128) ob_shift = 14;
         while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
         s->ob.shift = ob_shift;
         s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
-        if (const char* e = getenv("PGSGD_OUTBOX_QBITS"))  // test knob: narrow packed steps, so that most messages take the path of a step too wide for the packed form
+        if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_QBITS"))  // test knob: narrow packed steps, so that most messages take the path of a step too wide for the packed form
             s->ob.qbits = (uint32_t)std::min<int>((int)s->ob.qbits, std::max(2, atoi(e)));
         s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
+        if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_PART_SHIFT")) s->ob_part_shift = (uint32_t)std::min<int>((int)ob_shift, std::max(10, atoi(e)));  // experiment knob
         s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
         s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
         for (uint64_t i = 0; i < g->n_nodes; ++i) {
@@ -529,18 +538,18 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // (300k nodes: 1.97e10 terms/s against 1.33e10 with R = 512) and cost nothing on large ones (1e6 nodes, five
         // seeds each: 3.10e10 terms/s, stress 0.246 against 2.98e10, 0.255 with R = 512;
         // profiles/r01/tiles_region_256_vs_512.jsonl).  R = 128 with 256 lanes diverges.
-        if (const char* e = getenv("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
             const long r = atol(e);
             if (r >= 32 && r <= 2048 && (r & (r - 1)) == 0) {
                 s->region = (uint32_t)r;
                 s->tile_steps = (uint32_t)(r - r / 8);
             }
         }
-        if (const char* e = getenv("PGSGD_TILE_SUBSTEPS")) {  // experiment knob: window refreshes per iteration
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_SUBSTEPS")) {  // experiment knob: window refreshes per iteration
             const long k = atol(e);
             if (k >= 1 && k <= 64) s->tile_substeps = (uint32_t)k;
         }
-        if (const char* e = getenv("PGSGD_TILE_BLOCK")) {  // experiment knob: lanes per workgroup
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_BLOCK")) {  // experiment knob: lanes per workgroup
             const long b = atol(e);
             if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
         }
@@ -555,7 +564,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
-        const bool force = getenv("PGSGD_TILE_FORCE") != nullptr;
+        const bool force = pgsgd::debug_env("PGSGD_TILE_FORCE") != nullptr;
+        s->tile_forced = force;
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
         bool short_paths = true;
         for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
@@ -569,7 +579,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
             if (rc) return fail(rc);
             HostTiles ht = group_tiles(raw, g->n_nodes, s->region);
-            if (const char* e = getenv("PGSGD_TILE_LANES")) {
+            if (const char* e = pgsgd::debug_env("PGSGD_TILE_LANES")) {
                 const long l = atol(e);
                 if (l >= 1)
                     for (pgsgd::Tile& t : ht.tiles) t.lanes = std::min<uint32_t>(t.lanes, (uint32_t)l);
@@ -581,7 +591,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 s->tile_far = pgsgd::kFarExclusive;
             }
             s->tile_grid = (uint32_t)(prop.multiProcessorCount * bpc);
-            if (const char* e = getenv("PGSGD_TILE_GRID")) {
+            if (const char* e = pgsgd::debug_env("PGSGD_TILE_GRID")) {
                 const long gr = atol(e);
                 if (gr >= 1 && gr <= (long)s->tile_grid) s->tile_grid = (uint32_t)gr;
             }
@@ -709,6 +719,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     c.space_quant = p->space_quantization_step;
     c.terms_per_anchor = p->terms_per_anchor ? p->terms_per_anchor : 1;
     c.seed_base = p->seed + (uint64_t)p->stream_offset;
+    s->tile_seed_base = c.seed_base;
     c.zc.init(p->theta);
     c.node_steps = nullptr;
     c.hot_scale = (float)((double)s->n_streams / (double)g->n_steps);
@@ -788,7 +799,7 @@ static int choose_xform(pgsgd_session* s, const float* X, const float* Y) {
     }
     if (!(minx <= maxx) || !(miny <= maxy)) { set_error("the initial layout has no finite coordinate"); return PGSGD_E_INVALID; }
     double factor = 8.0;
-    if (const char* e = getenv("PGSGD_FRAME_SPAN")) factor = std::max(1.0, atof(e));  // test knob: a frame this tight must widen itself
+    if (const char* e = pgsgd::debug_env("PGSGD_FRAME_SPAN")) factor = std::max(1.0, atof(e));  // test knob: a frame this tight must widen itself
     const double extent = std::max({maxx - minx, maxy - miny, (double)s->max_path_bp, 1.0});
     const int span_log2 = (int)std::ceil(std::log2(factor * extent));
     const double span = std::ldexp(1.0, span_log2);
@@ -810,7 +821,7 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
         if (rc) return rc;
         s->frame_doublings = 0;
     }
-    if (s->tiled && !getenv("PGSGD_TILE_FORCE")) {
+    if (s->tiled && !s->tile_forced) {
         // 0.1 = long-range distances off by a third on average; `-N d` on a sorted graph measures ~0.01
         const double st = check_pairs_stress(s, X, Y);
         s->warm_per_lane = !(st <= 0.1);
@@ -981,7 +992,7 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     a.epoch = epoch;
     const uint32_t lanes = std::min<uint32_t>(t.lanes, s->tile_block);
     hipLaunchKernelGGL(pgsgd::tile_trace_kernel, dim3((lanes + pgsgd::kTileBlock - 1) / pgsgd::kTileBlock), dim3(pgsgd::kTileBlock), 0, s->stream, s->dc, t,
-                       tile, lanes, term_begin, term_end, a, d_out);
+                       tile, lanes, term_begin, term_end, a, s->tile_seed_base, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, cnt * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -990,14 +1001,25 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     return (int64_t)cnt;
 }
 
+// Multi-GPU: this session is rank `rank` of `world`.  by_region 0: every work item's tiles are dealt out to the ranks
+// (tile shard); 1: every world-th work item (node region) with all its tiles belongs to this rank — the ranks' private
+// windows are then disjoint, which keeps the one-GPU layout quality, but a launch has only (work items / world) items to
+// fill the GPU with; -1: by region when that still leaves a launch a thousand items per rank (BASELINE config 5 at
+// G = 8), by tile otherwise.  Returns 0: not a tiled session (the caller shards the term count),
+// 1: sharded by tile, 2: by region.
+// A sharded session's tile streams are keyed on (seed, iteration, tile, lane) only: every tile is run by exactly one
+// rank, and a rank-dependent stream_offset (which the per-lane streams of the ranks need to differ) would make rank r's
+// tile t draw the stream of rank 0's tile t + 1024 r.
 extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region) {
     pgsgd::clear_error();
     if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
+    if (by_region < 0) by_region = s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000 ? 1 : 0;
     s->shard_rank = by_region ? rank : 0;
     s->shard_world = by_region ? world : 1;
     s->tshard_rank = by_region ? 0 : rank;
     s->tshard_world = by_region ? 1 : world;
-    return s->tiled ? 1 : 0;
+    s->tile_seed_base = world > 1 ? s->params.seed : s->params.seed + (uint64_t)s->params.stream_offset;
+    return s->tiled ? (by_region ? 2 : 1) : 0;
 }
 
 extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles, uint64_t* n_work_items,
@@ -1024,7 +1046,7 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     const uint32_t B = s->ob.n_buckets;
     double frac = 1.3 * s->ob_msgs_per_term;  // every partner far, and slack for buckets that draw more than their share
     uint64_t open_chunks = (uint64_t)pgsgd::kObGroup * (s->tile_grid + 4);  // every resident workgroup may hold one partly filled group of chunks per bucket
-    if (const char* e = getenv("PGSGD_OUTBOX_FRACTION")) {  // test knob: a pool this small overflows into direct atomics
+    if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_FRACTION")) {  // test knob: a pool this small overflows into direct atomics
         frac = std::max(0.0, atof(e));
         open_chunks = pgsgd::kObGroup;
     }
@@ -1073,6 +1095,36 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     return PGSGD_OK;
 }
 
+// Deliver the far pulls waiting in the outbox (if any): far_drain_kernel adds every bucket's messages up and moves the
+// node ends; then the chunk counters, the work queues and `far_next` — the far-pull counter the next launch writes —
+// start from zero.
+static int drain_outbox(pgsgd_session* s, unsigned long long* far_next) {
+    if (!s->ob_pending) return PGSGD_OK;
+    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(s->ob.n_buckets << (s->ob.shift - s->ob_part_shift)), dim3(1024),
+                       sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift, s->dc.frame_flag);
+    s->n_kernels++;
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
+                       s->d_queue, far_next);
+    s->n_kernels++;
+    HIP_TRY(hipGetLastError());
+    s->ob_pending = false;
+    return PGSGD_OK;
+}
+
+// Apply what is still waiting in the outbox.  A tile launch's far pulls are delivered right before the NEXT launch, so
+// after an iteration the coordinates lack the pulls its last launch collected: a run flushes before it reads its result
+// (pgsgd_layout_run does), a snapshot between iterations does not.  A no-op for sessions that run the per-lane kernel.
+extern "C" int pgsgd_session_flush(pgsgd_session* s) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (!s->ob_pending) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    // (the counter zeroed is the one the next launch — colour 0 unless it has no items — will write)
+    const int next_colour = s->n_items[0] ? 0 : 1;
+    return drain_outbox(s, s->d_far + 2 * next_colour + (s->far_launches[next_colour] & 1u));
+}
+
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
     return pgsgd_session_iteration_part(s, eta, cooling, n_terms, 0, 1);
 }
@@ -1118,15 +1170,17 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const uint64_t nt = s->n_tiles + 1;
             hipLaunchKernelGGL(pgsgd::tile_terms_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s->stream, s->d_tiles, s->n_tiles,
                                s->tile_steps_total, n_terms, s->d_term0);
+            s->n_kernels++;
             HIP_TRY(hipGetLastError());
             s->term0_terms = n_terms;
         }
         // nothing was counted before a colour's first launch: assume three quarters of the partners of this call's
         // terms are far, half of them in each colour's launch
         const double h0 = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
-        HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, 2 * sizeof(unsigned int), s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));  // (the frame-guard flag next to it stays set until the frame is widened)
         // tile subsets: (part, window refresh, tile shard of this device) -> tiles with index = sub (mod n_sub)
         const uint32_t n_sub = n_parts * s->tile_substeps * s->tshard_world;
+        s->n_copies++;
         const int snap_grid = (int)std::min<uint64_t>((s->n_steps + 255) / 256, 256 * 16);
         bool snapshot_taken = false;
         for (uint32_t ps = part * s->tile_substeps; ps < (part + 1) * s->tile_substeps; ++ps)
@@ -1156,7 +1210,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
-            ta.experiment = getenv("PGSGD_TILE_EXP") ? (uint32_t)atoi(getenv("PGSGD_TILE_EXP")) : 0u;
+            ta.seed_base = s->tile_seed_base;
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;
@@ -1167,13 +1221,21 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own
             const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
             ta.n_items = s->n_items[colour] - windowless;
+            // The far pulls the launch before this one collected are delivered now, right before the windows are staged:
+            // an iteration ends with a launch's window-local terms, not with the arrival of a launch's worth of far
+            // pulls (each an average of a dozen long-range pulls — noise at the scale of neighbouring nodes until the
+            // next launch's local terms have worked on it; tools/cpu_transient.py).
             HIP_TRY(hipEventRecord(ev.e[2], s->stream));
-            // Partners outside a window are read from a snapshot of the coordinates: taken before every launch while the
-            // learning rate is at its cap for most pairs (the iterations before cooling, where a colour's launch moves
-            // node ends far), once per call in the cooling iterations (where it makes no measurable difference and the
-            // refresh is 0.6 ms at 4.7e7 steps).  profiles/r02/curves_far_policy.jsonl
-            if (!snapshot_taken || !cooling) {
+            rc = drain_outbox(s, s->d_far + 2 * colour + (launches & 1u));
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev.e[3], s->stream));
+            // Partners outside a window are read from a snapshot of the coordinates, taken once per call, after the drain.
+            // (Round 2 refreshed it before every launch of a warm iteration to tame the far pulls delivered at the END of
+            // an iteration; delivered at the start of the next launch they need no second refresh: the mirror's curves
+            // with one and with two refreshes are the same, tools/cpu_transient.py.)
+            if (!snapshot_taken) {
                 hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
+                s->n_kernels++;
                 HIP_TRY(hipGetLastError());
                 snapshot_taken = true;
             }
@@ -1181,6 +1243,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             if (ta.n_items) {
                 hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, true), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, ta, ts, a);
+                s->n_kernels++;
                 HIP_TRY(hipGetLastError());
             }
             if (windowless) {
@@ -1190,21 +1253,15 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
                 tw.queue = s->d_queue + 2;
                 hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, tw, ts, a);
+                s->n_kernels++;
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(ev.e[1], s->stream));
-            hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(s->ob.n_buckets << (s->ob.shift - s->ob_part_shift)), dim3(1024),
-                               sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift, s->dc.frame_flag);
-            HIP_TRY(hipGetLastError());
-            // (the far counter the next launch will write: colours alternate unless one of them has no work items)
-            const int next_colour = s->n_items[1 - colour] ? 1 - colour : colour;
-            hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
-                               s->d_queue, s->d_far + 2 * next_colour + (s->far_launches[next_colour] & 1u));
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(ev.e[3], s->stream));
+            s->ob_pending = true;
             s->pending_events.push_back(ev);
         }
         HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+        s->n_copies++;
         return PGSGD_OK;
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
@@ -1217,8 +1274,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         if (rc) return rc;
     }
     ev.n = 2;
-    HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, 2 * sizeof(unsigned int), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));  // (the frame-guard flag next to it stays set until the frame is widened)
     pgsgd::IterArgs a;
+    s->n_copies++;
     a.n_terms = n_terms;
     a.eta = (float)eta;
     a.cooling = cooling ? 1u : 0u;
@@ -1227,10 +1285,12 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     const uint32_t grid = (s->n_streams + block - 1) / block;
     HIP_TRY(hipEventRecord(ev.e[0], s->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
+    s->n_kernels++;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.e[1], s->stream));
     s->pending_events.push_back(ev);
     HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+    s->n_copies++;
     return PGSGD_OK;
 }
 
@@ -1240,8 +1300,13 @@ extern "C" int pgsgd_session_reframe(pgsgd_session* s) {
     if (!s) return PGSGD_E_INVALID;
     if (s->fmt != pgsgd::kFmtQ32) return PGSGD_OK;
     HIP_TRY(hipSetDevice(s->device));
+    if (s->ob_pending) {  // messages in the outbox are steps in quanta of the frame they were computed in
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     const uint64_t n_ends = 2 * s->n_nodes;
     const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    HIP_TRY(hipMemsetAsync(s->d_delta_max + 1, 0, sizeof(unsigned int), s->stream));  // the guard flag: cleared only here
     hipLaunchKernelGGL(pgsgd::reframe_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_coords, n_ends);
     HIP_TRY(hipGetLastError());
     if (s->d_base) {
@@ -1308,6 +1373,13 @@ extern "C" int64_t pgsgd_session_outbox_overflow(pgsgd_session* s) {
     return (int64_t)v;
 }
 
+extern "C" int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launches, uint64_t* copies) {
+    if (!s) return PGSGD_E_INVALID;
+    if (kernel_launches) *kernel_launches = s->n_kernels;
+    if (copies) *copies = s->n_copies;
+    return PGSGD_OK;
+}
+
 extern "C" int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, double* drain_ms) {
     if (!s) return PGSGD_E_INVALID;
     if (snapshot_ms) *snapshot_ms = s->aux_ms[0];
@@ -1339,6 +1411,19 @@ extern "C" int pgsgd_session_exchange_begin(pgsgd_session* s, void* device_buf_6
         hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (float*)device_buf_6N_floats);
     else
         hipLaunchKernelGGL(pgsgd::exchange_prepare_kernel<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (float*)device_buf_6N_floats);
+    HIP_TRY(hipGetLastError());
+    return PGSGD_OK;
+}
+
+// exchange_begin with a tail: device_buf holds 6N + 2*world floats; slot 6N + rank = this rank's max |Delta| since the
+// last iteration call, slot 6N + world + rank = its frame-guard flag, the other ranks' slots zero — after the SUM
+// all-reduce every rank holds all of them, so the stop rule and the frame widening need no collective of their own.
+extern "C" int pgsgd_session_exchange_begin_stats(pgsgd_session* s, void* device_buf, uint32_t rank, uint32_t world) {
+    if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
+    const int rc = pgsgd_session_exchange_begin(s, device_buf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pgsgd::exchange_stats_kernel, dim3((2 * world + 255) / 256), dim3(256), 0, s->stream, s->d_delta_max, rank, world,
+                       (float*)device_buf + 6 * s->n_nodes);
     HIP_TRY(hipGetLastError());
     return PGSGD_OK;
 }
@@ -1413,7 +1498,8 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         int dev;  // still refuse to "succeed" without a device: the product never runs on the CPU
         return pick_device(p->device, &dev);
     }
-    if (p->n_devices > 1) return pgsgd_layout_run_multi(g, p, X, Y, Xd, Yd, stats);  // pgsgd_multi.cpp
+    // pgsgd_multi.cpp (PGSGD_MULTI_FORCE, a test knob: a one-device run through the multi-GPU driver and a one-rank RCCL communicator)
+    if (p->n_devices > 1 || (p->n_devices == 1 && pgsgd::debug_env("PGSGD_MULTI_FORCE"))) return pgsgd_layout_run_multi(g, p, X, Y, Xd, Yd, stats);
     const auto t0 = std::chrono::steady_clock::now();
     pgsgd::PhaseTimer timer;
     pgsgd_session* s = nullptr;
@@ -1457,6 +1543,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         }
     }
     if (p->progress) fprintf(stderr, "\n");
+    if (rc == PGSGD_OK) rc = pgsgd_session_flush(s);  // the far pulls of the last tile launch
     timer.lap("iterations");
     if (rc == PGSGD_OK) rc = Xd ? pgsgd_session_download_coords_f64(s, Xd, Yd) : pgsgd_session_download_coords(s, X, Y);
     timer.lap("coordinates download");

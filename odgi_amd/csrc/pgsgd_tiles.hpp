@@ -129,7 +129,7 @@ struct TileArgs {
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
     const uint4* recs2;                // [2S] step records with the coordinate snapshot: {handle,len,pos}, {w_first, w_second}
-    uint32_t experiment;               // PGSGD_TILE_EXP (profiling only, results invalid): 1 = far updates are dropped
+    uint64_t seed_base;                // of the tile streams (tile_stream_seed)
     Outbox ob;
 };
 
@@ -417,35 +417,40 @@ __device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampl
     return r;
 }
 
-// a term whose first step is picked, whose Zipf/uniform and direction coins are drawn (path_sgd_layout.cpp:205-206) and
-// whose Zipf table entry is on its way
+// The stage registers of the term loop.  Every VGPR a stage keeps across a trip is held twice (two alternating sets, see the
+// loop), and the kernel's occupancy is set by its VGPRs (round 2: 110 -> 4 waves per SIMD), so a stage keeps only
+// what cannot be had again for a few instructions: step offsets instead of step records (the records are re-read from
+// the tile's LDS copy where they are used), the generator word with the term's coins instead of the decoded coins,
+// no validity flags (kNoTerm in `ka`: divergent flags live in SGPR pairs, and the kernel was spilling SGPRs).
+constexpr uint32_t kNoTerm = 0xffffffffu;
+
+// a term whose first step is picked and whose Zipf table entry is on its way
 struct PickedTerm {
-    uint4 ra;          // first step's record
-    double2 zd;        // {zeta_n, eta_n} for the jump
-    uint32_t s_rank, jump;
-    uint32_t flags;    // low half of the term's first word: coins and dither
-    bool valid, zipf, back;
+    double2 zd;      // {zeta_n, eta_n} for the jump (a Zipf term only)
+    uint32_t ka;     // first step, as an offset inside the tile; kNoTerm: no term in this slot
+    uint32_t flags;  // low half of the term's first word: coins and dither
 };
 
 // a term whose first step and partner are drawn and whose partner record is on its way
 struct PendingTerm {
-    uint4 ra;    // first step's record {handle, len, pos}
-    uint4 rb_l;  // partner's record from the tile's LDS copy (partner inside the tile) ...
-    uint4 rb_g;  // ... or from global memory, with
-    ulonglong2 snap;  // the partner's coordinate snapshot {w_first, w_second}, loaded as two 64-bit words (no repacking of a
-                      // value in flight).  Separate registers for the two sources of the record: a select of the two
-                      // ADDRESSES would become one flat load that waits for everything in flight
-    uint32_t flips;   // bit 0: far end of the first step's node, bit 1: of the partner's
-    uint32_t dither;
-    bool valid, from_global;
+    uint4 rb_g;                // partner's record {handle, len, pos} from global memory (a partner outside the tile) with
+    unsigned long long snapw;  // the snapshot word of the chosen end of its node — the one of the record's two the term reads
+    uint32_t ka;               // kNoTerm: no term in this slot
+    uint32_t kb_off;           // partner step minus the tile's first step: a step of the tile when < tile steps
+    uint32_t flags;
 };
 
 // COOLING: the launch's iteration is a cooling one (every partner by Zipf) — known per launch, so the coin and the
 // uniform-partner branch are compiled out.  LOCAL: the work items have a window (the usual case); window-less items
 // (tiles of unsorted stretches) run in their own launch with every end read from global memory and every update sent
 // through the outbox.
-template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL>
-__global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
+// Waves per SIMD the register allocation aims at (a workgroup is one wave per SIMD, so this is also the workgroups per
+// CU): the kernel hides its LDS round trips and its gathers behind other waves.
+#ifndef PGSGD_TILE_WAVES
+#define PGSGD_TILE_WAVES 5
+#endif
+template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int ABL = 0>
+__global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
     uint4* trec = reinterpret_cast<uint4*>(lds + 4 * (size_t)ta.region);         // [T] tile records
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
-            if (worker) rng.seed(tile_stream_seed(c.seed_base, a.epoch, ti, threadIdx.x));
+            if (worker) rng.seed(tile_stream_seed(ta.seed_base, a.epoch, ti, threadIdx.x));
             // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and two trips more
             // than the longest lane needs.  Every trip finishes term j - 2, draws the partner of term j - 1 (and requests
             // its record) and picks the first step of term j (and requests its Zipf table entry): whatever a trip loads
@@ -526,56 +531,57 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
             // for the load right where it was issued).
             PickedTerm K0, K1;
             PendingTerm Q0, Q1;
-            K0.valid = K1.valid = false;
-            Q0.valid = Q1.valid = false;
+            K0.ka = K1.ka = kNoTerm;
+            Q0.ka = Q1.ka = kNoTerm;
             // (stages take and return their registers BY VALUE: structs reached through references stay in memory, and a
             // select between two members becomes a load from a selected address — scratch traffic and flat loads)
+            // what the first word says about the partner (path_sgd_layout.cpp:205-206), from the step offset and the coins
+            auto jump_of = [&](uint32_t ka, uint32_t flags, uint32_t& s_rank, bool& zipf, bool& back) -> uint32_t {
+                s_rank = t0 + ka - pstart;
+                zipf = COOLING || (flags >> 31);
+                back = (s_rank > 0 && ((flags >> 30) & 1u)) || s_rank == cnt - 1;
+                const uint32_t room = back ? s_rank : cnt - s_rank - 1;
+                return ts.space < room ? ts.space : room;
+            };
             auto pick_stage = [&](uint32_t j) -> PickedTerm {
                 PickedTerm Kw;
-                Kw.valid = false;
+                Kw.ka = kNoTerm;
+                Kw.flags = 0;
                 if (worker && j < trips && threadIdx.x + j * lanes < n_tile_terms) {
                     // first step: uniform inside the tile; the reference's coins (path_sgd_layout.cpp:205-206) from the same word
-                    Kw.valid = true;
-                    const uint32_t ka = below32_hi(rng, t.n, Kw.flags);  // offset inside the tile
-                    Kw.ra = trec[ka];
-                    Kw.s_rank = t0 + ka - pstart;
-                    Kw.zipf = COOLING || (Kw.flags >> 31);
-                    Kw.back = false;
-                    Kw.jump = 0;
-                    if (Kw.zipf) {
-                        Kw.back = (Kw.s_rank > 0 && ((Kw.flags >> 30) & 1u)) || Kw.s_rank == cnt - 1;
-                        const uint32_t room = Kw.back ? Kw.s_rank : cnt - Kw.s_rank - 1;
-                        Kw.jump = ts.space < room ? ts.space : room;
-                        Kw.zd = ts.zipf_tab[Kw.jump];
-                    }
+                    Kw.ka = below32_hi(rng, t.n, Kw.flags);
+                    uint32_t s_rank;
+                    bool zipf, back;
+                    const uint32_t jump = jump_of(Kw.ka, Kw.flags, s_rank, zipf, back);
+                    if (zipf) Kw.zd = ts.zipf_tab[jump];
                 }
                 return Kw;
             };
             auto partner_stage = [&](const PickedTerm Kr) -> PendingTerm {
                 PendingTerm Qw;
-                Qw.valid = false;
-                if (Kr.valid) {
-                    // partner by the reference's rule (:207-237) from the term's second word; the two end choices (:253,262)
-                    Qw.valid = true;
-                    Qw.ra = Kr.ra;
-                    uint32_t b_rank;
-                    if (Kr.zipf) {
-                        const uint32_t z = zipf_tile(rng, ts, Kr.jump, Kr.zd.x, Kr.zd.y);
-                        b_rank = Kr.back ? Kr.s_rank - z : Kr.s_rank + z;
+                Qw.ka = kNoTerm;
+                if (Kr.ka != kNoTerm) {
+                    // partner by the reference's rule (:207-237) from the term's second word
+                    Qw.ka = Kr.ka;
+                    Qw.flags = Kr.flags;
+                    uint32_t s_rank, b_rank;
+                    bool zipf, back;
+                    const uint32_t jump = jump_of(Kr.ka, Kr.flags, s_rank, zipf, back);
+                    if (zipf) {
+                        const uint32_t z = zipf_tile(rng, ts, jump, Kr.zd.x, Kr.zd.y);
+                        b_rank = back ? s_rank - z : s_rank + z;
                     } else {
                         uint32_t unused;
                         b_rank = below32_hi(rng, cnt, unused);
                     }
-                    Qw.flips = ((Kr.flags >> 29) & 1u) | (((Kr.flags >> 28) & 1u) << 1);
-                    Qw.dither = Kr.flags & ((1u << 2 * kDitherBits) - 1u);
-                    // the partner's record: the tile's LDS copy when it is a step of the tile, otherwise ONE 32-byte gather
-                    // that also brings the coordinates both ends of its node had at the last snapshot
+                    // the partner's record: the tile's LDS copy when it is a step of the tile (read where it is used), otherwise
+                    // ONE 32-byte line: the record and, of the coordinates both ends of its node had at the last snapshot, the
+                    // word of the end the term's coin chose (:262, bit 28)
                     const uint32_t kb = pstart + b_rank;
-                    Qw.from_global = !(kb - t0 < t.n);
-                    if (!Qw.from_global) Qw.rb_l = trec[kb - t0];
-                    if (Qw.from_global) {
+                    Qw.kb_off = kb - t0;
+                    if (!(Qw.kb_off < t.n)) {
                         Qw.rb_g = ta.recs2[2 * (uint64_t)kb];
-                        Qw.snap = reinterpret_cast<const ulonglong2*>(ta.recs2)[2 * (uint64_t)kb + 1];
+                        Qw.snapw = reinterpret_cast<const unsigned long long*>(ta.recs2)[4 * (uint64_t)kb + 2 + ((Kr.flags >> 28) & 1u)];
                     }
                 }
                 return Qw;
@@ -585,16 +591,18 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                 bool msg_a = false, msg_b = false;
                 uint32_t end_a = 0, end_b = 0;
                 int32_t mqx = 0, mqy = 0;
-                if (Qr.valid) {
-                    // (component by component: a select between the two structs would be done on their ADDRESSES and force them into memory)
-                    const uint4 rb = make_uint4(Qr.from_global ? Qr.rb_g.x : Qr.rb_l.x, Qr.from_global ? Qr.rb_g.y : Qr.rb_l.y,
-                                                Qr.from_global ? Qr.rb_g.z : Qr.rb_l.z, Qr.from_global ? Qr.rb_g.w : Qr.rb_l.w);
+                if (Qr.ka != kNoTerm) {
+                    const uint32_t flip_a = (Qr.flags >> 29) & 1u, flip_b = (Qr.flags >> 28) & 1u;  // the two end choices (:253,262)
+                    const bool from_global = !(Qr.kb_off < t.n);
+                    const uint4 ra = trec[Qr.ka];
+                    uint4 rb = Qr.rb_g;
+                    if (!from_global) rb = trec[Qr.kb_off];
                     // the path position moves to the chosen end of each node (:242-269)
-                    uint64_t pos_a = (uint64_t)Qr.ra.z | ((uint64_t)Qr.ra.w << 32), pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
-                    if (Qr.flips & 1u) pos_a += Qr.ra.y;
-                    if (Qr.flips & 2u) pos_b += rb.y;
-                    end_a = Qr.ra.x ^ (Qr.flips & 1u);
-                    end_b = rb.x ^ (Qr.flips >> 1);
+                    uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32), pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+                    if (flip_a) pos_a += ra.y;
+                    if (flip_b) pos_b += rb.y;
+                    end_a = ra.x ^ flip_a;
+                    end_b = rb.x ^ flip_b;
                     // ends inside the staged window live in LDS (unsigned compare covers "below the window")
                     // A tile with a window has all its nodes inside it (that is what binds it to the window): the first end is
                     // always in LDS, and so is a partner that is a step of the tile.  Only window-less tiles read global words
@@ -604,10 +612,10 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                     uint64_t wa, wb;
                     if (LOCAL) {
                         wa = win[la];
-                        wb = in_b ? win[lb] : ((Qr.flips & 2u) ? Qr.snap.y : Qr.snap.x);  // live word, or the snapshot that came with the record
+                        wb = in_b ? win[lb] : Qr.snapw;  // live word, or the snapshot that came with the record
                     } else {
                         wa = load_word<COORD_LOAD>(c.coords, end_a);
-                        wb = Qr.from_global ? ((Qr.flips & 2u) ? Qr.snap.y : Qr.snap.x) : load_word<COORD_LOAD>(c.coords, end_b);
+                        wb = from_global ? Qr.snapw : load_word<COORD_LOAD>(c.coords, end_b);
                     }
                     // (float)(a - b) of two 32-bit fields, through fp64: the difference is exact there and is rounded once, as
                     // the conversion from a 64-bit integer is — four instructions instead of fifteen
@@ -621,8 +629,9 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         r_y *= 2.0f;
                     }
                     dmax = fmaxf(dmax, abs_delta);
-                    const float ux = (float)(Qr.dither >> kDitherBits) * (1.0f / (float)(1u << kDitherBits));
-                    const float uy = (float)(Qr.dither & ((1u << kDitherBits) - 1u)) * (1.0f / (float)(1u << kDitherBits));
+                    const uint32_t dither = Qr.flags & ((1u << 2 * kDitherBits) - 1u);
+                    const float ux = (float)(dither >> kDitherBits) * (1.0f / (float)(1u << kDitherBits));
+                    const float uy = (float)(dither & ((1u << kDitherBits) - 1u)) * (1.0f / (float)(1u << kDitherBits));
                     float fx = r_x * c.xf.scale;
                     float fy = r_y * c.xf.scale;
                     fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(kTileBlock) void sgd_tile_kernel(DevConst c, TileAr
                         else msg_a = true;
                     }
                 }
-                if (ta.experiment & 1u) msg_a = msg_b = false;
+                if (ABL == 1) msg_a = msg_b = false;  // profiling instance: far updates are dropped (results invalid)
                 return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
             };
             auto send = [&](const FarMessages m) {
@@ -795,13 +804,13 @@ __global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets, uint32_t
 // sampler-only replay of one tile's terms (parity hook): out[(q - first_term)*4 + {0..3}] = {ka, kb, off_a, off_b};
 // one thread per lane of the tile, terms in the lane's stream order
 __global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile t, uint64_t tile_index, uint32_t lanes, uint64_t term_begin,
-                                                                uint64_t term_end, IterArgs a, uint64_t* out) {
+                                                                uint64_t term_end, IterArgs a, uint64_t seed_base, uint64_t* out) {
     const uint64_t pstart = c.path_first[t.path];
     const uint64_t cnt = c.path_first[t.path + 1] - pstart;
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
     Xoshiro256Plus rng;
-    rng.seed(tile_stream_seed(c.seed_base, a.epoch, tile_index, lane));
+    rng.seed(tile_stream_seed(seed_base, a.epoch, tile_index, lane));
     for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
         uint32_t flags;
         const uint64_t k = t.t0 + below32_hi(rng, t.n, flags);

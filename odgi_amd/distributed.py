@@ -7,16 +7,18 @@ ranks), in `exchanges_per_iteration` parts (per-lane kernel: slices of 1/G of th
 the tiles with index = part*G + r (mod B*G), each with its whole share of the iteration's terms).
 After each part the ranks exchange what they changed since the previous exchange:
 
-    begin : buf[0..4N) = coords - base ; buf[4N..6N) = |delta of each node end|^2      (HIP kernel)
-    all-reduce(SUM) of the one fused 6N-float buffer over the G ranks                    (RCCL)
+    begin : buf[0..4N) = coords - base ; buf[4N..6N) = |delta of each node end|^2 ;
+            buf[6N + r] = rank r's max|Delta|, buf[6N + G + r] = its frame-guard flag     (HIP kernels)
+    all-reduce(SUM) of the one fused buffer of 6N + 2G floats over the G ranks            (RCCL)
     end   : coords = base + S * clamp(Q/|S|^2, 1/G, 1) per node end ; base = coords      (HIP kernel)
 
 The merge is not a plain sum: with the early learning rates every term is a full projection
 (mu = 1), each rank alone already moves a node end all the way, and summing G such deltas
 overshoots G-fold (measured: divergence at G = 2 on DRB1-3123).  The factor f = Q/|S|^2 is 1/G when
 the ranks' deltas agree (-> their mean) and 1 when they are uncorrelated small steps (-> their sum);
-validated by stress at G = 1,2,4,8.  max|Delta| is all-reduced with MAX for the
-reference's stop rule.  The reference has no multi-device path (src/cuda/layout.cu is single-GPU,
+validated by stress at G = 1,2,4,8.  Every rank's max|Delta| (the reference's stop rule) and
+frame-guard flag ride in a slot of their own behind the 6N floats — the other ranks write zero there — so
+the one SUM hands all of them to everybody: ONE collective per exchange, none besides.  The reference has no multi-device path (src/cuda/layout.cu is single-GPU,
 its NCCLCHECK macro is unused), so this exchange is new; SURVEY 8(e).
 """
 import ctypes as C
@@ -53,8 +55,8 @@ class HipEngine:
         self.tiled = bool(self.session.tile_info()["tiled"])
         self.device = torch.device("cuda", torch.cuda.current_device() if params.device < 0 else params.device)
 
-    def new_exchange_buffer(self):
-        return torch.empty(6 * self.n_nodes, dtype=torch.float32, device=self.device)
+    def new_exchange_buffer(self, world=1):
+        return torch.empty(6 * self.n_nodes + 2 * world, dtype=torch.float32, device=self.device)
 
     def iteration(self, eta, cooling, n_terms):
         self.session.iteration(eta, cooling, n_terms)
@@ -65,26 +67,38 @@ class HipEngine:
     def sync(self):
         return self.session.sync()
 
+    def flush(self):
+        self.session.flush()
+
     def warm_per_lane(self):
         return bool(self.session.tile_info()["warm_per_lane"])
 
-    def set_shard(self, rank, world, by_region=False):
-        """True when the engine shards by tile (or by node region) itself (tile kernel): iteration()
-        then takes the full term count of a block; False when the caller must shard the term count
-        (per-lane kernel)."""
-        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), 1 if by_region else 0)
+    def set_shard(self, rank, world, by_region=None):
+        """by_region None: by node region when that leaves a launch a thousand work items per rank, by tile
+        otherwise (pgsgd_session_set_shard).  True when the engine shards by tile or by region itself (tile
+        kernel): iteration() then takes the full term count of a block; False when the caller must shard the
+        term count (per-lane kernel)."""
+        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), -1 if by_region is None else 1 if by_region else 0)
         if rc < 0:
             check(rc, "set_shard")
-        return rc == 1
+        self.shard_mode = {0: "terms", 1: "tiles", 2: "regions"}[rc]
+        return rc > 0
 
     def exchange_mark(self):
         check(lib.pgsgd_session_exchange_mark(self.session._h), "exchange_mark")
 
-    def exchange_begin(self, buf):
-        check(lib.pgsgd_session_exchange_begin(self.session._h, C.c_void_p(buf.data_ptr())), "exchange_begin")
+    def exchange_begin(self, buf, rank=0, world=1):
+        check(lib.pgsgd_session_exchange_begin_stats(self.session._h, C.c_void_p(buf.data_ptr()), int(rank), int(world)), "exchange_begin")
 
     def exchange_end(self, buf, world):
         check(lib.pgsgd_session_exchange_end(self.session._h, C.c_void_p(buf.data_ptr()), int(world)), "exchange_end")
+
+    def reframe(self):
+        self.session.reframe()
+
+    def snapshot(self):
+        """Coordinates as a snapshot between iterations sees them (path_sgd_layout.cpp:379-408)."""
+        return self.session.download(flush=False)
 
     def result(self):
         return self.session.download()
@@ -96,13 +110,19 @@ class HipEngine:
 class DistributedLayout:
     """Drives one engine per rank through the schedule with the exchange between blocks."""
 
-    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None, region_shard=False, tile_shard=True):
+    def __init__(self, params: LayoutParams, engine, group=None, exchanges_per_iteration=None, region_shard=None, tile_shard=True,
+                 snapshot_prefix=None, force_exchange=False):
         self.params = params
         self.engine = engine
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
+        self.backend = dist.get_backend(group) if self.distributed else None
+        # force_exchange: a one-rank process group still runs the exchange (prepare, all-reduce, merge: the identity up to
+        # a quantum) — how the RCCL path is executed on a single-GPU box
+        self.exchanging = self.world > 1 or (bool(force_exchange) and self.distributed)
+        self.snapshot_prefix = snapshot_prefix
         if exchanges_per_iteration is None:
             # measured with G virtual ranks on one MI355X (profiles/r01/virtual_ranks_*.jsonl): the per-lane
             # kernel (small graphs) needs 4 exchanges per iteration to keep G = 1 quality, the tile kernel is
@@ -118,16 +138,16 @@ class DistributedLayout:
         # Every rank applies 1/G of each iteration's terms.  Per-lane kernel: 1/G of the term count, in B
         # slices.  Tile kernel: part b of an iteration runs the tiles with index = b*G + rank (mod B*G), each
         # with its whole share of the iteration's terms, so a visited tile always has a full term loop and
-        # the cost of an iteration grows neither with the number of exchanges nor with G.
-        # region_shard=True instead gives each rank every G-th node region with all its tiles (disjoint
-        # private windows; pays off only when there are >= ~1000 regions per rank and launch, i.e.
-        # N >~ 1e6 * G nodes: fewer leave most of the GPU idle).
+        # the cost of an iteration grows neither with the number of exchanges nor with G; or (region shard)
+        # every G-th node region with all its tiles: the ranks' private windows are then disjoint, which keeps
+        # the one-GPU layout quality, but a launch has only N/2RG work items — chosen by the engine when that
+        # is still a thousand per rank (BASELINE config 5 at G = 8), region_shard=True/False forces it.
         self.engine_sharded = False
-        if self.world > 1:
-            self._buf = engine.new_exchange_buffer()
+        if self.exchanging:
+            self._buf = engine.new_exchange_buffer(self.world)
             engine.exchange_mark()
-            if hasattr(engine, "set_shard") and (region_shard or (tile_shard and getattr(engine, "tiled", False))):
-                self.engine_sharded = bool(engine.set_shard(self.rank, self.world, by_region=bool(region_shard)))
+            if self.world > 1 and hasattr(engine, "set_shard") and (region_shard or (tile_shard and getattr(engine, "tiled", False))):
+                self.engine_sharded = bool(engine.set_shard(self.rank, self.world, by_region=region_shard))
 
     def _iteration_terms(self):
         """Term count this rank passes for one iteration: everything when the engine shards by tile or
@@ -141,10 +161,19 @@ class DistributedLayout:
             return self.params.min_term_updates // self.world
         return shard_terms(self.params.min_term_updates, self.world, self.rank)
 
+    def _exchange(self):
+        """One fused all-reduce; returns (max|Delta| over the ranks, any frame-guard flag) from its tail."""
+        eng, G = self.engine, self.world
+        eng.exchange_begin(self._buf, self.rank, G)
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        eng.exchange_end(self._buf, G)
+        tail = self._buf[-2 * G:].tolist()   # (waits for the stream: the step's one synchronisation)
+        return max(tail[:G]), any(v != 0.0 for v in tail[G:])
+
     def step(self, it):
         """Iteration `it` (0-based) on every rank with its exchanges.  Returns global max|Delta|."""
         eng = self.engine
-        dmax = 0.0
+        dmax, guard = 0.0, False
         # a tiled engine whose initial layout had no global structure runs the per-lane kernel until cooling: that
         # phase takes the per-lane kernel's four exchanges per iteration
         cooling = it >= self.first_cooling
@@ -153,27 +182,32 @@ class DistributedLayout:
             blocks = max(blocks, 4)
         for b in range(blocks):
             eng.iteration_part(self.etas[it], cooling, self._iteration_terms(), b, blocks)
-            if self.world > 1:
-                eng.exchange_begin(self._buf)
-                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
-                eng.exchange_end(self._buf, self.world)
-            dmax = max(dmax, eng.sync())
-        if self.world > 1:
-            # one MAX all-reduce carries max|Delta| and the ranks' frame-guard flags: when any rank saw a coordinate in
-            # the outer quarter of the fixed-point frame, every rank widens its frame before the next iteration
-            status = getattr(getattr(eng, "session", None), "frame_status", None)
-            hit = 1.0 if status is not None and status()[0] else 0.0
-            t = torch.tensor([dmax, hit], dtype=torch.float64, device=self._buf.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            vals = t.tolist()
-            dmax = float(vals[0])
-            if vals[1] > 0 and status is not None:
-                eng.session.reframe()
+            if self.exchanging:
+                d, g = self._exchange()
+                dmax, guard = max(dmax, d), guard or g
+            else:
+                dmax = max(dmax, eng.sync())
+        if self.exchanging:
+            eng.sync()
+            # when any rank saw a coordinate in the outer quarter of the fixed-point frame, every rank widens its
+            # frame before the next iteration (the flags came with the exchange: the same decision everywhere)
+            if guard and hasattr(eng, "reframe"):
+                eng.reframe()
         self.iterations_done = it + 1
         return dmax
 
+    def finish(self):
+        """The far pulls of every rank's last tile launch: delivered, then merged like any other move."""
+        eng = self.engine
+        if hasattr(eng, "flush"):
+            eng.flush()
+            if self.exchanging:
+                self._exchange()
+                eng.sync()
+
     def run(self):
-        """The whole schedule with the reference's stop rules (path_sgd_layout.cpp:139-149)."""
+        """The whole schedule with the reference's stop rules (path_sgd_layout.cpp:139-149) and, on rank 0, its
+        snapshots (:379-408: `prefix + k` after iteration k, k = 1 .. iter_max - 1)."""
         p = self.params
         for it in range(p.iter_max):
             dmax = self.step(it)
@@ -182,4 +216,9 @@ class DistributedLayout:
             if dmax <= p.delta:
                 self.stopped_early = True
                 break
+            if self.snapshot_prefix and self.rank == 0 and hasattr(self.engine, "snapshot"):
+                from .layout import Layout
+                X, Y = self.engine.snapshot()
+                Layout(X, Y).serialize(f"{self.snapshot_prefix}{it + 1}")
+        self.finish()
         return self.iterations_done

@@ -157,23 +157,35 @@ class LayoutSession:
         Yf = np.ascontiguousarray(Y, dtype=np.float32)
         check(lib.pgsgd_session_upload_coords(self._h, Xf.ctypes.data_as(_F32P), Yf.ctypes.data_as(_F32P)), "upload")
 
-    def download(self):
+    def flush(self):
+        """Deliver the far pulls of the last tile launch (pgsgd_session_flush; a no-op for the per-lane kernel)."""
+        check(lib.pgsgd_session_flush(self._h), "flush")
+
+    def download(self, flush=True):
+        """Coordinates as fp32 [2N] X, Y.  flush=False: as a snapshot between iterations sees them, without the far
+        pulls the last tile launch collected (they are delivered right before the next launch)."""
+        if flush:
+            self.flush()
         n = 2 * self.graph.n_nodes
         X = np.zeros(n, dtype=np.float32)
         Y = np.zeros(n, dtype=np.float32)
         check(lib.pgsgd_session_download_coords(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
         return X, Y
 
-    def download_f64(self):
+    def download_f64(self, flush=True):
         """Coordinates in double precision: exactly x_off + q / quanta_per_bp of the fixed-point words."""
+        if flush:
+            self.flush()
         n = 2 * self.graph.n_nodes
         X, Y = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
         f64p = C.POINTER(C.c_double)
         check(lib.pgsgd_session_download_coords_f64(self._h, X.ctypes.data_as(f64p), Y.ctypes.data_as(f64p)), "download_f64")
         return X, Y
 
-    def download_words(self):
+    def download_words(self, flush=True):
         """Raw device coordinate words, uint64 [2N] (see coord_format)."""
+        if flush:
+            self.flush()
         w = np.zeros(2 * self.graph.n_nodes, dtype=np.uint64)
         check(lib.pgsgd_session_download_words(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "download_words")
         return w
@@ -264,6 +276,12 @@ class LayoutSession:
         a, b = C.c_double(), C.c_double()
         check(lib.pgsgd_session_aux_time(self._h, C.byref(a), C.byref(b)), "aux_time")
         return a.value, b.value
+
+    def launch_counts(self):
+        """(kernel launches, memsets + copies) the session's iterations have put on the stream."""
+        k, c = C.c_uint64(), C.c_uint64()
+        check(lib.pgsgd_session_launch_counts(self._h, C.byref(k), C.byref(c)), "launch_counts")
+        return int(k.value), int(c.value)
 
     def outbox_overflow(self):
         """Far updates applied as direct atomics because the message pool share of their bucket was used up."""

@@ -73,6 +73,8 @@ def _load(name):
                                         _U32P, _U32P, _U32P, _U32P, C.c_uint32, C.c_double, C.c_double, C.c_double,
                                         _F32P, _F32P, C.POINTER(C.c_double), _U64P, C.POINTER(C.c_uint64)]
     lib.orc_tile_layout_q32.restype = None
+    lib.orc_tile_layout_q32_ex.argtypes = lib.orc_tile_layout_q32.argtypes + [C.c_uint32, C.c_uint64]
+    lib.orc_tile_layout_q32_ex.restype = None
     lib.orc_layout_streams_q32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double, _F32P, _F32P, _F64P, _U64P]
     lib.orc_layout_streams_f64.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
@@ -202,10 +204,14 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
     return X, Y, d.value, ck
 
 
-def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, quanta_per_bp):
+TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH = 1, 2, 4
+
+
+def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, quanta_per_bp, policy=0, stop_after=0):
     """Sequential mirror of the tile kernel (one workgroup, one lane per tile).  `tiles` / `items` are the dicts of
     LayoutSession.tile_table() / tile_items(); tiles["lanes"] (lanes per tile, default 1 each) selects the term
-    streams.  Returns X, Y (fp32), last delta_max, checksums[4], far terms."""
+    streams.  policy / stop_after: see orc_tile_layout_q32_ex (0, 0 = the product's run).
+    Returns X, Y (fp32), last delta_max, checksums[4], far terms."""
     X = np.ascontiguousarray(X, dtype=np.float32).copy()
     Y = np.ascontiguousarray(Y, dtype=np.float32).copy()
     d, far = C.c_double(), C.c_uint64()
@@ -215,12 +221,12 @@ def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, q
     t0, cum, tn, tp = u64(tiles["t0"]), u64(tiles["cum"]), u32(tiles["n"]), u32(tiles["path"])
     tl = u32(tiles["lanes"]) if "lanes" in tiles else np.ones(len(t0), dtype=np.uint32)
     tb, te, w0, lo = u32(items["tile_begin"]), u32(items["tile_end"]), u32(items["win0"]), u32(items["local"])
-    lib().orc_tile_layout_q32(C.byref(g.view), C.byref(p), seed_base, len(t0), t0.ctypes.data_as(_U64P), cum.ctypes.data_as(_U64P),
+    lib().orc_tile_layout_q32_ex(C.byref(g.view), C.byref(p), seed_base, len(t0), t0.ctypes.data_as(_U64P), cum.ctypes.data_as(_U64P),
                               tn.ctypes.data_as(_U32P), tp.ctypes.data_as(_U32P), tl.ctypes.data_as(_U32P), int(tiles["steps_total"]), len(tb),
                               int(items["n_first"]),
                               tb.ctypes.data_as(_U32P), te.ctypes.data_as(_U32P), w0.ctypes.data_as(_U32P), lo.ctypes.data_as(_U32P),
                               int(region), x_off, y_off, quanta_per_bp, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P),
-                              C.byref(d), ck.ctypes.data_as(_U64P), C.byref(far))
+                              C.byref(d), ck.ctypes.data_as(_U64P), C.byref(far), int(policy), int(stop_after))
     return X, Y, d.value, ck, far.value
 
 

@@ -1163,13 +1163,41 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
     return fabsf(Delta);
 }
 
+/* The launch order of an iteration (pgsgd_session_iteration_part): [deliver the far pulls the launch before collected]
+ * [snapshot, first launch of the iteration only] [launch of the even regions] [deliver] [launch of the odd regions]; what the
+ * last launch collected is delivered before the first launch of the next iteration, or by pgsgd_session_flush when the run ends.
+ * policy (0 = what the product ships; the others are the round-2 order, kept for tools/cpu_transient.py):
+ *   ORC_TILE_DRAIN_AFTER    a launch's far pulls are delivered right after it (an iteration then ends with the arrival of a
+ *                           launch's worth of far pulls instead of with window-local terms)
+ *   ORC_TILE_TWO_SNAPSHOTS  the coordinate snapshot is refreshed before both launches of a warm iteration
+ *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
+ * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
+void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
+                         uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
+                         const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
+                         double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
+                         double* last_delta_max, uint64_t* checksum, uint64_t* far_terms, uint32_t policy, uint64_t stop_after);
+
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
                          const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
                          const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
                          double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
                          double* last_delta_max, uint64_t* checksum, uint64_t* far_terms) {
+    orc_tile_layout_q32_ex(g, p, seed_base, n_tiles, t0, cum, tn, tpath, tlanes, steps_total, n_items, n_first, tile_begin, tile_end, win0, local,
+                           region, x_off, y_off, quanta_per_bp, X, Y, last_delta_max, checksum, far_terms, 0, 0);
+}
+
+void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
+                         uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
+                         const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
+                         double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
+                         double* last_delta_max, uint64_t* checksum, uint64_t* far_terms, uint32_t policy, uint64_t stop_after) {
     (void)n_tiles;
+    const int drain_first = !(policy & ORC_TILE_DRAIN_AFTER), one_snapshot = !(policy & ORC_TILE_TWO_SNAPSHOTS);
+    int pending = 0;   /* a launch's far pulls wait in the outbox */
     if (last_delta_max) *last_delta_max = 0.0;
     const uint64_t n_ends = 2 * g->n_nodes;
     const float scale = (float)quanta_per_bp, inv_scale = (float)(1.0 / quanta_per_bp);
@@ -1211,7 +1239,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
             const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
             if (ib == ie) continue;
             /* snapshot before every launch of a warm iteration, before the first launch of a cooling one */
-            if (!snap_taken || !cooling) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }
+            if (pending) { for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; } pending = 0; }
+            if (!snap_taken || (!cooling && !one_snapshot)) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }
             for (uint64_t it = ib; it < ie; ++it) {
                 const uint64_t wbase = 2 * (uint64_t)win0[it];
                 if (local[it])
@@ -1256,7 +1285,9 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                         if ((qx | qy) == 0) continue;
                         if (!in_b) far_count[colour]++;
                         const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-                        if (in_b) win[eb - wbase] += delta; else outbox[eb] += delta;
+                        if (!in_b && (policy & 0x100u)) continue;                 /* experiment: far terms do nothing */
+                        if (in_b) win[eb - wbase] += delta; else if (!(policy & 0x200u)) outbox[eb] += delta;
+                        if (!in_b && (policy & 0x400u)) continue;                 /* experiment: far terms move only the partner */
                         if (in_a) win[ea - wbase] -= delta; else outbox[ea] -= delta;
                     }
                     free(streams);
@@ -1265,7 +1296,8 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
                     for (uint32_t i = 0; i < win_words; ++i)
                         if (wbase + i < n_ends) W[wbase + i] = win[i];
             }
-            for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
+            if (drain_first) pending = 1;
+            else for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
         }
         for (int colour = 0; colour < 2; ++colour) {
             const double h = (double)far_count[colour] / (double)n_ends;
@@ -1274,7 +1306,10 @@ void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_
         }
         if (last_delta_max) *last_delta_max = dmax;
         if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;
+        if (stop_after && iter + 1 >= stop_after) break;
     }
+    if (pending && !(policy & ORC_TILE_NO_FLUSH))
+        for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
     if (far_terms) *far_terms = far_total;
     if (checksum) {
         checksum[2] = checksum[3] = 0;

@@ -84,12 +84,21 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
  * stochastic rounding of each step with the term's spare random bits; X,Y are quantised on entry and
  * de-quantised on exit exactly as the device's upload/download do.  Bit-exact for n_streams == 1. */
 /* sequential mirror of the tile kernel run by one workgroup with one lane per tile (see the .c file) */
+#define ORC_TILE_DRAIN_AFTER 1u
+#define ORC_TILE_TWO_SNAPSHOTS 2u
+#define ORC_TILE_NO_FLUSH 4u
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
                          const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
                          const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
                          double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
                          double* last_delta_max, uint64_t* checksum, uint64_t* far_terms);
+void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
+                         uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
+                         const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
+                         const uint32_t* tile_end, const uint32_t* win0, const uint32_t* local, uint32_t region,
+                         double x_off, double y_off, double quanta_per_bp, float* X, float* Y,
+                         double* last_delta_max, uint64_t* checksum, uint64_t* far_terms, uint32_t policy, uint64_t stop_after);
 void orc_layout_streams_q32(const orc_graph* g, const orc_params* p, uint64_t seed,
                             uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
                             double x_off, double y_off, double quanta_per_bp, float* X, float* Y, double* last_delta_max,

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the library reads its test and experiment knobs (PGSGD_TILE_*, PGSGD_OUTBOX_*, PGSGD_MULTI_*, PGSGD_FRAME_SPAN) only in a
+# process that sets PGSGD_DEBUG=1 (odgi_amd/csrc/pgsgd_internal.hpp: debug_env); a test that sets none of them runs
+# the product path as a user gets it
+os.environ["PGSGD_DEBUG"] = "1"
 
 
 def pytest_configure(config):

@@ -51,17 +51,19 @@ class OracleEngine:
         return self._dmax
 
     # the exchange of odgi_amd/csrc/pgsgd_kernels.hpp (exchange_prepare/apply kernels), in numpy
-    def new_exchange_buffer(self):
-        return torch.zeros(6 * len(self.coords), dtype=torch.float32)
+    def new_exchange_buffer(self, world=1):
+        return torch.zeros(6 * len(self.coords) + 2 * world, dtype=torch.float32)
 
     def exchange_mark(self):
         self.base = self.coords.clone()
 
-    def exchange_begin(self, buf):
+    def exchange_begin(self, buf, rank=0, world=1):
         n = len(self.coords)
         d = self.coords - self.base
         buf[:4 * n] = d.reshape(-1)
-        buf[4 * n:] = torch.stack([d[:, 0] ** 2 + d[:, 1] ** 2, d[:, 2] ** 2 + d[:, 3] ** 2], dim=1).reshape(-1)
+        buf[4 * n:6 * n] = torch.stack([d[:, 0] ** 2 + d[:, 1] ** 2, d[:, 2] ** 2 + d[:, 3] ** 2], dim=1).reshape(-1)
+        buf[6 * n:] = 0.0                      # the tail: a slot per rank for max|Delta| and one for the frame-guard flag
+        buf[6 * n + rank] = self._dmax
 
     def exchange_end(self, buf, world):
         self.coords.copy_(merge_rule(self.base, buf, world))
@@ -71,7 +73,7 @@ class OracleEngine:
 def merge_rule(base, buf, world):
     n = len(base)
     S = buf[:4 * n].reshape(n, 4)
-    Q = buf[4 * n:].reshape(n, 2)
+    Q = buf[4 * n:6 * n].reshape(n, 2)
     S2 = torch.stack([S[:, 0] ** 2 + S[:, 1] ** 2, S[:, 2] ** 2 + S[:, 3] ** 2], dim=1)
     f = torch.where(S2 > 0, torch.clamp(Q / torch.clamp(S2, min=1e-38), 1.0 / world, 1.0), torch.ones_like(S2))
     return base + S * f.repeat_interleave(2, dim=1)
@@ -130,7 +132,7 @@ def test_two_rank_delta_allreduce_matches_single_process_merge(tmp_path):
     cur = engines[0].coords.clone()
     for it in range(p.iter_max):
         for b in range(4):
-            total = torch.zeros(6 * len(cur))
+            total = torch.zeros(6 * len(cur) + 2)
             for r, e in enumerate(engines):
                 e.coords.copy_(cur)
                 e.base = cur.clone()

@@ -6,11 +6,12 @@ the concurrent run is Hogwild by construction, like the reference — statistica
 stress tolerance stated in each test.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -431,7 +432,7 @@ def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             s.sync()
             if it + 1 in snap_iters:
-                X, Y = s.download_f64()
+                X, Y = s.download_f64(flush=False)   # what a snapshot after this iteration sees (path_sgd_layout.cpp:379-408)
                 assert np.isfinite(X).all() and np.isfinite(Y).all()
                 out.append(orc.path_stress_sampled(og, X, Y, pairs, eval_seed))
         assert s.outbox_overflow() == 0
@@ -802,6 +803,62 @@ def test_cpp_multi_gpu_run_with_two_virtual_devices(oa, graphs, graph_name, monk
     assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1])) + 0.01
 
 
+def test_cpp_multi_gpu_run_writes_snapshots(oa, graphs, tmp_path, monkeypatch):
+    """`odgi layout --gpus 2 -u prefix`: rank 0 writes prefix1 .. prefix(iter_max-1) from the merged coordinates
+    (path_sgd_layout.cpp:379-408), as a one-device run does — tiled graph and per-lane graph."""
+    monkeypatch.setenv("PGSGD_MULTI_HOST_REDUCE", "1")
+    for name, g, kw in (("tiled", oa.Graph.synthetic(100_000, 12, seed=3), dict(min_term_updates=200_000)), ("lanes", graphs("DRB1-3123"), {})):
+        X, Y = oa.initial_layout(g, "d", seed=4)
+        pre = str(tmp_path / f"{name}_")
+        p = _params(oa, g, n_devices=2, iter_max=5, snapshot_prefix=pre, **kw)
+        st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+        assert st["iterations"] == 5
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith(name))
+        assert files == [f"{name}_{k}" for k in (1, 2, 3, 4)], files
+        lay = oa.Layout.load(pre + "4")
+        assert lay.size() == 2 * g.n_nodes and np.isfinite(lay.X).all() and np.isfinite(lay.Y).all()
+        # the last snapshot is one (small-eta) iteration away from the result
+        assert np.abs(lay.X - X).max() < 0.25 * (X.max() - X.min())
+
+
+def test_cpp_multi_gpu_driver_executes_rccl_with_one_rank(oa, graphs, monkeypatch):
+    """The RCCL binding of the C++ multi-GPU driver (dlopen'ed ncclCommInitAll / ncclAllReduce / ncclCommDestroy) run
+    for real on the one GPU of the test box: PGSGD_MULTI_FORCE=1 sends an n_devices = 1 run through the driver — one
+    rank, a one-rank communicator, the same fused all-reduce after every exchange block.  A one-rank exchange is the
+    identity up to a quantum per exchange, so the layout must be as good as the plain run's."""
+    for g, kw in ((oa.Graph.synthetic(100_000, 12, seed=3), dict(min_term_updates=300_000)), (graphs("LPA"), {})):
+        X0, Y0 = oa.initial_layout(g, "d", seed=4)
+        X1, Y1 = X0.copy(), Y0.copy()
+        p = _params(oa, g, **kw)
+        st1 = oa.path_linear_sgd_layout_gpu(g, p, X1, Y1)
+        monkeypatch.setenv("PGSGD_MULTI_FORCE", "1")
+        X2, Y2 = X0.copy(), Y0.copy()
+        st2 = oa.path_linear_sgd_layout_gpu(g, p, X2, Y2)
+        monkeypatch.delenv("PGSGD_MULTI_FORCE")
+        assert st2["iterations"] == st1["iterations"] == p.iter_max and st2["term_updates"] == st1["term_updates"]
+        s1, s2 = oa.path_stress(g, X1, Y1, 500_000, seed=1), oa.path_stress(g, X2, Y2, 500_000, seed=1)
+        print(f"one-rank RCCL run: stress {s2:.4f} vs plain run {s1:.4f}")
+        assert np.isfinite(X2).all() and 0.8 * s1 <= s2 <= 1.25 * s1
+
+
+def test_bench_runs_the_rccl_exchange_under_torchrun_with_one_rank(tmp_path):
+    """bench.py as the driver launches it for N > 1 — torch.distributed.run, backend nccl (= RCCL) — with one rank and
+    --force-exchange: the one-process-per-GPU route's exchange (prepare kernel, RCCL all-reduce of the fused buffer,
+    merge kernel, statistics from the buffer's tail) executed on a single-GPU box."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PGSGD_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29713", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--nodes", "200000",
+           "--paths", "20", "--cpu-seconds", "0", "--force-exchange", "--stress"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["collective_backend"] == "nccl"
+    assert out["value"] > 0 and out["stress_sampled"] < out["stress_initial"]
+
+
 def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
     """`odgi layout -i graph.og` (the reference's primary input form): the reference's own fixture
     test/DRB1-3123_sorted.og through the CLI; the layout of this graph must meet the bar of the one layout
@@ -882,12 +939,19 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         for it in range(p.iter_max):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             dmax_g = s.sync()
+        # two observation points: the coordinates as a snapshot between iterations sees them (the far pulls of the last
+        # launch still wait in the outbox: they are delivered right before the next launch), and after the flush that
+        # ends a run
+        Xs, Ys = s.download(flush=False)
         Xg, Yg = s.download()
         w1 = s.download_words()
         assert s.outbox_overflow() == 0      # every far update went through the outbox, as the mirror assumes
         assert s.frame_status()[1] == 0      # and the fixed-point frame stayed as it was chosen
-    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
+    args = (og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
+    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(*args)
+    Xn, Yn, _, _, _ = orc.tile_layout_q32(*args, policy=orc.TILE_NO_FLUSH)
     assert far > 0 and not np.array_equal(w0, w1)
+    assert np.array_equal(Xs, Xn) and np.array_equal(Ys, Yn) and not (np.array_equal(Xs, Xg) and np.array_equal(Ys, Yg))
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
     assert dmax_g == dmax_o
     sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))

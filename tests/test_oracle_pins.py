@@ -193,10 +193,11 @@ def test_oracle_hogwild_reaches_reference_quality(oa, orc, graphs, ographs):
     assert orc.path_stress_exhaustive(og, Xf, Yf) < 0.0871 * 1.25 and dmax > 0
 
 
-def tile_mirror_case(orc, pyref):
+def tile_mirror_case(orc, pyref, policy=0):
     """The committed tile-mirror case (also called by tests/golden/make_golden.py): DRB1-3123, region 64,
     6 iterations of 2*S terms, deterministic initial layout (X = cumulative bp at node ends, Y = a fixed
-    pattern), frame 16 quanta per bp around it.  Returns the final coordinates and bookkeeping."""
+    pattern), frame 16 quanta per bp around it.  Returns the final coordinates and bookkeeping.
+    policy 0 = the launch order the product ships; TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS = round 2's."""
     from conftest import parse_gfa_py
     d = parse_gfa_py(os.path.join(GOLDEN, "DRB1-3123.gfa"))
     g = orc.Graph(d["node_len"], d["path_first"], d["step_path"], d["step_handle"], d["step_pos"])
@@ -209,7 +210,7 @@ def tile_mirror_case(orc, pyref):
     ends = np.cumsum(np.repeat(d["node_len"].astype(np.float64), 2) * np.tile([0.0, 1.0], g.n_nodes))
     X0 = ends.astype(np.float32)
     Y0 = (((np.arange(2 * g.n_nodes) * 2654435761) % 1000) / 10.0 - 50.0).astype(np.float32)
-    X, Y, dmax, ck, far = orc.tile_layout_q32(g, p, 9399220, tiles, items, 64, X0, Y0, -float(1 << 27), -float(1 << 27), 16.0)
+    X, Y, dmax, ck, far = orc.tile_layout_q32(g, p, 9399220, tiles, items, 64, X0, Y0, -float(1 << 27), -float(1 << 27), 16.0, policy=policy)
     return dict(X=X, Y=Y, dmax=np.array([dmax]), checksum=ck, far=np.array([far], dtype=np.uint64),
                 n_tiles=np.array([len(tiles["t0"])]), n_items=np.array([len(items["local"])]),
                 n_windowless=np.array([int((items["local"] == 0).sum())]))
@@ -224,6 +225,13 @@ def test_tile_mirror_golden_regression(orc):
         assert np.array_equal(v, gv[f"tile_mirror/{k}"]), k
     ck = got["checksum"]
     assert (ck[0], ck[1]) == (ck[2], ck[3]) and got["far"][0] > 0 and got["n_windowless"][0] > 0
+    # round 2's launch order (far pulls delivered right after their launch, two snapshots per warm iteration) is still
+    # in the mirror as a policy, and still gives the vectors committed in round 2: the terms and their arithmetic did
+    # not change with the order of the launches
+    old = tile_mirror_case(orc, pyref, policy=orc.TILE_DRAIN_AFTER | orc.TILE_TWO_SNAPSHOTS)
+    for k, v in old.items():
+        assert np.array_equal(v, gv[f"tile_mirror_r2/{k}"]), k
+    assert not np.array_equal(old["X"], got["X"])
 
 
 def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
