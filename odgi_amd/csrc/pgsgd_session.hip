@@ -93,8 +93,9 @@ struct pgsgd_session {
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
+    uint32_t item_chunk[2][pgsgd::kItemQueues + 1] = {};  // per colour: runs of the windowed items, one per XCD
     uint32_t n_windowless = 0;            // the last n_windowless items of colour 0 have no window (their own launch)
-    uint32_t* d_queue = nullptr;          // [3] work-item counters: colour 0, colour 1, colour 0's window-less items
+    uint32_t* d_queue = nullptr;          // [3][kItemQueues] work-item counters: colour 0, colour 1, colour 0's window-less items
     uint64_t tile_steps_total = 0;
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
     size_t tile_lds = 0;
@@ -230,6 +231,7 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
 struct HostTiles {
     std::vector<pgsgd::Tile> tiles;
     std::vector<pgsgd::WorkItem> items[2];
+    uint32_t chunk[2][pgsgd::kItemQueues + 1] = {};  // per colour: the windowed items' runs, one per XCD (TileArgs::chunk)
     uint64_t steps_total = 0, n_nonlocal = 0;
 };
 
@@ -296,7 +298,7 @@ static int device_tile_stats(hipStream_t stream, const uint32_t* d_handle, uint3
 }
 
 // bind tiles to region windows and order the work (host: linear in the number of tiles)
-static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, uint32_t R) {
+static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, uint32_t R, bool by_size) {
     // local tiles grouped by (colour, region of rmin); a tile that does not fit two regions is its own global item
     struct Group { uint32_t r0 = 0; uint64_t steps = 0; std::vector<uint32_t> members; };
     std::vector<Group> groups[2];
@@ -334,9 +336,27 @@ static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, 
         ht.tiles.push_back(t);
     };
     for (int colour = 0; colour < 2; ++colour) {
-        // big work items first: the persistent workgroups pull from a queue
-        std::sort(groups[colour].begin(), groups[colour].end(),
-                  [](const Group& a, const Group& b) { return a.steps != b.steps ? a.steps > b.steps : a.r0 < b.r0; });  // a total order
+        // Items in node order (as the regions were visited above), cut into one run per XCD of about equal step count:
+        // the workgroups of an XCD then work on neighbouring windows at the same time and share the partner records just
+        // outside their tiles in their L2 (TileArgs::chunk).  (Round 2 sorted by size, big items first, one queue; the
+        // items of a linearised pangenome are all alike, and the runs are balanced by stealing.)  by_size: the round-2
+        // order, one run (experiment knob PGSGD_TILE_ORDER=size).
+        if (by_size)
+            std::sort(groups[colour].begin(), groups[colour].end(),
+                      [](const Group& a, const Group& b) { return a.steps != b.steps ? a.steps > b.steps : a.r0 < b.r0; });  // a total order
+        {
+            uint64_t total = 0, acc = 0;
+            for (const Group& gr : groups[colour]) total += gr.steps;
+            uint32_t q = 0, i = 0;
+            ht.chunk[colour][0] = 0;
+            for (const Group& gr : groups[colour]) {
+                // item i starts run q + 1 when the runs before it hold their share of the steps
+                while (!by_size && q + 1 < pgsgd::kItemQueues && acc * pgsgd::kItemQueues >= (uint64_t)(q + 1) * total) ht.chunk[colour][++q] = i;
+                acc += gr.steps;
+                ++i;
+            }
+            while (q < pgsgd::kItemQueues) ht.chunk[colour][++q] = i;
+        }
         for (const Group& gr : groups[colour]) {
             pgsgd::WorkItem wi;
             wi.tile_begin = (uint32_t)ht.tiles.size();
@@ -486,14 +506,14 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         (void)hipFree(d_counts);
         (void)hipFree(d_bad);
         if (h_bad) { set_error("a step names a node rank outside the graph"); return fail(PGSGD_E_INVALID); }
-        // Outbox buckets: power-of-two ranges of node ends.  A tile workgroup stages a 64-byte line per bucket in LDS (and
-        // a few words of bookkeeping: 84 bytes a bucket), and LDS is what bounds the workgroups per CU once the kernel's
-        // registers allow five or six: at most 128 buckets while one drain workgroup can still accumulate a whole bucket
-        // (2^14 ends, 128 KiB of LDS: graphs up to 2^20 nodes), at most 256 beyond, where a bucket is read by
-        // 2^(shift - 14) drain workgroups (a second bucketing pass is the fix for very large graphs).
+        // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
+        // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
+        // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (a second bucketing pass is the fix).
+        // (Round 3 measured coarser buckets at config 4 — 123 or 62 instead of 245, 26 / 21 KB of LDS per tile workgroup
+        // instead of 36, five workgroups per CU instead of four: the warm iterations get 9 % SLOWER with the fifth
+        // workgroup, the cooling ones 3 % faster, the drain 30-100 % slower; profiles/r03/bench_variants_call1.txt.)
         uint32_t ob_shift = 13;
         if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
-        else if (((2 * g->n_nodes - 1) >> 14) + 1 <= 128) ob_shift = 14;
         while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
         s->ob.shift = ob_shift;
         s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
@@ -578,7 +598,9 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
             if (rc) return fail(rc);
-            HostTiles ht = group_tiles(raw, g->n_nodes, s->region);
+            const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");  // experiment knob: "size" = round 2's order and single queue
+            HostTiles ht = group_tiles(raw, g->n_nodes, s->region, order && !strcmp(order, "size"));
+            memcpy(s->item_chunk, ht.chunk, sizeof s->item_chunk);
             if (const char* e = pgsgd::debug_env("PGSGD_TILE_LANES")) {
                 const long l = atol(e);
                 if (l >= 1)
@@ -625,8 +647,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 s->h_items = all;
                 S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
                 S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
-                S_TRY(hipMalloc(&s->d_queue, 3 * sizeof(uint32_t)));
-                S_TRY(hipMemset(s->d_queue, 0, 3 * sizeof(uint32_t)));
+                S_TRY(hipMalloc(&s->d_queue, 3 * pgsgd::kItemQueues * sizeof(uint32_t)));
+                S_TRY(hipMemset(s->d_queue, 0, 3 * pgsgd::kItemQueues * sizeof(uint32_t)));
                 if ((sizeof(uint64_t) << s->ob_part_shift) > 48 * 1024)
                     S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)(sizeof(uint64_t) << s->ob_part_shift)));
@@ -1195,7 +1217,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             pgsgd::TileArgs ta;
             ta.tiles = s->d_tiles;
             ta.items = s->d_items + (colour ? s->n_items[0] : 0);
-            ta.queue = s->d_queue + colour;
+            ta.queue = s->d_queue + colour * pgsgd::kItemQueues;
+            memcpy(ta.chunk, s->item_chunk[colour], sizeof ta.chunk);
             ta.region = s->region;
             ta.tile_steps = s->tile_steps;
             ta.term0 = s->d_term0;
@@ -1250,7 +1273,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
                 pgsgd::TileArgs tw = ta;
                 tw.items = ta.items + ta.n_items;
                 tw.n_items = windowless;
-                tw.queue = s->d_queue + 2;
+                tw.queue = s->d_queue + 2 * pgsgd::kItemQueues;
+                tw.chunk[0] = 0;
+                for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) tw.chunk[q] = windowless;  // one run: every workgroup ends up pulling from it
                 hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, tw, ts, a);
                 s->n_kernels++;

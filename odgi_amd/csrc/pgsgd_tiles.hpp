@@ -109,6 +109,8 @@ __device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg
     return (uint64_t)qx + ((uint64_t)qy << 32);
 }
 
+constexpr uint32_t kItemQueues = 8;
+constexpr uint32_t kNoItem = 0xffffffffu;
 constexpr int kTileBlock = 256;
 constexpr int kTileWaves = kTileBlock / 64;
 
@@ -116,7 +118,14 @@ struct TileArgs {
     const Tile* tiles;
     const WorkItem* items;
     const uint64_t* term0;  // [n_tiles + 1] first term of every tile for this call's term count (tile_terms_kernel)
-    uint32_t* queue;      // work-item counter of this launch
+    // Work items of a launch are pulled from kItemQueues queues, one per XCD: the windowed items of a colour are in
+    // node order and cut into kItemQueues runs of equal step count; a workgroup pulls from the run of the XCD it runs on
+    // (HW_REG_XCC_ID; observed: block b -> XCD b % 8) and, when that is used up, from the following ones.  Workgroups
+    // of one XCD then work on neighbouring windows at the same time, and the partner records just outside a tile —
+    // a quarter of all gathers — are lines their common L2 already holds, instead of lines up to eight L2s fetch
+    // separately.  A pure speed choice: which workgroup runs an item changes nothing about its terms.
+    uint32_t* queue;      // [kItemQueues] work-item counters of this launch
+    uint32_t chunk[9];    // queue q serves items [chunk[q], chunk[q + 1]) (relative to `items`)
     uint32_t n_items;
     uint32_t region;      // R
     uint32_t tile_steps;  // T
@@ -491,11 +500,28 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         far_mu_cap = h > 1.0 ? (float)(1.0 / h) : 1.0f;
     }
     far_mu_cap *= kFarRelax;
+    uint32_t my_queue = 0, queues_done = 0;  // (lane 0's copies are the ones used)
+    if (gridDim.x >= kItemQueues) {          // a launch of fewer workgroups (parity tests: one) takes the runs in order
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        my_queue = xcc & (kItemQueues - 1u);
+    }
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ta.queue, 1u);
+        if (threadIdx.x == 0) {
+            uint32_t it = kNoItem;
+            for (; queues_done < kItemQueues; ++queues_done) {  // a run that is used up stays used up: never asked again
+                const uint32_t q = (my_queue + queues_done) & (kItemQueues - 1u);
+                const uint32_t cand = ta.chunk[q] + atomicAdd(ta.queue + q, 1u) * ta.shard_world + ta.shard_rank;
+                if (cand < ta.chunk[q + 1]) {
+                    it = cand;
+                    break;
+                }
+            }
+            s_item = it;
+        }
         __syncthreads();
-        const uint32_t item = s_item * ta.shard_world + ta.shard_rank;
-        if (item >= ta.n_items) break;
+        const uint32_t item = s_item;
+        if (item == kNoItem) break;
         const WorkItem wi = ta.items[item];
         const uint32_t wbase = 2 * wi.win0;  // first coordinate word of the window
         if (LOCAL) {
@@ -797,7 +823,7 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
 __global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets, uint32_t* queues, unsigned long long* far_next) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_buckets) next[b] = 0;
-    if (b < 3) queues[b] = 0;
+    if (b < 3 * kItemQueues) queues[b] = 0;
     if (b == 0) *far_next = 0;
 }
 

@@ -150,12 +150,12 @@ def decode_og(path):
     return dict(header=header, node_len=[len(n[1]) for n in nodes], node_seq=[n[1] for n in nodes], edges=edges, paths=paths)
 
 
-def build_tiles_py(path_first, step_handle, R, T):
+def build_tiles_py(path_first, step_handle, R, T, order="region"):
     """Independent restatement of the tile table of the region-exclusive tile kernel: paths cut
     into tiles of T steps (single-step paths have none); a tile whose node ranks fit the window
-    [r0*R, (r0+2)*R), r0 = rmin // R, joins work item r0; the launch of the even regions takes its items by
-    decreasing step count (ties: smaller region first), then every window-less tile as an item of its own;
-    the launch of the odd regions follows.  Returns (tiles dict, items dict) shaped like
+    [r0*R, (r0+2)*R), r0 = rmin // R, joins work item r0; the launch of the even regions takes its items in
+    node order (order="size": round 2's order, by decreasing step count, ties: smaller region first), then every
+    window-less tile as an item of its own; the launch of the odd regions follows.  Returns (tiles dict, items dict) shaped like
     LayoutSession.tile_table() / tile_items()."""
     import numpy as np
     pf = np.asarray(path_first, dtype=np.int64)
@@ -188,8 +188,8 @@ def build_tiles_py(path_first, step_handle, R, T):
 
     n_first = 0
     for colour in (0, 1):
-        order = sorted(groups[colour].items(), key=lambda kv: (-sum(raw[i][1] for i in kv[1]), kv[0]))
-        for r0, members in order:
+        ordered = sorted(groups[colour].items(), key=(lambda kv: (-sum(raw[i][1] for i in kv[1]), kv[0])) if order == "size" else (lambda kv: kv[0]))
+        for r0, members in ordered:
             items["tile_begin"].append(len(tiles["t0"]))
             for i in members:
                 emit(i)

@@ -508,14 +508,25 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
             assert tile[k] <= 150.0 * cpu_mean[k], msg                   # the first iteration's excursion (see above)
 
 
+_CONFIG5 = {}
+
+
+def _config5_graph(oa):
+    if "g" not in _CONFIG5:
+        _CONFIG5["g"] = oa.Graph.synthetic(10_000_000, 50, seed=42)
+        _CONFIG5["init"] = oa.initial_layout(_CONFIG5["g"], "d", seed=42)
+    return _CONFIG5["g"], _CONFIG5["init"]
+
+
 def test_config5_size_properties(oa, tmp_path):
     """BASELINE config 5 size (1e7 nodes, ~4.7e8 path steps), three iterations with a snapshot each: exact term
-    accounting, coordinate checksums conserved over 1.4e10 concurrent updates, finite coordinates, snapshots readable.
-    (The oracle cannot run at this size in a test; its parity is pinned at config 4.  Three iterations end inside the
-    first-iterations excursion described there, so the stress is printed, not asserted.)"""
-    g = oa.Graph.synthetic(10_000_000, 50, seed=42)
+    accounting, coordinate checksums conserved over 1.4e10 concurrent updates, finite coordinates, snapshots readable,
+    and the layout after these three iterations against the per-lane kernel's (the reference's rule term by term) after
+    the same three: the reference itself makes the `-N d` layout worse in its first iterations (full projections of
+    every sampled pair, section 4a of DESIGN.md); the tile kernel's excursion must stay within 30x of it."""
+    from odgi_amd import _lib
+    g, (X0, Y0) = _config5_graph(oa)
     assert g.n_nodes == 10_000_000 and 4.4e8 < g.n_steps < 5.2e8
-    X0, Y0 = oa.initial_layout(g, "d", seed=42)
     p = _params(oa, g, iter_max=3)
     etas = oa.path_linear_sgd_layout_schedule(p)
     with oa.LayoutSession(g, p) as s:
@@ -525,16 +536,25 @@ def test_config5_size_properties(oa, tmp_path):
         for it in range(p.iter_max):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             assert s.sync() > 0
-        w1 = s.download_words()
+        Xs, Ys = s.download_f64(flush=False)     # what a snapshot after iteration 3 sees
+        w1 = s.download_words()                  # (flushed: every term's two sides applied)
         X, Y = s.download_f64()
         ms, launches = s.kernel_time()
         _FRAME_DOUBLINGS[0] = s.frame_status()[1]
         assert s.outbox_overflow() == 0
     assert _words_conserved(w0, w1) and np.count_nonzero(w0 != w1) > 19_000_000
     assert np.isfinite(X).all() and np.isfinite(Y).all()
-    s0, s1 = oa.path_stress(g, X0, Y0, 500_000), oa.path_stress(g, X, Y, 500_000)
-    print(f"config 5 size: {3 * p.min_term_updates} terms in {ms:.0f} ms of update kernels ({launches} launches); stress {s0:.0f} -> {s1:.1f}")
-    assert np.isfinite(s1)
+    pl = _params(oa, g, iter_max=3, flags=_lib.FLAG_NO_TILES)
+    with oa.LayoutSession(g, pl) as s:
+        s.upload(X0, Y0)
+        for it in range(pl.iter_max):
+            s.iteration(etas[it], False, pl.min_term_updates)
+            s.sync()
+        Xl, Yl = s.download_f64()
+    s0, s1, s1f, sl = (oa.path_stress(g, a, b, 500_000) for a, b in ((X0, Y0), (Xs, Ys), (X, Y), (Xl, Yl)))
+    print(f"config 5 size: {3 * p.min_term_updates} terms in {ms:.0f} ms of update kernels ({launches} launches); stress {s0:.0f} -> "
+          f"{s1:.1f} as a snapshot sees it ({s1f:.1f} flushed); per-lane kernel (reference rule) {sl:.1f}")
+    assert np.isfinite(s1) and s1 <= 30.0 * sl
     # one-call form with snapshots: <prefix>1, <prefix>2 readable and of full size (path_sgd_layout.cpp:379-408)
     import dataclasses
     X, Y = X0.copy(), Y0.copy()
@@ -545,12 +565,35 @@ def test_config5_size_properties(oa, tmp_path):
     assert lay.size() == 2 * g.n_nodes and np.isfinite(lay.X).all() and np.isfinite(lay.Y).all()
 
 
-def test_reference_signature_shim_runs_on_gpu(tmp_path):
-    """The C++ shim with the reference's path_linear_sgd_layout_gpu signature, end to end."""
-    import subprocess
-    from test_host_logic import _build_shim_mock
-    r = subprocess.run([str(_build_shim_mock(tmp_path))], capture_output=True, text=True)
-    assert r.returncode == 0 and "stress" in r.stdout, r.stdout + r.stderr
+def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
+    """BASELINE config 5 size, the WHOLE 30-iteration schedule (1.4e11 terms): the tile kernel against the per-lane kernel
+    — the reference's rule term by term, within 4 % of the CPU restatement at config 4 — from the same initial layout,
+    one evaluator.  Sampled stress after iterations 20 and 30 two-sided within 10 %."""
+    from odgi_amd import _lib
+    g, (X0, Y0) = _config5_graph(oa)
+    curves, ms = {}, {}
+    for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES)):
+        p = _params(oa, g, flags=flags)
+        etas = oa.path_linear_sgd_layout_schedule(p)
+        out = []
+        with oa.LayoutSession(g, p) as s:
+            s.upload(X0, Y0)
+            assert s.tile_info()["tiled"] == (name == "tile")
+            for it in range(p.iter_max):
+                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+                s.sync()
+                if it + 1 in (10, 20, 30):
+                    X, Y = s.download_f64(flush=it + 1 == 30)
+                    assert np.isfinite(X).all() and np.isfinite(Y).all()
+                    out.append(oa.path_stress(g, X, Y, 2_000_000, seed=1))
+            ms[name] = s.kernel_time()[0] + sum(s.aux_time())
+            assert s.outbox_overflow() == 0
+        curves[name] = out
+    print(f"config 5 size, whole schedule: stress after iterations 10/20/30 tile {curves['tile']} ({ms['tile']:.0f} ms of kernels), "
+          f"per-lane {curves['per_lane']} ({ms['per_lane']:.0f} ms)")
+    for k in (1, 2):
+        assert 0.9 * curves["per_lane"][k] <= curves["tile"][k] <= 1.1 * curves["per_lane"][k], (k, curves)
+    assert curves["tile"][0] <= 1.1 * curves["per_lane"][0]   # before cooling the tile kernel is ahead (DESIGN 4a)
 
 
 def _words_conserved(w0, w1):
@@ -765,6 +808,16 @@ def test_tile_sharded_virtual_ranks(oa, init):
                     e.exchange_end(total, G)
             for e in engines:
                 e.sync()
+        # the far pulls of every rank's last launch: delivered, then merged like any other move (DistributedLayout.finish)
+        for e in engines:
+            e.flush()
+        if G > 1:
+            for e, b in zip(engines, bufs):
+                e.exchange_begin(b)
+            torch.cuda.synchronize()
+            total = torch.stack(bufs).sum(0)
+            for e in engines:
+                e.exchange_end(total, G)
         out = [e.result() for e in engines]
         for e in engines:
             e.close()
@@ -775,6 +828,60 @@ def test_tile_sharded_virtual_ranks(oa, init):
     print(f"tile-sharded virtual ranks, init {init}: stress G=1 {res[1]} G=2 {res[2]}")
     # measured (profiles/r01/virtual_ranks_tiled_tile_shard.jsonl): G = 2 costs +5..11 % at this size
     assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))
+
+
+@pytest.mark.parametrize("mode", ["tiles", "regions"])
+def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
+    """The multi-GPU split at G = 1, 2, 4, 8 with G sessions on the one GPU of the test box (the exchange kernels as in
+    production, the all-reduce replaced by a sum on the device), three seeds each, both ways of sharding the tile
+    kernel's work: by tile (every G-th tile of every window) and by node region (every G-th window, the ranks' private
+    windows disjoint).  Mean sampled stress of the merged layout against the one-rank runs'.  Measured in round 2 at
+    config 4: by tile +11 / +26 / +23 % at G = 2 / 4 / 8, by region +1 / +6 / +6 %."""
+    import torch
+    from odgi_amd.distributed import HipEngine
+    g = oa.Graph.synthetic(600_000, 24, seed=7)
+    kw = dict(min_term_updates=3 * g.n_steps)
+    p = _params(oa, g, **kw)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    res = {}
+    for G in (1, 2, 4, 8):
+        for rep in range(3):
+            X0, Y0 = oa.initial_layout(g, "d", seed=7 + rep)
+            engines = [HipEngine(g, _params(oa, g, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep, **kw), X0, Y0) for r in range(G)]
+            for r, e in enumerate(engines):
+                e.exchange_mark()
+                assert e.tiled and e.set_shard(r, G, by_region=(mode == "regions")) and not e.warm_per_lane()
+            bufs = [e.new_exchange_buffer() for e in engines]
+
+            def exchange():
+                for e, b in zip(engines, bufs):
+                    e.exchange_begin(b)
+                torch.cuda.synchronize()
+                total = torch.stack(bufs).sum(0)
+                for e in engines:
+                    e.exchange_end(total, G)
+
+            for it in range(p.iter_max):
+                for e in engines:
+                    e.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, 0, 1)
+                if G > 1:
+                    exchange()
+                for e in engines:
+                    e.sync()
+            for e in engines:
+                e.flush()
+            if G > 1:
+                exchange()
+            X, Y = engines[0].result()
+            for e in engines:
+                e.close()
+            assert np.isfinite(X).all() and np.isfinite(Y).all()
+            res.setdefault(G, []).append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
+    means = {G: float(np.mean(v)) for G, v in res.items()}
+    print(f"virtual ranks sharded by {mode}: mean stress {means}, runs {res}")
+    band = {"tiles": {2: 1.20, 4: 1.35, 8: 1.35}, "regions": {2: 1.10, 4: 1.15, 8: 1.15}}[mode]
+    for G in (2, 4, 8):
+        assert means[G] <= band[G] * means[1], (mode, G, means)
 
 
 @pytest.mark.parametrize("graph_name", ["synthetic-300k", "LPA"])
@@ -988,7 +1095,7 @@ def test_exchange_kernels_match_the_merge_rule_word_for_word(oa, graphs):
         dy = ((moved[r] >> np.uint64(32)).astype(np.int64) - (base >> np.uint64(32)).astype(np.int64)).astype(np.float32) * inv
         b = bufs[r].cpu().numpy()
         assert np.array_equal(b[:2 * n_ends].reshape(-1, 2), np.stack([dx, dy], axis=1))
-        assert np.array_equal(b[2 * n_ends:], dx * dx + dy * dy)
+        assert np.array_equal(b[2 * n_ends:3 * n_ends], dx * dx + dy * dy)
     total = torch.stack(bufs).sum(0)
     t = total.cpu().numpy()
     S, Q = t[:2 * n_ends].reshape(-1, 2), t[2 * n_ends:]

@@ -206,7 +206,8 @@ def tile_mirror_case(orc, pyref, policy=0):
     p = orc.params(iter_max=6, iter_with_max_learning_rate=0, min_term_updates=2 * g.n_steps, delta=0.0, eps=0.01,
                    eta_max=float(max_steps) ** 2, theta=0.99, space=max_steps, space_max=1000, space_quantization_step=100,
                    cooling_start=0.5)
-    tiles, items = pyref.build_tiles_py(d["path_first"], d["step_handle"], 64, 56)
+    # (round 2 ordered the work items by size; its vectors are pinned with its order)
+    tiles, items = pyref.build_tiles_py(d["path_first"], d["step_handle"], 64, 56, order="size" if policy else "region")
     ends = np.cumsum(np.repeat(d["node_len"].astype(np.float64), 2) * np.tile([0.0, 1.0], g.n_nodes))
     X0 = ends.astype(np.float32)
     Y0 = (((np.arange(2 * g.n_nodes) * 2654435761) % 1000) / 10.0 - 50.0).astype(np.float32)
