@@ -66,7 +66,7 @@ struct pgsgd_session {
     uint32_t region = 256, tile_steps = 224, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
-    uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
+    uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed, index of the far-pull relaxation)
     uint64_t tile_seed_base = 0;          // seed + stream_offset; a sharded session: seed alone (pgsgd_session_set_shard)
     unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
@@ -83,6 +83,7 @@ struct pgsgd_session {
     uint64_t ob_total_chunks = 0;
     double aux_ms[2] = {0, 0};            // snapshot_kernel, far_drain_kernel (HIP events)
     bool ob_pending = false;              // the last tile launch's far pulls wait in the outbox (drained before the next launch)
+    bool snap_stale = true;               // the snapshot halves of the step records do not follow from the tile kernel's own writes
     bool tile_forced = false;             // PGSGD_TILE_FORCE (parity knob) was set when the session was created
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
     uint64_t term0_terms = 0;
@@ -336,11 +337,13 @@ static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, 
         ht.tiles.push_back(t);
     };
     for (int colour = 0; colour < 2; ++colour) {
-        // Items in node order (as the regions were visited above), cut into one run per XCD of about equal step count:
-        // the workgroups of an XCD then work on neighbouring windows at the same time and share the partner records just
-        // outside their tiles in their L2 (TileArgs::chunk).  (Round 2 sorted by size, big items first, one queue; the
-        // items of a linearised pangenome are all alike, and the runs are balanced by stealing.)  by_size: the round-2
-        // order, one run (experiment knob PGSGD_TILE_ORDER=size).
+        // by_size (the default): big work items first, one run that every workgroup pulls from.
+        // !by_size (experiment, PGSGD_TILE_ORDER=region): items in node order (as the regions were visited above), cut
+        // into one run per XCD of about equal step count, so that the workgroups of an XCD work on neighbouring windows at
+        // the same time and share the partner records just outside their tiles in their L2 (TileArgs::chunk).  Measured
+        // at config 4 (profiles/r03/bench_variants_call2.txt, sq_tcc_xcd_vs_size.json): L2 misses of the tile kernel fall
+        // 8 % (1.51e8 -> 1.39e8 per launch) and the kernel gets SLOWER, 9.09 / 7.48 ms against 8.75 / 7.37 per warm /
+        // cooling iteration — neighbours in lock step also fill the same outbox buckets at the same time.
         if (by_size)
             std::sort(groups[colour].begin(), groups[colour].end(),
                       [](const Group& a, const Group& b) { return a.steps != b.steps ? a.steps > b.steps : a.r0 < b.r0; });  // a total order
@@ -598,8 +601,9 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
             if (rc) return fail(rc);
-            const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");  // experiment knob: "size" = round 2's order and single queue
-            HostTiles ht = group_tiles(raw, g->n_nodes, s->region, order && !strcmp(order, "size"));
+            // experiment knob: "region" = work items in node order, one run per XCD (TileArgs::chunk); measured slower, see group_tiles
+            const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");
+            HostTiles ht = group_tiles(raw, g->n_nodes, s->region, !(order && !strcmp(order, "region")));
             memcpy(s->item_chunk, ht.chunk, sizeof s->item_chunk);
             if (const char* e = pgsgd::debug_env("PGSGD_TILE_LANES")) {
                 const long l = atol(e);
@@ -865,6 +869,7 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(dX);
     (void)hipFree(dY);
+    s->snap_stale = true;
     return PGSGD_OK;
 }
 
@@ -1174,6 +1179,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         }
     }
     HIP_TRY(hipSetDevice(s->device));
+    if (part == 0) s->tile_epoch++;  // iterations started, whichever kernel runs them (tile seeds, far-pull relaxation)
     if (s->pending_events.size() >= 64) {  // bound the event pool
         HIP_TRY(hipStreamSynchronize(s->stream));
         int rc = collect_events(s);
@@ -1184,7 +1190,6 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         a.n_terms = n_terms;
         a.eta = (float)eta;
         a.cooling = cooling ? 1u : 0u;
-        if (part == 0) s->tile_epoch++;
         a.epoch = s->tile_epoch;
         int rc = ensure_outbox(s, n_terms, n_parts);
         if (rc) return rc;
@@ -1230,6 +1235,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
+            ta.far_relax = pgsgd::tile_far_relax(s->tile_epoch - 1);
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
@@ -1252,11 +1258,17 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             rc = drain_outbox(s, s->d_far + 2 * colour + (launches & 1u));
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.e[3], s->stream));
-            // Partners outside a window are read from a snapshot of the coordinates, taken once per call, after the drain.
-            // (Round 2 refreshed it before every launch of a warm iteration to tame the far pulls delivered at the END of
-            // an iteration; delivered at the start of the next launch they need no second refresh: the mirror's curves
-            // with one and with two refreshes are the same, tools/cpu_transient.py.)
-            if (!snapshot_taken) {
+            // Partners outside a window are read from the snapshot halves of the step records.  A tile rewrites the records
+            // of its own steps when its terms are done (sgd_tile_kernel), so a session that runs every tile itself needs
+            // the pass over all records only when the coordinates changed behind the tile kernel's back (snap_stale:
+            // upload, per-lane iterations, a widened frame, a merge with other devices); a sharded session runs a share
+            // of the tiles and takes the pass once per call, after the drain.  (Round 2 took it before every launch of a
+            // warm iteration to tame the far pulls delivered at the END of an iteration; delivered at the start of the
+            // next launch they need no second refresh, and the tiles' own writes give the same curves as a pass per
+            // iteration: tools/cpu_transient.py.)
+            const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || n_parts > 1 || s->tile_substeps > 1;  // this launch runs a share of the tiles
+            ta.recs2_out = sharded ? nullptr : s->d_recs2;
+            if (!snapshot_taken && (sharded || s->snap_stale)) {
                 hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());
@@ -1283,6 +1295,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             HIP_TRY(hipEventRecord(ev.e[1], s->stream));
             s->ob_pending = true;
+            s->snap_stale = sharded;
             s->pending_events.push_back(ev);
         }
         HIP_TRY(hipMemcpyAsync(s->h_delta_max, s->d_delta_max, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
@@ -1311,6 +1324,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     HIP_TRY(hipEventRecord(ev.e[0], s->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
     s->n_kernels++;
+    s->snap_stale = true;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.e[1], s->stream));
     s->pending_events.push_back(ev);
@@ -1345,6 +1359,7 @@ extern "C" int pgsgd_session_reframe(pgsgd_session* s) {
     xf.inv_scale *= 2.0f;
     s->h_delta_max[1] = 0;
     s->frame_doublings++;
+    s->snap_stale = true;
     if (s->params.progress)
         fprintf(stderr, "\n[odgi::path_linear_sgd_layout] a node end reached the outer quarter of the fixed-point frame: frame doubled (now %g quanta per bp)\n",
                 (double)xf.scale);
@@ -1465,6 +1480,7 @@ extern "C" int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_b
     else
         hipLaunchKernelGGL(pgsgd::exchange_apply_kernel<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (const float*)device_buf_6N_floats, inv_world);
     HIP_TRY(hipGetLastError());
+    s->snap_stale = true;
     return PGSGD_OK;
 }
 

@@ -118,12 +118,12 @@ struct TileArgs {
     const Tile* tiles;
     const WorkItem* items;
     const uint64_t* term0;  // [n_tiles + 1] first term of every tile for this call's term count (tile_terms_kernel)
-    // Work items of a launch are pulled from kItemQueues queues, one per XCD: the windowed items of a colour are in
-    // node order and cut into kItemQueues runs of equal step count; a workgroup pulls from the run of the XCD it runs on
-    // (HW_REG_XCC_ID; observed: block b -> XCD b % 8) and, when that is used up, from the following ones.  Workgroups
-    // of one XCD then work on neighbouring windows at the same time, and the partner records just outside a tile —
-    // a quarter of all gathers — are lines their common L2 already holds, instead of lines up to eight L2s fetch
-    // separately.  A pure speed choice: which workgroup runs an item changes nothing about its terms.
+    // Work items of a launch are pulled from up to kItemQueues runs.  By default there is one run (items by decreasing
+    // size); the experiment PGSGD_TILE_ORDER=region keeps the items in node order and cuts them into one run per XCD: a
+    // workgroup pulls from the run of the XCD it runs on (HW_REG_XCC_ID; observed: block b -> XCD b % 8) and, when that
+    // is used up, from the following ones, so that the workgroups of one XCD work on neighbouring windows at the same
+    // time and find the partner records just outside a tile in their common L2 (measured: 8 % fewer L2 misses, and a
+    // slower kernel — pgsgd_session.hip: group_tiles).  Which workgroup runs an item changes nothing about its terms.
     uint32_t* queue;      // [kItemQueues] work-item counters of this launch
     uint32_t chunk[9];    // queue q serves items [chunk[q], chunk[q + 1]) (relative to `items`)
     uint32_t n_items;
@@ -134,10 +134,13 @@ struct TileArgs {
     // learning-rate cap of terms whose partner is outside the window: 1/h, h = far pulls per node end in the previous
     // launch of this colour (read on the device: no host round trip), or far_mu_cap_first in the first iteration
     float far_mu_cap_first;
+    float far_relax;      // tile_far_relax(iteration)
     uint32_t far_from_prev;
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
     const uint4* recs2;                // [2S] step records with the coordinate snapshot: {handle,len,pos}, {w_first, w_second}
+    uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
+                                       // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
     Outbox ob;
 };
@@ -357,7 +360,19 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
 //                  iteration.  Measured (profiles/r01/one_sided_far_experiment.jsonl): stress +1..9 %; not the
 //                  reference's rule, never the default.
 constexpr int kFarTwoSided = 0, kFarExclusive = 2;
-constexpr float kFarRelax = 0.5f;
+// Under-relaxation of a launch's far pulls: together they amount to this fraction of a projection (see the kernel).
+// Half a projection — except in the first iterations: there the layout is globally inconsistent (a `-N d` layout has to
+// contract by the share of nodes a path skips), the dozen-odd long-range pulls an end averages over are then a noisy
+// estimate of where it should go, and the noise — not the mean — is what neighbouring nodes see: at 0.5 the first
+// iteration leaves neighbours ten thousand bp apart (sampled stress 20-60x the reference's at that point).  Noise and
+// mean both scale with the factor, the reference itself does not converge globally before its learning rate falls
+// (iteration ~15 of 30), so the first iterations pull gently and the factor ramps up while the windows' local terms and
+// the mean field bring the layout together: measured on the CPU mirror, 1e5 nodes (tools/cpu_transient.py,
+// profiles/r03/far_relax_schedules.txt) stress after iterations 1/2/3/5/10: 1.8e3 1.3e3 3.6e3 2.8e3 12 (reference:
+// 1.6e3 until iteration 10; constant 0.5: 3.1e4 5.2e3 9.2e2 45 11), the same final layout.
+__host__ __device__ inline float tile_far_relax(uint64_t iteration /* 0-based */) {
+    return iteration < 2 ? 0.1f : iteration < 5 ? 0.1f * (float)iteration : 0.5f;   // 0.1 0.1 0.2 0.3 0.4 0.5 ...
+}
 
 // What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has
 // fewer than 2^32 path steps), and everything about a Zipf draw that depends on the jump length n alone comes from a
@@ -490,18 +505,18 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     // A partner outside the window is read from the last snapshot, and what the term adds to it reaches its owner
     // after the launch: all the far pulls an end receives during one launch are computed against one stale position
     // and land together — a Jacobi step.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
-    // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = kFarRelax / h,
+    // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = far_relax / h,
     // h = far pulls per node end in the previous launch of this colour: together they amount to half a projection,
-    // the usual under-relaxation of a Jacobi step (measured against 1 and 1/4: profiles/r02/curves_far_policy.jsonl).
-    // Inactive once eta/d < kFarRelax / h.
+    // the usual under-relaxation of a Jacobi step (measured against 1 and 1/4: profiles/r02/curves_far_policy.jsonl),
+    // less in the first iterations (tile_far_relax).  Inactive once eta/d < far_relax / h.
     float far_mu_cap = ta.far_mu_cap_first;
     if (ta.far_from_prev) {
         const double h = (double)*ta.far_prev / (double)n_ends;
         far_mu_cap = h > 1.0 ? (float)(1.0 / h) : 1.0f;
     }
-    far_mu_cap *= kFarRelax;
+    far_mu_cap *= ta.far_relax;
     uint32_t my_queue = 0, queues_done = 0;  // (lane 0's copies are the ones used)
-    if (gridDim.x >= kItemQueues) {          // a launch of fewer workgroups (parity tests: one) takes the runs in order
+    if (gridDim.x >= kItemQueues && ta.chunk[1] != ta.chunk[kItemQueues]) {  // more than one run, and enough workgroups to have one per XCD
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         my_queue = xcc & (kItemQueues - 1u);
@@ -695,6 +710,28 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 K1 = pick_stage(j + 1);
                 send(m);
             }
+            // The tile's terms are done: rewrite the snapshot records of its OWN steps — the static half from the LDS copy,
+            // the coordinates of the step's node from the window (a tile with a window has all its nodes in it) — so that
+            // a partner outside somebody's window is seen as its tile last left it, this iteration or the one before,
+            // and no pass over all the records is needed between iterations (snapshot_kernel: 0.45 ms per iteration at
+            // config 4, a twentieth of the iteration).  Consecutive lanes write consecutive 16-byte pieces of the tile's 32 n
+            // bytes: whole 64-byte units per store instruction.  Readers in other workgroups may see a record's old or new
+            // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
+            // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
+            if (ta.recs2_out) {
+                __syncthreads();
+                uint4* dst = ta.recs2_out + 2 * (uint64_t)t.t0;
+                for (uint32_t piece = threadIdx.x; piece < 2 * t.n; piece += blockDim.x) {
+                    uint4 v = trec[piece >> 1];
+                    if (piece & 1u) {  // the two ends of the step's node, the one the step enters first in front
+                        const uint32_t e0 = v.x;
+                        const uint64_t w0 = LOCAL ? win[e0 - wbase] : load_word<COORD_LOAD>(c.coords, e0);
+                        const uint64_t w1 = LOCAL ? win[(e0 ^ 1u) - wbase] : load_word<COORD_LOAD>(c.coords, e0 ^ 1u);
+                        v = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+                    }
+                    dst[piece] = v;
+                }
+            }
         }
         __syncthreads();
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
@@ -725,9 +762,12 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
 }
 
-// Before a tile launch (every launch of a warm iteration, the first launch of a cooling one): every 32-byte step record is rewritten — the static half from the 16-byte records, the
-// second half with the coordinates of the two ends of the step's node (the end the step enters first) — so that a
-// partner outside the window costs one gather, not a record gather plus a dependent coordinate load.  Whole-line
+// Every 32-byte step record rewritten in one pass — the static half from the 16-byte records, the second half with the
+// coordinates of the two ends of the step's node (the end the step enters first) — so that a partner outside the window
+// costs one gather, not a record gather plus a dependent coordinate load.  Run when the records do not follow from the
+// tile kernel's own writes (sgd_tile_kernel rewrites a tile's records when its terms are done): before a session's first
+// tile launch, after iterations of the per-lane kernel, after the frame was widened or the coordinates were merged with
+// other devices', and before every launch of a sharded session (which runs only its share of the tiles).  Whole-line
 // writes (writing only the second halves costs a read-for-ownership of every line: 0.70 against 0.47 ms at 4.7e7
 // steps, profiles/r02/microbench_r2b.jsonl).
 __global__ __launch_bounds__(256) void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {

@@ -1144,6 +1144,25 @@ double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, ui
  * counted in the previous launch of the same parity (first iteration: 0.75 * 0.5 * n_terms / 2N assumed).
  * The tile table and the work items are the product's (pgsgd_session_tile_table / _tile_items); the test
  * checks them separately as an exact partition of steps and terms. */
+/* Under-relaxation of the far pulls of a launch (pgsgd_tiles.hpp: tile_far_relax): together they amount to this
+ * fraction of a projection — half, less in the first five iterations.  ORC_FAR_RELAX="r0,r1,..." (experiments, tools/cpu_transient.py) overrides the schedule:
+ * iteration i uses r_i, iterations past the list the last value. */
+float orc_tile_far_relax(uint64_t iter) {
+    const char* e = getenv("ORC_FAR_RELAX");
+    if (e) {
+        float v = 0.5f;
+        for (uint64_t i = 0; *e; ++i) {
+            char* end;
+            v = strtof(e, &end);
+            if (end == e) break;
+            e = *end == ',' ? end + 1 : end;
+            if (i == iter) break;
+        }
+        return v;
+    }
+    return iter < 2 ? 0.1f : iter < 5 ? 0.1f * (float)iter : 0.5f;   /* 0.1 0.1 0.2 0.3 0.4 0.5 ... (pgsgd_tiles.hpp: tile_far_relax) */
+}
+
 static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy, float mu_cap,
                                             float* r_x, float* r_y) {
     const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
@@ -1166,10 +1185,13 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
 /* The launch order of an iteration (pgsgd_session_iteration_part): [deliver the far pulls the launch before collected]
  * [snapshot, first launch of the iteration only] [launch of the even regions] [deliver] [launch of the odd regions]; what the
  * last launch collected is delivered before the first launch of the next iteration, or by pgsgd_session_flush when the run ends.
- * policy (0 = what the product ships; the others are the round-2 order, kept for tools/cpu_transient.py):
+ * policy (0 = what the product ships; the others are round 2's choices, kept for tools/cpu_transient.py and its pinned vectors):
  *   ORC_TILE_DRAIN_AFTER    a launch's far pulls are delivered right after it (an iteration then ends with the arrival of a
  *                           launch's worth of far pulls instead of with window-local terms)
  *   ORC_TILE_TWO_SNAPSHOTS  the coordinate snapshot is refreshed before both launches of a warm iteration
+ *   ORC_TILE_CONSTANT_RELAX the far pulls of a launch amount to half a projection in every iteration (no gentle start)
+ *   ORC_TILE_SNAPSHOT_PASS  partners outside a window are read from a snapshot of ALL coordinates taken once per iteration
+ *                           (sharded sessions; round 2), not from words the tiles rewrite for their own steps
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
  * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
 void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
@@ -1220,6 +1242,14 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
      * adds to them: collected (the outbox) and applied when the launch is over (far_drain_kernel) */
     uint64_t* snap = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
     uint64_t* outbox = (uint64_t*)calloc(n_ends, sizeof(uint64_t));
+    /* the snapshot words a partner outside the window is read from: a tile rewrites those of its OWN steps when its terms are
+     * done (from the window), so a partner is seen as its tile last left it, this iteration or the one before; the words of
+     * all steps are taken from the coordinates only when the run starts.  ORC_TILE_SNAPSHOT_PASS: a pass over all node
+     * ends once per iteration instead (what a sharded session does, and round 2 did) */
+    const int tile_snap = !(policy & ORC_TILE_SNAPSHOT_PASS);
+    uint64_t* snapw = tile_snap ? (uint64_t*)malloc(2 * g->n_steps * sizeof(uint64_t)) : NULL;
+    if (tile_snap)
+        for (uint64_t k = 0; k < g->n_steps; ++k) { snapw[2 * k] = W[g->step_handle[k]]; snapw[2 * k + 1] = W[g->step_handle[k] ^ 1u]; }
     const uint64_t first_cooling = (uint64_t)floor(p->cooling_start * (double)p->iter_max);
     const uint64_t n_terms = p->min_term_updates;
     float far_cap[2];
@@ -1232,6 +1262,7 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
         const float eta = (float)etas[iter];
         const int cooling = iter >= first_cooling;
         const uint64_t epoch = iter + 1;
+        const float far_relax = (policy & ORC_TILE_CONSTANT_RELAX) ? 0.5f : orc_tile_far_relax(iter);
         float dmax = 0.0f;
         uint64_t far_count[2] = {0, 0};
         int snap_taken = 0;
@@ -1268,12 +1299,16 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                          * window-less tile then reads the partner's word where it reads the first end's, in global memory */
                         const int b_in_tile = t.kb - t0[ti] < (uint64_t)tn[ti];
                         const uint64_t wa = in_a ? win[ea - wbase] : W[ea];
-                        const uint64_t wb = in_b ? win[eb - wbase] : b_in_tile ? W[eb] : snap[eb];
+                        /* experiments (tools/cpu_transient.py): 0x800 far partners are read live, 0x1000 no learning-rate cap of far terms
+                         * once cooling has started, 0x2000 no cap at all, 0x4000 far moves are applied at once (no outbox) */
+                        const uint64_t wb = in_b ? win[eb - wbase] : (b_in_tile || (policy & 0x800u)) ? W[eb]
+                                          : tile_snap ? snapw[2 * t.kb + (eb != g->step_handle[t.kb] ? 1 : 0)] : snap[eb];
                         const float dx = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * inv_scale;
                         const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * inv_scale;
                         float r_x, r_y;
                         /* far pulls are capped at kFarRelax / h: half a projection per launch in total (pgsgd_tiles.hpp) */
-                        const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, in_b ? 1.0f : far_cap[colour] * 0.5f, &r_x, &r_y);
+                        const int uncapped = (policy & 0x2000u) || ((policy & 0x1000u) && cooling);
+                        const float da = displacement_capped_f32(eta, t.pos_a, t.pos_b, dx, dy, (in_b || uncapped) ? 1.0f : far_cap[colour] * far_relax, &r_x, &r_y);
                         if (da > dmax) dmax = da;
                         const float ux = (float)(t.dither >> 14) * (1.0f / 16384.0f);
                         const float uy = (float)(t.dither & 0x3fffu) * (1.0f / 16384.0f);
@@ -1286,11 +1321,17 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                         if (!in_b) far_count[colour]++;
                         const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
                         if (!in_b && (policy & 0x100u)) continue;                 /* experiment: far terms do nothing */
-                        if (in_b) win[eb - wbase] += delta; else if (!(policy & 0x200u)) outbox[eb] += delta;
+                        if (in_b) win[eb - wbase] += delta; else if (policy & 0x4000u) W[eb] += delta; else if (!(policy & 0x200u)) outbox[eb] += delta;
                         if (!in_b && (policy & 0x400u)) continue;                 /* experiment: far terms move only the partner */
                         if (in_a) win[ea - wbase] -= delta; else outbox[ea] -= delta;
                     }
                     free(streams);
+                    if (tile_snap)
+                        for (uint64_t k = t0[ti]; k < t0[ti] + tn[ti]; ++k)
+                            for (int e = 0; e < 2; ++e) {
+                                const uint64_t end = (uint64_t)g->step_handle[k] ^ (uint64_t)e;
+                                snapw[2 * k + e] = (local[it] && end >= wbase && end - wbase < win_words) ? win[end - wbase] : W[end];
+                            }
                 }
                 if (local[it])   /* the window's only writer since it was staged: plain stores */
                     for (uint32_t i = 0; i < win_words; ++i)
@@ -1319,5 +1360,5 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
         X[i] = (float)(x_off + (double)(uint32_t)W[i] * (double)inv_scale);
         Y[i] = (float)(y_off + (double)(uint32_t)(W[i] >> 32) * (double)inv_scale);
     }
-    free(W); free(zetas); free(etas); free(win); free(orig); free(snap); free(outbox);
+    free(W); free(zetas); free(etas); free(win); free(orig); free(snap); free(outbox); free(snapw);
 }

@@ -46,6 +46,6 @@ from test_oracle_pins import tile_mirror_case  # noqa: E402
 out.update({f"tile_mirror/{k}": v for k, v in tile_mirror_case(orc, pyref).items()})
 # the same case in round 2's launch order (far pulls delivered right after their launch, two snapshots per warm
 # iteration): the vectors committed in round 2 as tile_mirror/*, unchanged
-out.update({f"tile_mirror_r2/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_DRAIN_AFTER | orc.TILE_TWO_SNAPSHOTS).items()})
+out.update({f"tile_mirror_r2/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_ROUND2).items()})
 np.savez_compressed(os.path.join(GOLDEN, "golden_vectors.npz"), **out)
 print("wrote", len(out), "arrays")

@@ -150,11 +150,12 @@ def decode_og(path):
     return dict(header=header, node_len=[len(n[1]) for n in nodes], node_seq=[n[1] for n in nodes], edges=edges, paths=paths)
 
 
-def build_tiles_py(path_first, step_handle, R, T, order="region"):
+def build_tiles_py(path_first, step_handle, R, T, order="size"):
     """Independent restatement of the tile table of the region-exclusive tile kernel: paths cut
     into tiles of T steps (single-step paths have none); a tile whose node ranks fit the window
     [r0*R, (r0+2)*R), r0 = rmin // R, joins work item r0; the launch of the even regions takes its items in
-    node order (order="size": round 2's order, by decreasing step count, ties: smaller region first), then every
+    order of decreasing step count, ties: smaller region first (order="region": in node order, the product's
+    experiment PGSGD_TILE_ORDER=region), then every
     window-less tile as an item of its own; the launch of the odd regions follows.  Returns (tiles dict, items dict) shaped like
     LayoutSession.tile_table() / tile_items()."""
     import numpy as np

@@ -305,6 +305,30 @@ def test_reference_layout_quality_bar(oa, orc, graphs, ographs):
     assert float(np.mean(vals)) <= 0.0871 * 1.10
 
 
+def test_reference_fixture_statistics_two_sided_on_gpu(oa, orc, graphs, ographs):
+    """The GPU counterpart of tests/test_oracle_pins.py::test_reference_fixture_is_reproduced_two_sided: run as the
+    reference's file was made — no cooling phase — the GPU layouts of DRB1-3123_unsorted (three initial layouts, three
+    sampler seeds) reproduce the file's statistics two-sidedly: stress, `odgi stats -s` path distance per node and per
+    bp, the percentiles of layout distance over path distance for adjacent steps and for Zipf-sampled pairs, the
+    extent.  With the default cooling phase they match the CPU restatement's default runs instead (13 % better)."""
+    import refstats
+    g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
+    terms = refstats.zipf_pairs(orc, og, orc.params_from(oa.LayoutParams.defaults(g)))
+    runs = {1.0: [], 0.5: []}
+    for cs in runs:
+        for i, seed in enumerate((7, 8, 9)):
+            p = _params(oa, g, cooling_start=cs, seed=9399220 + 7919 * i)
+            X, Y = oa.initial_layout(g, "d", seed=seed)
+            oa.path_linear_sgd_layout_gpu(g, p, X, Y)
+            runs[cs].append(refstats.layout_stats(orc, g, og, X, Y, terms))
+    no_cooling, default = refstats.mean_stats(runs[1.0]), refstats.mean_stats(runs[0.5])
+    print("reference file    ", refstats.FIXTURE)
+    print("GPU, no cooling   ", no_cooling)
+    print("GPU, default -K   ", default)
+    refstats.assert_matches_fixture(no_cooling, "GPU without cooling", stress_band=0.05)
+    assert 0.072 <= default["stress"] <= 0.079 and 8.75 <= default["per_node"] <= 9.15, default
+
+
 def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs):
     """BASELINE config 3 in small: deterministic -N h initial layout, theta and -K sweep."""
     g, og = graphs("chr6.C4"), ographs("chr6.C4")
@@ -422,6 +446,10 @@ def test_synthetic_million_node_properties(oa, orc):
     assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p2), p2.seed, 256, 0, True, 4))
 
 
+# the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
+TILE_CURVE = {5: 72.7, 10: 6.9, 15: 6.4}
+
+
 def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
     """Sampled path stress after the iterations in snap_iters (1-based), one evaluator for every run."""
     etas = oa.path_linear_sgd_layout_schedule(p)
@@ -500,12 +528,19 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
         band = 1.0 + max(0.10, 2.0 * spread[k])
         msg = f"iteration {it}: cpu {cpu_mean[k]:.4g} (spread {spread[k]:.2g}) per-lane {lane[k]:.4g} tile {tile[k]:.4g} band {band:.2f}"
         assert cpu_mean[k] / band <= lane[k] <= band * cpu_mean[k], msg    # the reference's rule, term by term
-        if it >= 20:
-            assert cpu_mean[k] / band <= tile[k] <= band * cpu_mean[k], msg  # the same layout once the cap is inactive
+        if it >= 30:
+            assert cpu_mean[k] / band <= tile[k] <= band * cpu_mean[k], msg  # the same layout at the end
+        elif it >= 20:
+            # through the cooling transition the tile kernel is AHEAD of the reference (measured 0.73 against 0.80 at
+            # iteration 20): not more than 20 % ahead, not more than the band behind
+            assert 0.80 * cpu_mean[k] <= tile[k] <= band * cpu_mean[k], msg
         elif it >= 5:
             assert tile[k] <= band * cpu_mean[k], msg                    # milder transient, never worse
+            # and two-sided against the tile kernel's own committed curve (+-25 %... a factor 2: these points fall three
+            # orders of magnitude within five iterations), so that a change of the transient is at least detected
+            assert 0.5 * TILE_CURVE[it] <= tile[k] <= 2.0 * TILE_CURVE[it], msg
         else:
-            assert tile[k] <= 150.0 * cpu_mean[k], msg                   # the first iteration's excursion (see above)
+            assert tile[k] <= 10.0 * cpu_mean[k], msg                    # the first iteration's excursion (see above)
 
 
 _CONFIG5 = {}
@@ -933,7 +968,7 @@ def test_cpp_multi_gpu_driver_executes_rccl_with_one_rank(oa, graphs, monkeypatc
     for real on the one GPU of the test box: PGSGD_MULTI_FORCE=1 sends an n_devices = 1 run through the driver — one
     rank, a one-rank communicator, the same fused all-reduce after every exchange block.  A one-rank exchange is the
     identity up to a quantum per exchange, so the layout must be as good as the plain run's."""
-    for g, kw in ((oa.Graph.synthetic(100_000, 12, seed=3), dict(min_term_updates=300_000)), (graphs("LPA"), {})):
+    for g, kw in ((oa.Graph.synthetic(100_000, 12, seed=3), {}), (graphs("LPA"), {})):
         X0, Y0 = oa.initial_layout(g, "d", seed=4)
         X1, Y1 = X0.copy(), Y0.copy()
         p = _params(oa, g, **kw)
@@ -1098,7 +1133,7 @@ def test_exchange_kernels_match_the_merge_rule_word_for_word(oa, graphs):
         assert np.array_equal(b[2 * n_ends:3 * n_ends], dx * dx + dy * dy)
     total = torch.stack(bufs).sum(0)
     t = total.cpu().numpy()
-    S, Q = t[:2 * n_ends].reshape(-1, 2), t[2 * n_ends:]
+    S, Q = t[:2 * n_ends].reshape(-1, 2), t[2 * n_ends:3 * n_ends]
     s2 = S[:, 0] * S[:, 0] + S[:, 1] * S[:, 1]
     with np.errstate(divide="ignore", invalid="ignore"):
         f = np.where(s2 > 0, np.minimum(np.maximum(Q / s2, np.float32(1.0 / G)), np.float32(1.0)), np.float32(1.0)).astype(np.float32)

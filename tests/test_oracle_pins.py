@@ -176,6 +176,38 @@ def test_reference_layout_fixture_quality_bar(oa, orc, graphs, ographs):
     assert per_node == pytest.approx(9.59988, abs=1e-4) and per_bp == pytest.approx(1.28546, abs=1e-4)
 
 
+def test_reference_fixture_is_reproduced_two_sided(oa, orc, graphs, ographs):
+    """The reference's one layout file against the oracle, TWO-sided and on more than one number.  Round 2 could only
+    say "the oracle is at least as good" (0.0755 against the file's 0.0871, a 13 % gap no seed or thread count closes:
+    nine runs give 0.0750 .. 0.0758).  A sweep of the generating parameters (tools/reference_pin_sweep.py) finds the
+    one that does: WITHOUT the cooling phase (`-K 1`: never switch to Zipf-only partners; the file is older than the
+    `-K` option's default of 0.5) the restatement reproduces the file — stress, `odgi stats -s`, the distribution of
+    layout distance over path distance for adjacent steps and for Zipf-sampled pairs, the layout's extent — within the
+    bands of tests/refstats.py, from three initial layouts, with the docs' `--threads 2`
+    (docs/rst/tutorials/sort_layout.rst:365).  With the default cooling phase the same restatement is 13 % better,
+    also asserted two-sided."""
+    import refstats
+    g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
+    lay = oa.Layout.load(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"))
+    terms = refstats.zipf_pairs(orc, og, orc.params_from(oa.LayoutParams.defaults(g)))
+    fx = refstats.layout_stats(orc, g, og, lay.X, lay.Y, terms)
+    for k, v in refstats.FIXTURE.items():   # the constants the GPU test compares with are the file's
+        assert np.allclose(fx[k], v, rtol=2e-3), (k, fx[k], v)
+    runs = {1.0: [], 0.5: []}
+    for cs in runs:
+        p = oa.LayoutParams.defaults(g, cooling_start=cs)
+        for seed in (7, 8, 9):
+            X0, Y0 = oa.initial_layout(g, "d", seed=seed)
+            X, Y, _ = orc.layout_hogwild(og, orc.params_from(p), 2, X0, Y0)
+            runs[cs].append(refstats.layout_stats(orc, g, og, X, Y, terms))
+    no_cooling, default = refstats.mean_stats(runs[1.0]), refstats.mean_stats(runs[0.5])
+    print("reference file      ", fx)
+    print("oracle, no cooling  ", no_cooling)
+    print("oracle, default -K  ", default)
+    refstats.assert_matches_fixture(no_cooling, "oracle without cooling")
+    assert 0.0735 <= default["stress"] <= 0.0775 and 8.8 <= default["per_node"] <= 9.1, default
+
+
 def test_oracle_hogwild_reaches_reference_quality(oa, orc, graphs, ographs):
     """The oracle's restatement of the reference loop lays DRB1-3123_unsorted out as well as the
     reference did (0.0871): this pins the whole restated chain end to end, statistically."""
@@ -206,8 +238,7 @@ def tile_mirror_case(orc, pyref, policy=0):
     p = orc.params(iter_max=6, iter_with_max_learning_rate=0, min_term_updates=2 * g.n_steps, delta=0.0, eps=0.01,
                    eta_max=float(max_steps) ** 2, theta=0.99, space=max_steps, space_max=1000, space_quantization_step=100,
                    cooling_start=0.5)
-    # (round 2 ordered the work items by size; its vectors are pinned with its order)
-    tiles, items = pyref.build_tiles_py(d["path_first"], d["step_handle"], 64, 56, order="size" if policy else "region")
+    tiles, items = pyref.build_tiles_py(d["path_first"], d["step_handle"], 64, 56)
     ends = np.cumsum(np.repeat(d["node_len"].astype(np.float64), 2) * np.tile([0.0, 1.0], g.n_nodes))
     X0 = ends.astype(np.float32)
     Y0 = (((np.arange(2 * g.n_nodes) * 2654435761) % 1000) / 10.0 - 50.0).astype(np.float32)
@@ -229,7 +260,7 @@ def test_tile_mirror_golden_regression(orc):
     # round 2's launch order (far pulls delivered right after their launch, two snapshots per warm iteration) is still
     # in the mirror as a policy, and still gives the vectors committed in round 2: the terms and their arithmetic did
     # not change with the order of the launches
-    old = tile_mirror_case(orc, pyref, policy=orc.TILE_DRAIN_AFTER | orc.TILE_TWO_SNAPSHOTS)
+    old = tile_mirror_case(orc, pyref, policy=orc.TILE_ROUND2)
     for k, v in old.items():
         assert np.array_equal(v, gv[f"tile_mirror_r2/{k}"]), k
     assert not np.array_equal(old["X"], got["X"])

@@ -42,9 +42,11 @@ def main():
     print(json.dumps(dict(policy="reference rule (CPU restatement, 8 threads)", seconds=round(time.time() - t, 1),
                           stress={k: orc.path_stress_sampled(og, sx[i], sy[i], 400000) for i, k in enumerate(its)})), flush=True)
     NF = orc.TILE_NO_FLUSH   # what a snapshot after the iteration sees
-    for name, pol in (("round 2: drain after its launch, two snapshots per warm iteration", orc.TILE_DRAIN_AFTER | orc.TILE_TWO_SNAPSHOTS),
-                      ("drain before the next launch, two snapshots", orc.TILE_TWO_SNAPSHOTS | NF),
-                      ("shipped: drain before the next launch, one snapshot", NF), ("drain after, one snapshot", orc.TILE_DRAIN_AFTER)):
+    CR = orc.TILE_CONSTANT_RELAX
+    for name, pol in (("round 2: drain after its launch, two snapshots per warm iteration, far pulls = half a projection", orc.TILE_ROUND2),
+                      ("drain before the next launch, two snapshots, half a projection", orc.TILE_TWO_SNAPSHOTS | CR | NF),
+                      ("drain before the next launch, one snapshot, half a projection", CR | NF),
+                      ("shipped: drain before the next launch, one snapshot, gentle first iterations", NF)):
         out = {}
         t = time.time()
         for k in its:
