@@ -84,6 +84,9 @@ typedef struct pgsgd_graph_view {
                                            /* busiest one, and cap the learning rate of terms on busier nodes at 1/h.      */
                                            /* 12x faster on a hub graph (DRB1-3123_unsorted) at +30 % stress, worse        */
                                            /* everywhere else (profiles/r02/hotcap_per_lane_*.jsonl): never the default    */
+#define PGSGD_FLAG_NO_PIPELINE       0x80u /* per-lane kernel: the plain term loop (one term per lane in flight) instead of the    */
+                                           /* software-pipelined one (four terms per lane in different stages); same terms, same   */
+                                           /* arithmetic, A/B and parity                                                            */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

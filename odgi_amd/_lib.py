@@ -54,6 +54,7 @@ FLAG_NO_TILES = 0x8
 FLAG_NO_FAR_CAP = 0x10
 FLAG_ONE_SIDED_FAR = 0x20
 FLAG_HOT_NODE_CAP = 0x40
+FLAG_NO_PIPELINE = 0x80
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8

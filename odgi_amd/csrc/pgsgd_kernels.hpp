@@ -466,6 +466,194 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel(DevConst c, IterA
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same kernel for the default configuration (fixed-point coordinates, terms_per_anchor = 1, fewer than 2^32 path
+// steps, no hot-node cap), software-pipelined: a lane has FOUR terms in different stages at any time.
+//
+// The loop above is one dependent chain per term — zeta entry (L2) -> partner record (HBM) -> the two coordinate words
+// -> two atomics — and a lane waits out each of the three loads in turn.  With the stream count bounded by the busiest
+// node (auto_streams: 128 ... 5632 lanes on the reference's fixture graphs, on a chip that holds half a million) the
+// lanes' own latency is the whole run time.  Here every trip of the loop
+//   S4  finishes term j-3: its two coordinate words have arrived — displacement, rounding, the two atomics;
+//   S3  takes term j-2's partner record, which has arrived, and requests the two coordinate words;
+//   S2  takes term j-1's zeta entry and first record, draws nothing, computes the Zipf partner, requests its record;
+//   S1  draws ALL of term j's variates, in the reference's order (path_sgd_layout.cpp:182,205-206,215/228,235-237,
+//       253,262 — so a lane's stream is consumed exactly as above and trace_kernel still describes it), and requests
+//       the first step's record and the zeta entry;
+// so whatever a trip requests is consumed a trip later, in one place (gfx9 counts loads and stores in one counter: one
+// full wait per trip, for requests that are a trip old).  Oldest stage first: a stage's registers are read before the
+// younger stage overwrites them.  The coordinate words of a term are requested after the atomics of the term before it
+// were issued (S4 runs before S3), so a lane's own updates are seen by its next term exactly as in the loop above: a
+// one-stream run gives the same bits (tests: one-stream mirrors), and the window between reading an end and moving it
+// — what the stream-count rule is about — holds one term per lane, as before.
+struct PipeS1 {            // a term whose variates are drawn; first record and zeta entry on their way
+    uint4 ra;
+    double2 zd;
+    double u;              // the Zipf variate (generate_canonical), a Zipf term only
+    uint32_t s_rank, pstart;
+    uint32_t aux;          // Zipf term: the jump length; otherwise the partner's rank in the path
+    uint32_t flags;        // bit 0 valid, 1 Zipf partner, 2 backwards, 3 far end of the first step's node, 4 of the partner's
+    uint32_t dither;
+};
+struct PipeS2 {            // partner chosen; its record on its way
+    uint4 rb;
+    uint64_t pos_a;
+    uint32_t end_a, flags, dither;
+};
+struct PipeS3 {            // both ends known; their coordinate words on their way
+    uint64_t wa, wb;
+    float d;               // path distance of the two ends, (float)|pos_a - pos_b|
+    uint32_t end_a, end_b, flags, dither;
+};
+
+template <bool PF_LDS, int COORD_LOAD, int UPD>
+__global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c, IterArgs a) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    float dmax = 0.0f;
+    bool guard = false;
+    const uint64_t n_mine = a.n_terms > g ? (a.n_terms - g + L - 1) / L : 0;  // terms g, g + L, ... of the iteration
+    PipeS1 p1;
+    PipeS2 p2;
+    PipeS3 p3;
+    p1.flags = p2.flags = p3.flags = 0;
+    // (the generator state has to be here before the loop: the compiler would otherwise wait for it at its first use
+    // inside the loop — a counted wait that, executed every trip, also waits for the loads the trip has just issued)
+    asm volatile("" ::"v"(rng.s0), "v"(rng.s1), "v"(rng.s2), "v"(rng.s3));
+    p1.ra = make_uint4(0, 0, 0, 0);
+    p1.zd = make_double2(0.0, 0.0);
+    p2.rb = make_uint4(0, 0, 0, 0);
+    p3.wa = p3.wb = 0;
+    for (uint64_t j = 0; j < n_mine + 3; ++j) {
+        // The trip's one wait.  Everything the last trip requested is used here, by every lane, before this trip's atomics
+        // go out: with a use only inside the stages' branches the compiler has to wait again after the atomics (a branch
+        // may have been skipped), and that wait — loads and atomics share a counter — would be for the atomics' round trip.
+        asm volatile("" ::"v"(p3.wa), "v"(p3.wb), "v"(p2.rb.x), "v"(p2.rb.w), "v"(p1.ra.x), "v"(p1.ra.w), "v"(p1.zd.x), "v"(p1.zd.y));
+        // ---- S4: term j - 3 (path_sgd_layout.cpp:280-363) ----
+        if (p3.flags & 1u) {
+            const uint64_t wa = p3.wa, wb = p3.wb;
+            const float dx0 = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;  // exact integer differences
+            const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+            guard |= in_frame_guard(wa) || in_frame_guard(wb);
+            // term_displacement() with the distance already converted: the same operations
+            float d = p3.d;
+            if (d == 0.0f) d = 1e-9f;
+            const float w = 1.0f / d;
+            float mu = a.eta * w;
+            if (mu > 1.0f) mu = 1.0f;
+            float dx = dx0;
+            if (dx == 0.0f) dx = 1e-9f;
+            const float dx2 = dx * dx;
+            const float dy2 = dy * dy;
+            const float mag = sqrtf(dx2 + dy2);
+            const float Delta = (mu * (mag - d)) / 2.0f;
+            dmax = fmaxf(dmax, fabsf(Delta));
+            const float r = Delta / mag;
+            const float r_x = r * dx, r_y = r * dy;
+            if (!(UPD == kUpdStore && p3.end_a == p3.end_b)) {  // (Hogwild stores: the reference's two load/store pairs cancel)
+                const float ux = (float)(p3.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(p3.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    if ((qx | qy) != 0) {  // a step that rounds to no quantum adds zero: nothing to send
+                        const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_b), (unsigned long long)delta);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_a), (unsigned long long)(0 - delta));
+                    }
+                } else {
+                    __hip_atomic_store(c.coords + p3.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(c.coords + p3.end_a, q32_shift(wa, -qx, -qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- S3: term j - 2: the partner's record is here (:242-269), the coordinate words go out ----
+        p3.flags = p2.flags;
+        if (p2.flags & 1u) {
+            const uint4 rb = p2.rb;
+            uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+            uint32_t off_b = rb.x & 1u;
+            if (p2.flags & 16u) { pos_b += rb.y; off_b ^= 1u; }
+            p3.end_a = p2.end_a;
+            p3.end_b = (rb.x & ~1u) | off_b;
+            p3.dither = p2.dither;
+            const int64_t diff = (int64_t)p2.pos_a - (int64_t)pos_b;
+            p3.d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+            p3.wa = load_word<COORD_LOAD>(c.coords, p3.end_a);
+            p3.wb = load_word<COORD_LOAD>(c.coords, p3.end_b);
+        }
+        // ---- S2: term j - 1: zeta entry and first record are here; the partner (:207-237), its record goes out ----
+        p2.flags = p1.flags;
+        if (p1.flags & 1u) {
+            uint32_t b_rank = p1.aux;
+            if (p1.flags & 2u) {
+                const uint32_t z = (uint32_t)zipf_tabled_u(p1.u, c.zc, p1.aux, p1.zd.x, p1.zd.y);  // (z <= the jump length < 2^32)
+                b_rank = (p1.flags & 4u) ? p1.s_rank - z : p1.s_rank + z;
+            }
+            p2.rb = c.recs[(uint64_t)p1.pstart + b_rank];
+            const uint4 ra = p1.ra;
+            uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32);
+            uint32_t off_a = ra.x & 1u;
+            if (p1.flags & 8u) { pos_a += ra.y; off_a ^= 1u; }
+            p2.pos_a = pos_a;
+            p2.end_a = (ra.x & ~1u) | off_a;
+            p2.dither = p1.dither;
+        }
+        // ---- S1: term j: every variate, in the reference's order; first record and zeta entry go out ----
+        p1.flags = 0;
+        if (j < n_mine) {
+            uint32_t k, pstart, cnt;
+            do {  // :182-192 — a single-step path makes the reference draw again without counting a term
+                k = (uint32_t)uniform_below(rng, c.n_steps);
+                const uint32_t p = find_path(pf, c.n_paths, (uint64_t)k);
+                pstart = (uint32_t)pf[p];
+                cnt = (uint32_t)(pf[p + 1] - pf[p]);
+            } while (cnt == 1);
+            p1.ra = c.recs[k];
+            p1.s_rank = k - pstart;
+            p1.pstart = pstart;
+            uint32_t flags = 1u;
+            if (a.cooling || coin(rng)) {                                                       // :205
+                const bool back = (p1.s_rank > 0 && coin(rng)) || p1.s_rank == cnt - 1;         // :206
+                const uint32_t room = back ? p1.s_rank : cnt - p1.s_rank - 1;
+                const uint32_t jump = c.space < room ? (uint32_t)c.space : room;
+                p1.zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
+                p1.u = canonical(rng);
+                p1.aux = jump;
+                flags |= 2u | (back ? 4u : 0u);
+            } else {
+                p1.aux = (uint32_t)uniform_below(rng, (uint64_t)cnt);                           // :235-237
+            }
+            const uint64_t draw_a = rng.next(), draw_b = rng.next();                            // :253, :262
+            flags |= (uint32_t)(draw_a >> 63) << 3 | (uint32_t)(draw_b >> 63) << 4;
+            p1.dither = (uint32_t)draw_a;
+            p1.flags = flags;
+        }
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500): the layout's
 // sibling — same first-step/partner sampler, one coordinate per node, no end choice.  Differences:
 // the Zipf draw uses adj_theta = 0.001 once cooling starts while the zeta cache keeps the user's theta

@@ -170,9 +170,9 @@ PGSGD_HD uint64_t zipf(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n, doubl
 // per table entry by the same two fp64 operations (zipf_denominator), and the exponents pre-split (pow_split).
 // Bit-identical to zipf(): one fp64 division and two per-lane exponent loops less per draw.
 PGSGD_HD double zipf_denominator(const ZipfConst& zc, double zeta_n) { return 1.0 - zc.zeta2 / zeta_n; }
-PGSGD_HD uint64_t zipf_tabled(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n, double zeta_n, double denom) {
+// (the variate u = canonical(g) drawn by the caller: a pipelined kernel draws it a stage before it has zeta_n)
+PGSGD_HD uint64_t zipf_tabled_u(double u, const ZipfConst& zc, uint64_t n, double zeta_n, double denom) {
     const double eta = (1.0 - pow_split(2.0 / (double)n, zc.omt_e, zc.omt_frac)) / denom;
-    const double u = canonical(g);
     const double uz = u * zeta_n;
     if (uz < 1.0) return 1;
     if (uz < zc.one_plus_half_pow) return 2;
@@ -181,6 +181,9 @@ PGSGD_HD uint64_t zipf_tabled(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n
     if (r < 1) r = 1;
     if (r > n) r = n;
     return r;
+}
+PGSGD_HD uint64_t zipf_tabled(Xoshiro256Plus& g, const ZipfConst& zc, uint64_t n, double zeta_n, double denom) {
+    return zipf_tabled_u(canonical(g), zc, n, zeta_n, denom);  // (eta does not depend on the draw: the same operations, the same bits)
 }
 
 // index into the zeta cache for a jump of `jump` steps (path_sgd_layout.cpp:208-212)

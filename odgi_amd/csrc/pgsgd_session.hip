@@ -85,6 +85,7 @@ struct pgsgd_session {
     bool ob_pending = false;              // the last tile launch's far pulls wait in the outbox (drained before the next launch)
     bool snap_stale = true;               // the snapshot halves of the step records do not follow from the tile kernel's own writes
     bool tile_forced = false;             // PGSGD_TILE_FORCE (parity knob) was set when the session was created
+    bool snapshot_pass = false;           // PGSGD_TILE_SNAPSHOT_PASS (experiment knob): a pass over all records per iteration, as a sharded session takes
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
     uint64_t term0_terms = 0;
     uint32_t ob_part_shift = 13;          // log2 of the node ends one drain workgroup accumulates in LDS
@@ -226,6 +227,25 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
     using namespace pgsgd;
     if (fmt == kFmtQ32) return upd == kUpdStore ? select_kernel_fu<kFmtQ32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtQ32, kUpdAtomic>(pf_lds, plain, grouped, abl);
     return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, grouped, abl);
+}
+
+// the software-pipelined instance of the default configuration (pgsgd_kernels.hpp: sgd_iteration_kernel_piped)
+static iter_kernel_t select_piped(bool pf_lds, bool plain, int upd) {
+    using namespace pgsgd;
+    if (upd == kUpdStore) {
+        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore> : sgd_iteration_kernel_piped<true, 1, kUpdStore>;
+        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore> : sgd_iteration_kernel_piped<false, 1, kUpdStore>;
+    }
+    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic>;
+    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic>;
+}
+// which per-lane kernel a session launches: the pipelined one for fixed-point coordinates, one term per first step,
+// fewer than 2^32 path steps and no hot-node cap; the general one otherwise
+static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t abl) {
+    const bool grouped = s->params.terms_per_anchor > 1;
+    if (s->fmt == pgsgd::kFmtQ32 && !grouped && !abl && s->n_steps < 0xffffffffull && !(s->params.flags & (PGSGD_FLAG_HOT_NODE_CAP | PGSGD_FLAG_NO_PIPELINE)))
+        return select_piped(s->pf_lds, plain, s->upd);
+    return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
 // Host side of the tiled kernel: cut paths into tiles, bind tiles to region windows, order the work.
@@ -544,7 +564,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = p->n_streams;
     } else {
         int bpc = 0;
-        iter_kernel_t k = select_kernel(s->pf_lds, false, s->fmt, s->upd, p->terms_per_anchor > 1, 0);
+        iter_kernel_t k = session_kernel(s, false, 0);
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k, pgsgd::kBlock, s->lds_bytes));
         if (bpc < 1) bpc = 1;
         s->n_streams = (p->flags & PGSGD_FLAG_HOT_NODE_CAP) ? capped_streams(s, prop.multiProcessorCount, bpc, p->min_term_updates)
@@ -589,6 +609,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
         const bool force = pgsgd::debug_env("PGSGD_TILE_FORCE") != nullptr;
         s->tile_forced = force;
+        s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
         bool short_paths = true;
         for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
@@ -1266,7 +1287,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // warm iteration to tame the far pulls delivered at the END of an iteration; delivered at the start of the
             // next launch they need no second refresh, and the tiles' own writes give the same curves as a pass per
             // iteration: tools/cpu_transient.py.)
-            const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || n_parts > 1 || s->tile_substeps > 1;  // this launch runs a share of the tiles
+            const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || n_parts > 1 || s->tile_substeps > 1 || s->snapshot_pass;  // this launch runs a share of the tiles
             ta.recs2_out = sharded ? nullptr : s->d_recs2;
             if (!snapshot_taken && (sharded || s->snap_stale)) {
                 hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
@@ -1304,7 +1325,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     }
     const bool plain = (s->params.flags & PGSGD_FLAG_COORD_LOAD_PLAIN) != 0;
     const uint32_t abl = (s->params.flags >> 8) & 0xfu;
-    iter_kernel_t kernel = select_kernel(s->pf_lds, plain, s->fmt, s->upd, s->dc.terms_per_anchor > 1, abl);
+    iter_kernel_t kernel = session_kernel(s, plain, abl);
     if (!kernel) { set_error("no kernel instance for these debug flags"); return PGSGD_E_UNSUPPORTED; }
     pgsgd_session::EvSet ev;
     {
