@@ -89,13 +89,11 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
 
     timer.lap("gfa: read file");
     const int nt_lines = std::max(1, std::min(n_threads, 64));
+    bool threads_ok = true;  // false: a worker ran out of memory (checked after every parallel section)
     // fn(t, begin, end) on contiguous slices of [0, n): on threads when there is enough to split
     auto parallel_slices = [&](uint64_t n, uint64_t min_per_thread, auto&& fn) {
         const unsigned k = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt_lines, n / std::max<uint64_t>(1, min_per_thread)));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < k; ++t) th.emplace_back(fn, t, n * t / k, n * (t + 1) / k);
-        fn(0u, (uint64_t)0, n / k);
-        for (auto& x : th) x.join();
+        if (!pgsgd::run_threads(k, [&](unsigned t) { fn(t, n * t / k, n * (t + 1) / k); })) threads_ok = false;
         return k;
     };
     // lines: the file is cut at newlines into one range per thread, every range lists its S, L and P lines, the lists
@@ -135,6 +133,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         }
     }
     if (s_lines.empty()) { set_error("'%s' has no S lines", path); return PGSGD_E_FORMAT; }
+    if (!threads_ok) { set_error("out of memory while reading '%s'", path); return PGSGD_E_NOMEM; }
     timer.lap("gfa: split lines");
 
     auto g = new pgsgd_graph();
@@ -150,7 +149,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         return best;
     };
     {
-        std::vector<uint8_t> seen(N, 0);
+        std::vector<uint64_t> seen(N, 0);  // 1 + the S line that claimed the id (0: none yet)
         std::vector<LineError> errs((size_t)nt_lines);
         std::vector<uint64_t> lo((size_t)nt_lines, UINT64_MAX), hi((size_t)nt_lines, 0);
         const unsigned k = parallel_slices(N, 1 << 16, [&](unsigned t, uint64_t b0, uint64_t b1) {
@@ -171,11 +170,17 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
                 const char* sb = ne < ln.e ? ne + 1 : ln.e;
                 const char* se = next_tab(sb, ln.e);
                 if (id >= 1 && id <= N) {
-                    if (__atomic_exchange_n(&seen[id - 1], (uint8_t)1, __ATOMIC_RELAXED)) {
-                        errs[t].line = i;
-                        errs[t].code = PGSGD_E_FORMAT;
-                        errs[t].msg = "duplicate node id " + std::to_string(id);
-                        break;
+                    if (const uint64_t prev = __atomic_exchange_n(&seen[id - 1], i + 1, __ATOMIC_RELAXED)) {
+                        // the duplicate is the LATER of the two lines, whichever thread got there first (a reader going
+                        // through the file in order reports it there); this slice goes on unless that line is its own
+                        const uint64_t dup = std::max(i, prev - 1);
+                        if (dup < errs[t].line) {
+                            errs[t].line = dup;
+                            errs[t].code = PGSGD_E_FORMAT;
+                            errs[t].msg = "duplicate node id " + std::to_string(id);
+                        }
+                        if (dup == i) break;
+                        continue;
                     }
                     g->node_len[id - 1] = (uint32_t)(se - sb);
                 }
@@ -198,6 +203,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
             return PGSGD_E_NOTOPTIMIZED;
         }
     }
+    if (!threads_ok) { set_error("out of memory while reading '%s'", path); delete g; return PGSGD_E_NOMEM; }
     timer.lap("gfa: S lines");
     // edges (only needed for the weakly-connected-component post step)
     {
@@ -242,6 +248,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         g->edges.reserve(total);
         for (unsigned t = 0; t < k; ++t) g->edges.insert(g->edges.end(), part[t].begin(), part[t].end());
     }
+    if (!threads_ok) { set_error("out of memory while reading '%s'", path); delete g; return PGSGD_E_NOMEM; }
     timer.lap("gfa: L lines");
     // graph_t::create_edge ignores an edge that exists (odgi.cpp:611-631), and a -> b is the same edge as
     // flip(b) -> flip(a): keep the first occurrence of each, in file order
@@ -304,10 +311,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         auto body = [&]() {
             for (uint64_t ci = next.fetch_add(1); ci < chunks.size(); ci = next.fetch_add(1)) fn(chunks[ci]);
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt && (size_t)t < chunks.size(); ++t) th.emplace_back(body);
-        body();
-        for (auto& t : th) t.join();
+        if (!pgsgd::run_threads((unsigned)std::max<size_t>(1, std::min<size_t>((size_t)nt, chunks.size())), [&](unsigned) { body(); })) threads_ok = false;
     };
     // a token is what lies between commas; empty tokens and the placeholder "*" are not steps
     // pass 1: steps = tokens - empty tokens - "*" tokens, each counted by a loop without carried state (the compiler
@@ -388,6 +392,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         }
         c.bp = bp;
     });
+    if (!threads_ok) { set_error("out of memory while reading '%s'", path); delete g; return PGSGD_E_NOMEM; }
     timer.lap("gfa: P lines (threads)");
     for (const Chunk& c : chunks)  // the first error in file order
         if (c.err) {
@@ -407,6 +412,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
             pos += g->node_len[g->step_handle[k] >> 1];
         }
     });
+    if (!threads_ok) { set_error("out of memory while reading '%s'", path); delete g; return PGSGD_E_NOMEM; }
     timer.lap("gfa: step index (threads)");
     *out = g;
     return PGSGD_OK;
@@ -484,11 +490,10 @@ extern "C" int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_
             }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(worker);
-        worker();
-        for (auto& t : th) t.join();
+    if (!pgsgd::run_threads((unsigned)nt, [&](unsigned) { worker(); })) {
+        delete g;
+        pgsgd::set_error("out of memory while generating the synthetic graph");
+        return PGSGD_E_NOMEM;
     }
     g->path_first.assign(P + 1, 0);
     g->path_names.resize(P);
@@ -516,11 +521,10 @@ extern "C" int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_
             std::vector<uint32_t>().swap(walks[pi]);
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(filler);
-        filler();
-        for (auto& t : th) t.join();
+    if (!pgsgd::run_threads((unsigned)nt, [&](unsigned) { filler(); })) {
+        delete g;
+        pgsgd::set_error("out of memory while generating the synthetic graph");
+        return PGSGD_E_NOMEM;
     }
     *out = g;
     return PGSGD_OK;

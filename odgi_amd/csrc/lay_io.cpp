@@ -114,11 +114,9 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
     uint64_t z_size = 0, max_sample = 0;
     std::vector<uint64_t> block_bits((size_t)samples + 1, 0);
     const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({32, std::thread::hardware_concurrency(), samples / 64 + 1}));
+    bool threads_ok = true;
     auto on_threads = [&](auto&& body) {  // body(thread index): contiguous ranges of blocks
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(body, t);
-        body(0u);
-        for (auto& t : th) t.join();
+        if (!pgsgd::run_threads(nt, body)) threads_ok = false;
     };
     auto range = [&](unsigned t) { return std::make_pair(samples * t / nt, samples * (t + 1) / nt); };
     on_threads([&](unsigned t) {
@@ -130,6 +128,7 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
             block_bits[(size_t)b + 1] = bits;
         }
     });
+    if (!threads_ok) return PGSGD_E_NOMEM;
     for (uint64_t b = 0; b < samples; ++b) {
         if (max_sample < vals[b * dens]) max_sample = vals[b * dens];
         block_bits[(size_t)b + 1] += block_bits[(size_t)b];  // -> bit offset of block b + 1
@@ -162,6 +161,7 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
                 for (uint64_t i = b * dens + 1; i < e; ++i) delta_put(w, vals[i] - vals[i - 1]);
             }
         });
+        if (!threads_ok) return PGSGD_E_NOMEM;
         for (unsigned t = 0; t < nt; ++t) {
             const auto [b0, b1] = range(t);
             if (b0 == b1) continue;
@@ -445,10 +445,11 @@ extern "C" int pgsgd_write_tsv(const char* path, uint64_t n_nodes, const uint32_
     };
     {
         const unsigned nt = n_chunks > 1 ? std::max(1u, std::min<unsigned>({64u, std::thread::hardware_concurrency(), (unsigned)n_chunks})) : 1u;
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(format);
-        format();
-        for (auto& t : th) t.join();
+        if (!pgsgd::run_threads(nt, [&](unsigned) { format(); })) {
+            pgsgd::set_error("out of memory while formatting the TSV");
+            if (f != stdout) fclose(f);
+            return PGSGD_E_NOMEM;
+        }
     }
     for (const std::string& o : out)
         if (fwrite(o.data(), 1, o.size(), f) != o.size()) {

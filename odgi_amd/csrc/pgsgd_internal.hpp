@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <memory>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -27,6 +29,30 @@ inline const char* debug_env(const char* name) {
     const char* dbg = getenv("PGSGD_DEBUG");
     if (!dbg || dbg[0] != '1') return nullptr;
     return getenv(name);
+}
+
+// body(t) for t = 0 .. n-1 on n threads (t = 0 on the caller), joined before returning.  Nothing escapes: a thread that
+// cannot be started has its index run by the caller (a worker-pool body then simply finds no work left), an exception
+// in a body (std::bad_alloc while a worker grows its vectors) is caught, and either makes the call return false — a
+// joinable std::thread that is destroyed, or an exception leaving a thread, would end the process in std::terminate,
+// where the single-threaded readers returned PGSGD_E_NOMEM.
+template <class F>
+inline bool run_threads(unsigned n, F&& body) {
+    std::atomic<bool> ok{true};
+    auto guarded = [&](unsigned t) {
+        try { body(t); } catch (...) { ok.store(false); }
+    };
+    std::vector<std::thread> th;
+    unsigned started = 1;
+    try {
+        th.reserve(n > 1 ? n - 1 : 0);
+        for (unsigned t = 1; t < n; ++t) { th.emplace_back(guarded, t); ++started; }
+    } catch (...) {  // (std::system_error: no more threads; nothing is lost, the caller runs the rest)
+    }
+    guarded(0u);
+    for (unsigned t = started; t < n; ++t) guarded(t);
+    for (auto& x : th) x.join();
+    return ok.load();
 }
 
 // PGSGD_TIMING=1: wall-clock of the set-up phases on stderr (where the time of a run goes besides the kernels)

@@ -468,26 +468,6 @@ struct PendingTerm {
 // uniform-partner branch are compiled out.  LOCAL: the work items have a window (the usual case); window-less items
 // (tiles of unsorted stretches) run in their own launch with every end read from global memory and every update sent
 // through the outbox.
-// How a tile writes its snapshot records: a streaming write of 1.5 GB per iteration next to the gathers that live on
-// what the L2 holds.  0: plain stores (the lines stay in the writing XCD's L2), 1: write-through stores that drop the
-// line (sc1), 2: non-temporal.  Measured: profiles/r03/bench_variants_call4.txt.
-#ifndef PGSGD_SNAP_STORE
-#define PGSGD_SNAP_STORE 0
-#endif
-__device__ __forceinline__ void snapshot_store(uint4* p, uint4 v) {
-#if PGSGD_SNAP_STORE == 1
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-#elif PGSGD_SNAP_STORE == 2
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p));
-#else
-    *p = v;
-#endif
-}
-
 // Waves per SIMD the register allocation aims at (a workgroup is one wave per SIMD, so this is also the workgroups per
 // CU): the kernel hides its LDS round trips and its gathers behind other waves.
 #ifndef PGSGD_TILE_WAVES
@@ -749,7 +729,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         const uint64_t w1 = LOCAL ? win[(e0 ^ 1u) - wbase] : load_word<COORD_LOAD>(c.coords, e0 ^ 1u);
                         v = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                     }
-                    snapshot_store(dst + piece, v);
+                    dst[piece] = v;  // (plain stores; write-through (sc1) and non-temporal ones measured the same: profiles/r03/bench_variants_call4.txt)
                 }
             }
         }

@@ -58,6 +58,31 @@ def test_gfa_errors_are_codes_not_exits(oa, tmp_path):
     assert list(g.path_first) == [0, 0, 1, 3] and list(g.step_handle) == [3, 0, 3] and list(g.step_pos) == [0, 0, 4]
 
 
+def test_gfa_errors_are_the_first_in_file_order_on_any_thread_count(oa, tmp_path):
+    """S lines are parsed on threads (slices of 65536+ lines each): a duplicate node id is reported for the LATER of its
+    two lines, whichever thread met it first, and the error returned is the first one in file order — so one thread and
+    eight threads give the same message."""
+    from odgi_amd._lib import PgsgdError
+    n = 300_000
+    ids = [str(i + 1) for i in range(n)]
+    ids[250_000] = "5"                      # duplicate of line 4's id, a quarter of a million lines later
+    f = tmp_path / "dup.gfa"
+    f.write_text("".join(f"S\t{i}\tA\n" for i in ids))
+    msgs = set()
+    for threads in (1, 8, 5):
+        with pytest.raises(PgsgdError) as e:
+            oa.Graph.from_gfa(f, threads=threads)
+        assert e.value.code == -6
+        msgs.add(str(e.value).split("(")[-1])
+    assert len(msgs) == 1 and "duplicate node id 5" in msgs.pop()
+    ids[120_000] = "x7"                     # an earlier error in file order wins, wherever the threads' slices fall
+    f.write_text("".join(f"S\t{i}\tA\n" for i in ids))
+    for threads in (1, 8):
+        with pytest.raises(PgsgdError) as e:
+            oa.Graph.from_gfa(f, threads=threads)
+        assert "x7" in str(e.value)
+
+
 def test_defaults_match_reference_rules(oa, graphs):
     # SURVEY 8a: C1 DRB1-3123 -> min_term_updates 350 590, eta_max 9.61e6, space 3100
     p = oa.LayoutParams.defaults(graphs("DRB1-3123"))
