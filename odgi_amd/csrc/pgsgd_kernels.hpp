@@ -505,14 +505,12 @@ struct PipeS3 {            // both ends known; their coordinate words on their w
     uint32_t end_a, end_b, flags, dither;
 };
 
-// NT terms per stage and trip.  With few lanes (the fixture graphs) a lane is alone on its SIMD and a trip lasts as long
-// as the slowest request of the trip before — the first-step gather goes out at the end of a trip and is needed at the
-// top of the next — whatever the trip computes: two terms per stage (eight in flight) put twice the work behind the same
-// wait.  The two terms of a stage are consecutive terms of the lane; the second one's coordinate words were requested
-// before the first one's atomics went out, so where they share a node end the first one's move is added to the word in
-// registers (an exact 64-bit add, like the atomic): a one-stream run still gives the sequential program's bits.
-template <bool PF_LDS, int COORD_LOAD, int UPD, int NT>
+// (Two terms per stage — eight in flight per lane — were tried for the few-lane case: the second term of a stage reads its
+// ends before the first one's atomics go out, so the window between reading an end and moving it holds two terms per
+// lane, which is twice the concurrency the stream-count rule allows: DRB1-3123, LPA and chr6.C4 diverge.  One term per stage.)
+template <bool PF_LDS, int COORD_LOAD, int UPD>
 __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c, IterArgs a) {
+    constexpr int NT = 1;  // terms per stage (see above)
     extern __shared__ uint64_t s_pf[];
     if (PF_LDS) {
         for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
@@ -553,25 +551,10 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
         for (int i = 0; i < NT; ++i)
             asm volatile("" ::"v"(p3[i].wa), "v"(p3[i].wb), "v"(p2[i].rb.x), "v"(p2[i].rb.w), "v"(p1[i].ra.x), "v"(p1[i].ra.w), "v"(p1[i].zd.x), "v"(p1[i].zd.y));
         // ---- S4: the terms of trip j - 3 (path_sgd_layout.cpp:280-363), in term order ----
-        uint64_t moved_b = 0, moved_a = 0;  // what the stage's first term wrote: deltas (atomic adds) or words (stores)
-        uint32_t moved_end_a = 0xffffffffu, moved_end_b = 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             if (!(p3[i].flags & 1u)) continue;
-            uint64_t wa = p3[i].wa, wb = p3[i].wb;
-            if (NT > 1 && i > 0) {  // the term before this one in the lane's order moved these ends after they were read
-                if (UPD == kUpdAtomic) {
-                    if (p3[i].end_a == moved_end_b) wa += moved_b;
-                    if (p3[i].end_a == moved_end_a) wa -= moved_b;
-                    if (p3[i].end_b == moved_end_b) wb += moved_b;
-                    if (p3[i].end_b == moved_end_a) wb -= moved_b;
-                } else {
-                    if (p3[i].end_a == moved_end_b) wa = moved_b;
-                    if (p3[i].end_a == moved_end_a) wa = moved_a;
-                    if (p3[i].end_b == moved_end_b) wb = moved_b;
-                    if (p3[i].end_b == moved_end_a) wb = moved_a;
-                }
-            }
+            const uint64_t wa = p3[i].wa, wb = p3[i].wb;
             const float dx0 = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;  // exact integer differences
             const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
             guard |= in_frame_guard(wa) || in_frame_guard(wb);
@@ -603,13 +586,11 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
                     const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
                     atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3[i].end_b), (unsigned long long)delta);
                     atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3[i].end_a), (unsigned long long)(0 - delta));
-                    if (NT > 1 && i == 0) { moved_b = delta; moved_end_a = p3[i].end_a; moved_end_b = p3[i].end_b; }
                 }
             } else {
                 const uint64_t nb = q32_shift(wb, qx, qy), na = q32_shift(wa, -qx, -qy);
                 __hip_atomic_store(c.coords + p3[i].end_b, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(c.coords + p3[i].end_a, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (NT > 1 && i == 0) { moved_b = nb; moved_a = na; moved_end_a = p3[i].end_a; moved_end_b = p3[i].end_b; }
             }
         }
         // ---- S3: the terms of trip j - 2: the partners' records are here (:242-269), the coordinate words go out ----

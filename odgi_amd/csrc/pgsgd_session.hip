@@ -42,7 +42,6 @@ struct pgsgd_session {
     int fmt = pgsgd::kFmtQ32;
     int upd = pgsgd::kUpdAtomic;
     bool pf_lds = false;
-    bool pipe_pairs = false;              // per-lane kernel: two terms per pipeline stage (few lanes: the lanes' own latency is the run time)
     size_t lds_bytes = 0;
     // device buffers
     uint4* d_recs = nullptr;
@@ -230,23 +229,22 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
     return upd == kUpdStore ? select_kernel_fu<kFmtF32, kUpdStore>(pf_lds, plain, grouped, abl) : select_kernel_fu<kFmtF32, kUpdAtomic>(pf_lds, plain, grouped, abl);
 }
 
-// the software-pipelined instance of the default configuration (pgsgd_kernels.hpp: sgd_iteration_kernel_piped), NT terms per stage
-template <int NT>
+// the software-pipelined instance of the default configuration (pgsgd_kernels.hpp: sgd_iteration_kernel_piped)
 static iter_kernel_t select_piped(bool pf_lds, bool plain, int upd) {
     using namespace pgsgd;
     if (upd == kUpdStore) {
-        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore, NT> : sgd_iteration_kernel_piped<true, 1, kUpdStore, NT>;
-        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore, NT> : sgd_iteration_kernel_piped<false, 1, kUpdStore, NT>;
+        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore> : sgd_iteration_kernel_piped<true, 1, kUpdStore>;
+        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore> : sgd_iteration_kernel_piped<false, 1, kUpdStore>;
     }
-    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic, NT> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic, NT>;
-    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic, NT> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic, NT>;
+    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic>;
+    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic>;
 }
 // which per-lane kernel a session launches: the pipelined one for fixed-point coordinates, one term per first step,
 // fewer than 2^32 path steps and no hot-node cap; the general one otherwise
 static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t abl) {
     const bool grouped = s->params.terms_per_anchor > 1;
     if (s->fmt == pgsgd::kFmtQ32 && !grouped && !abl && s->n_steps < 0xffffffffull && !(s->params.flags & (PGSGD_FLAG_HOT_NODE_CAP | PGSGD_FLAG_NO_PIPELINE)))
-        return s->pipe_pairs ? select_piped<2>(s->pf_lds, plain, s->upd) : select_piped<1>(s->pf_lds, plain, s->upd);
+        return select_piped(s->pf_lds, plain, s->upd);
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
@@ -572,8 +570,6 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = (p->flags & PGSGD_FLAG_HOT_NODE_CAP) ? capped_streams(s, prop.multiProcessorCount, bpc, p->min_term_updates)
                                                             : auto_streams(s, prop.multiProcessorCount, bpc);
     }
-    // at most two waves per SIMD: the lanes' own latency is the run time — two terms per pipeline stage (sgd_iteration_kernel_piped)
-    s->pipe_pairs = (uint64_t)s->n_streams <= (uint64_t)prop.multiProcessorCount * 4 * 64 * 2;
 
     // region-exclusive tiles: with the default coordinate format, update mode and term stream, an
     // automatic stream count, and a graph that is big enough and whose hottest node does not ask for
