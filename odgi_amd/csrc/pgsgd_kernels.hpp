@@ -505,12 +505,13 @@ struct PipeS3 {            // both ends known; their coordinate words on their w
     uint32_t end_a, end_b, flags, dither;
 };
 
-// (Two terms per stage — eight in flight per lane — were tried for the few-lane case: the second term of a stage reads its
-// ends before the first one's atomics go out, so the window between reading an end and moving it holds two terms per
-// lane, which is twice the concurrency the stream-count rule allows: DRB1-3123, LPA and chr6.C4 diverge.  One term per stage.)
+// Tried and dropped (profiles/r03/per_lane_plain_vs_piped*.jsonl): two terms per stage — the second term of a stage reads
+// its ends before the first one's atomics go out, so the window between reading an end and moving it holds two terms
+// per lane, twice the concurrency the stream-count rule allows: DRB1-3123, LPA and chr6.C4 diverge; and issuing every
+// load of the loop on every path (an empty slot asking for entry 0), which spares the compiler its waits inside the
+// stages' branches but measured 10-20 % slower on three of the four fixture graphs than the loop below.
 template <bool PF_LDS, int COORD_LOAD, int UPD>
 __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c, IterArgs a) {
-    constexpr int NT = 1;  // terms per stage (see above)
     extern __shared__ uint64_t s_pf[];
     if (PF_LDS) {
         for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
@@ -528,38 +529,30 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
     float dmax = 0.0f;
     bool guard = false;
     const uint64_t n_mine = a.n_terms > g ? (a.n_terms - g + L - 1) / L : 0;  // terms g, g + L, ... of the iteration
-    const uint64_t n_trips = (n_mine + NT - 1) / NT + 3;
+    PipeS1 p1;
+    PipeS2 p2;
+    PipeS3 p3;
+    p1.flags = p2.flags = p3.flags = 0;
     // (the generator state has to be here before the loop: the compiler would otherwise wait for it at its first use
     // inside the loop — a counted wait that, executed every trip, also waits for the loads the trip has just issued)
     asm volatile("" ::"v"(rng.s0), "v"(rng.s1), "v"(rng.s2), "v"(rng.s3));
-    PipeS1 p1[NT];
-    PipeS2 p2[NT];
-    PipeS3 p3[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        p1[i].flags = p2[i].flags = p3[i].flags = 0;
-        p1[i].ra = make_uint4(0, 0, 0, 0);
-        p1[i].zd = make_double2(0.0, 0.0);
-        p2[i].rb = make_uint4(0, 0, 0, 0);
-        p3[i].wa = p3[i].wb = 0;
-    }
-    for (uint64_t j = 0; j < n_trips; ++j) {
+    p1.ra = make_uint4(0, 0, 0, 0);
+    p1.zd = make_double2(0.0, 0.0);
+    p2.rb = make_uint4(0, 0, 0, 0);
+    p3.wa = p3.wb = 0;
+    for (uint64_t j = 0; j < n_mine + 3; ++j) {
         // The trip's one wait.  Everything the last trip requested is used here, by every lane, before this trip's atomics
         // go out: with a use only inside the stages' branches the compiler has to wait again after the atomics (a branch
         // may have been skipped), and that wait — loads and atomics share a counter — would be for the atomics' round trip.
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-            asm volatile("" ::"v"(p3[i].wa), "v"(p3[i].wb), "v"(p2[i].rb.x), "v"(p2[i].rb.w), "v"(p1[i].ra.x), "v"(p1[i].ra.w), "v"(p1[i].zd.x), "v"(p1[i].zd.y));
-        // ---- S4: the terms of trip j - 3 (path_sgd_layout.cpp:280-363), in term order ----
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (!(p3[i].flags & 1u)) continue;
-            const uint64_t wa = p3[i].wa, wb = p3[i].wb;
+        asm volatile("" ::"v"(p3.wa), "v"(p3.wb), "v"(p2.rb.x), "v"(p2.rb.w), "v"(p1.ra.x), "v"(p1.ra.w), "v"(p1.zd.x), "v"(p1.zd.y));
+        // ---- S4: term j - 3 (path_sgd_layout.cpp:280-363) ----
+        if (p3.flags & 1u) {
+            const uint64_t wa = p3.wa, wb = p3.wb;
             const float dx0 = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;  // exact integer differences
             const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
             guard |= in_frame_guard(wa) || in_frame_guard(wb);
             // term_displacement() with the distance already converted: the same operations
-            float d = p3[i].d;
+            float d = p3.d;
             if (d == 0.0f) d = 1e-9f;
             const float w = 1.0f / d;
             float mu = a.eta * w;
@@ -573,98 +566,87 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
             dmax = fmaxf(dmax, fabsf(Delta));
             const float r = Delta / mag;
             const float r_x = r * dx, r_y = r * dy;
-            if (UPD == kUpdStore && p3[i].end_a == p3[i].end_b) continue;  // (Hogwild stores: the reference's two load/store pairs cancel)
-            const float ux = (float)(p3[i].dither & 0xffffu) * (1.0f / 65536.0f);
-            const float uy = (float)(p3[i].dither >> 16) * (1.0f / 65536.0f);
-            float fx = r_x * c.xf.scale;
-            float fy = r_y * c.xf.scale;
-            fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
-            fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
-            const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
-            if (UPD == kUpdAtomic) {
-                if ((qx | qy) != 0) {  // a step that rounds to no quantum adds zero: nothing to send
-                    const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3[i].end_b), (unsigned long long)delta);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3[i].end_a), (unsigned long long)(0 - delta));
+            if (!(UPD == kUpdStore && p3.end_a == p3.end_b)) {  // (Hogwild stores: the reference's two load/store pairs cancel)
+                const float ux = (float)(p3.dither & 0xffffu) * (1.0f / 65536.0f);
+                const float uy = (float)(p3.dither >> 16) * (1.0f / 65536.0f);
+                float fx = r_x * c.xf.scale;
+                float fy = r_y * c.xf.scale;
+                fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+                fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+                const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+                if (UPD == kUpdAtomic) {
+                    if ((qx | qy) != 0) {  // a step that rounds to no quantum adds zero: nothing to send
+                        const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_b), (unsigned long long)delta);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_a), (unsigned long long)(0 - delta));
+                    }
+                } else {
+                    __hip_atomic_store(c.coords + p3.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(c.coords + p3.end_a, q32_shift(wa, -qx, -qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else {
-                const uint64_t nb = q32_shift(wb, qx, qy), na = q32_shift(wa, -qx, -qy);
-                __hip_atomic_store(c.coords + p3[i].end_b, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(c.coords + p3[i].end_a, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        // ---- S3: the terms of trip j - 2: the partners' records are here (:242-269), the coordinate words go out ----
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            // (Every request of the loop goes out on every path — an empty slot asks for entry 0 —: a register that is
-            // loaded on one path and kept on the other is merged by a COPY, and a copy of a register in flight waits
-            // for the load right where it was issued.)
-            p3[i].flags = p2[i].flags;
-            const bool on = p2[i].flags & 1u;
-            const uint4 rb = p2[i].rb;
+        // ---- S3: term j - 2: the partner's record is here (:242-269), the coordinate words go out ----
+        p3.flags = p2.flags;
+        if (p2.flags & 1u) {
+            const uint4 rb = p2.rb;
             uint64_t pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
             uint32_t off_b = rb.x & 1u;
-            if (p2[i].flags & 16u) { pos_b += rb.y; off_b ^= 1u; }
-            p3[i].end_a = on ? p2[i].end_a : 0u;
-            p3[i].end_b = on ? ((rb.x & ~1u) | off_b) : 0u;
-            p3[i].dither = p2[i].dither;
-            const int64_t diff = (int64_t)p2[i].pos_a - (int64_t)pos_b;
-            p3[i].d = (float)(uint64_t)(diff < 0 ? -diff : diff);
-            p3[i].wa = load_word<COORD_LOAD>(c.coords, p3[i].end_a);
-            p3[i].wb = load_word<COORD_LOAD>(c.coords, p3[i].end_b);
+            if (p2.flags & 16u) { pos_b += rb.y; off_b ^= 1u; }
+            p3.end_a = p2.end_a;
+            p3.end_b = (rb.x & ~1u) | off_b;
+            p3.dither = p2.dither;
+            const int64_t diff = (int64_t)p2.pos_a - (int64_t)pos_b;
+            p3.d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+            p3.wa = load_word<COORD_LOAD>(c.coords, p3.end_a);
+            p3.wb = load_word<COORD_LOAD>(c.coords, p3.end_b);
         }
-        // ---- S2: the terms of trip j - 1: zeta entries and first records are here; the partners (:207-237), their records go out ----
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            p2[i].flags = p1[i].flags;
-            uint32_t b_rank = p1[i].aux;
-            if ((p1[i].flags & 3u) == 3u) {
-                const uint32_t z = (uint32_t)zipf_tabled_u(p1[i].u, c.zc, p1[i].aux, p1[i].zd.x, p1[i].zd.y);  // (z <= the jump length < 2^32)
-                b_rank = (p1[i].flags & 4u) ? p1[i].s_rank - z : p1[i].s_rank + z;
+        // ---- S2: term j - 1: zeta entry and first record are here; the partner (:207-237), its record goes out ----
+        p2.flags = p1.flags;
+        if (p1.flags & 1u) {
+            uint32_t b_rank = p1.aux;
+            if (p1.flags & 2u) {
+                const uint32_t z = (uint32_t)zipf_tabled_u(p1.u, c.zc, p1.aux, p1.zd.x, p1.zd.y);  // (z <= the jump length < 2^32)
+                b_rank = (p1.flags & 4u) ? p1.s_rank - z : p1.s_rank + z;
             }
-            p2[i].rb = c.recs[(p1[i].flags & 1u) ? (uint64_t)p1[i].pstart + b_rank : 0ull];
-            const uint4 ra = p1[i].ra;
+            p2.rb = c.recs[(uint64_t)p1.pstart + b_rank];
+            const uint4 ra = p1.ra;
             uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32);
             uint32_t off_a = ra.x & 1u;
-            if (p1[i].flags & 8u) { pos_a += ra.y; off_a ^= 1u; }
-            p2[i].pos_a = pos_a;
-            p2[i].end_a = (ra.x & ~1u) | off_a;
-            p2[i].dither = p1[i].dither;
+            if (p1.flags & 8u) { pos_a += ra.y; off_a ^= 1u; }
+            p2.pos_a = pos_a;
+            p2.end_a = (ra.x & ~1u) | off_a;
+            p2.dither = p1.dither;
         }
-        // ---- S1: the terms of trip j: every variate, in the reference's order; first records and zeta entries go out ----
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            uint32_t flags = 0, k = 0;
-            uint64_t zi = 0;
-            if (j * NT + i < n_mine) {
-                uint32_t pstart, cnt;
-                do {  // :182-192 — a single-step path makes the reference draw again without counting a term
-                    k = (uint32_t)uniform_below(rng, c.n_steps);
-                    const uint32_t p = find_path(pf, c.n_paths, (uint64_t)k);
-                    pstart = (uint32_t)pf[p];
-                    cnt = (uint32_t)(pf[p + 1] - pf[p]);
-                } while (cnt == 1);
-                p1[i].s_rank = k - pstart;
-                p1[i].pstart = pstart;
-                flags = 1u;
-                if (a.cooling || coin(rng)) {                                                             // :205
-                    const bool back = (p1[i].s_rank > 0 && coin(rng)) || p1[i].s_rank == cnt - 1;         // :206
-                    const uint32_t room = back ? p1[i].s_rank : cnt - p1[i].s_rank - 1;
-                    const uint32_t jump = c.space < room ? (uint32_t)c.space : room;
-                    zi = zeta_index(jump, c.space_max, c.space_quant);
-                    p1[i].u = canonical(rng);
-                    p1[i].aux = jump;
-                    flags |= 2u | (back ? 4u : 0u);
-                } else {
-                    p1[i].aux = (uint32_t)uniform_below(rng, (uint64_t)cnt);                              // :235-237
-                }
-                const uint64_t draw_a = rng.next(), draw_b = rng.next();                                  // :253, :262
-                flags |= (uint32_t)(draw_a >> 63) << 3 | (uint32_t)(draw_b >> 63) << 4;
-                p1[i].dither = (uint32_t)draw_a;
+        // ---- S1: term j: every variate, in the reference's order; first record and zeta entry go out ----
+        p1.flags = 0;
+        if (j < n_mine) {
+            uint32_t k, pstart, cnt;
+            do {  // :182-192 — a single-step path makes the reference draw again without counting a term
+                k = (uint32_t)uniform_below(rng, c.n_steps);
+                const uint32_t p = find_path(pf, c.n_paths, (uint64_t)k);
+                pstart = (uint32_t)pf[p];
+                cnt = (uint32_t)(pf[p + 1] - pf[p]);
+            } while (cnt == 1);
+            p1.ra = c.recs[k];
+            p1.s_rank = k - pstart;
+            p1.pstart = pstart;
+            uint32_t flags = 1u;
+            if (a.cooling || coin(rng)) {                                                       // :205
+                const bool back = (p1.s_rank > 0 && coin(rng)) || p1.s_rank == cnt - 1;         // :206
+                const uint32_t room = back ? p1.s_rank : cnt - p1.s_rank - 1;
+                const uint32_t jump = c.space < room ? (uint32_t)c.space : room;
+                p1.zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
+                p1.u = canonical(rng);
+                p1.aux = jump;
+                flags |= 2u | (back ? 4u : 0u);
+            } else {
+                p1.aux = (uint32_t)uniform_below(rng, (uint64_t)cnt);                           // :235-237
             }
-            p1[i].flags = flags;
-            p1[i].ra = c.recs[k];
-            p1[i].zd = c.zeta_denom[zi];
+            const uint64_t draw_a = rng.next(), draw_b = rng.next();                            // :253, :262
+            flags |= (uint32_t)(draw_a >> 63) << 3 | (uint32_t)(draw_b >> 63) << 4;
+            p1.dither = (uint32_t)draw_a;
+            p1.flags = flags;
         }
     }
     c.rng[g] = rng.s0;
