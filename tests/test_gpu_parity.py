@@ -650,7 +650,7 @@ def test_tiled_kernel_matches_per_lane_kernel_and_oracle(oa, orc):
     kernel and the CPU oracle on a 300k-node synthetic pangenome, 3*S terms per iteration, three
     seeds each (single runs of either kernel scatter by ~10 %, with rare outliers): same term
     accounting, conserved coordinate sums, mean sampled stress within 15 % of the per-lane
-    kernel's and both within 25 % (+0.02) of the oracle's Hogwild run."""
+    kernel's and both within 15 % of the oracle's Hogwild run."""
     from odgi_amd import _lib
     g = oa.Graph.synthetic(300_000, 24, seed=7)
     og = orc.Graph.from_product(g)
@@ -674,8 +674,9 @@ def test_tiled_kernel_matches_per_lane_kernel_and_oracle(oa, orc):
     s_cpu = orc.path_stress_sampled(og, Xo, Yo, 1_000_000)
     m_t, m_p = float(np.mean(res["tiled"])), float(np.mean(res["per_lane"]))
     print(f"synthetic 300k: stress tiled {res['tiled']} per-lane {res['per_lane']} cpu oracle {s_cpu:.4f}")
-    assert m_t <= 1.15 * m_p + 0.01
-    assert m_t <= 1.25 * s_cpu + 0.02 and m_p <= 1.25 * s_cpu + 0.02
+    # measured (round 3, profiles/r03/pytest_gpu_r03_call6.log): tiled 0.162, per-lane 0.151, CPU restatement 0.159
+    assert m_t <= 1.15 * m_p
+    assert m_t <= 1.15 * s_cpu and m_p <= 1.15 * s_cpu
 
 
 def test_tiled_kernel_terms_bit_exact_and_tile_table(oa, orc):
@@ -763,7 +764,7 @@ def test_outbox_overflow_falls_back_to_direct_atomics(oa, monkeypatch):
         assert _words_conserved(w0, w1) and np.isfinite(X).all() and np.isfinite(Y).all()
         res[name] = oa.path_stress(g, X, Y, 1_000_000, seed=1)
     print(f"outbox overflow: stress full pool {res['full']:.4f}, 2 % pool {res['tiny']:.4f}")
-    assert res["tiny"] <= 1.15 * res["full"] + 0.01
+    assert res["tiny"] <= 1.10 * res["full"]   # measured 0.1603 against 0.1604
 
 
 def test_small_and_hub_graphs_run_the_per_lane_kernel(oa, graphs):
@@ -811,7 +812,7 @@ def test_tiled_kernel_with_tandem_repeats(oa):
     print(f"tandem repeats: tiled={info['tiled']} stress tiled {res['tiled']} per-lane {res['per_lane']}")
     assert info["tiled"]
     # single runs of either kernel scatter by ~10 % on this graph (round 1: 0.13 .. 0.16): means within 15 %
-    assert float(np.mean(res["tiled"])) <= 1.15 * float(np.mean(res["per_lane"])) + 0.01
+    assert float(np.mean(res["tiled"])) <= 1.10 * float(np.mean(res["per_lane"]))   # measured 0.144 against 0.186
 
 
 @pytest.mark.parametrize("init", ["d", "g"])
@@ -819,7 +820,7 @@ def test_tile_sharded_virtual_ranks(oa, init):
     """Multi-GPU path of the tile kernel on one GPU: two sessions play ranks 0 and 1 (tiles rank, rank+2, ...
     of every work item, each with its whole share of the iteration's terms), merged after every iteration
     by the exchange kernels, the all-reduce replaced by a sum on the device.  Both ranks must end with the
-    same coordinates, and the stress must stay within 25 % (+0.02) of the one-rank run's.  With the Gaussian
+    same coordinates, and the mean stress of three runs must stay within 20 % of the one-rank runs (measured +4 %).  With the Gaussian
     initial layout the iterations before cooling run the per-lane kernel, each rank with its half of the terms."""
     import torch
     from odgi_amd.distributed import HipEngine
@@ -946,7 +947,7 @@ def test_cpp_multi_gpu_run_with_two_virtual_devices(oa, graphs, graph_name, monk
             assert np.isfinite(X).all() and np.isfinite(Y).all()
             res[G].append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
     print(f"C++ multi-GPU driver, {graph_name}: stress one device {res[1]}, two virtual devices {res[2]}")
-    assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1])) + 0.01
+    assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))   # measured +4.6 % (synthetic), -6 % (LPA)
 
 
 def test_cpp_multi_gpu_run_writes_snapshots(oa, graphs, tmp_path, monkeypatch):
@@ -1198,9 +1199,10 @@ def test_kernel_plan_follows_graph_order_and_initial_layout(oa):
     print(f"kernel plan: random numbering {s_random}; init g {res['g', 'default']} vs {res['g', 'per_lane']}; "
           f"init d {res['d', 'default']} vs {res['d', 'per_lane']}")
     # single runs scatter by ~10 % (round 1); means of three within 15 %
-    assert float(np.mean(s_random)) <= 1.15 * m["d", "per_lane"] + 0.01
-    assert m["g", "default"] <= 1.15 * m["g", "per_lane"] + 0.01
-    assert m["d", "default"] <= 1.15 * m["d", "per_lane"] + 0.01
+    # measured: 0.1206 / 0.1208 / 0.1204 against 0.1205 / 0.1206 / 0.1205
+    assert float(np.mean(s_random)) <= 1.10 * m["d", "per_lane"]
+    assert m["g", "default"] <= 1.10 * m["g", "per_lane"]
+    assert m["d", "default"] <= 1.10 * m["d", "per_lane"]
 
 
 def test_double_precision_download_is_exact(oa, graphs):
