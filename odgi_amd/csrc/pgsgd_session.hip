@@ -42,6 +42,7 @@ struct pgsgd_session {
     int fmt = pgsgd::kFmtQ32;
     int upd = pgsgd::kUpdAtomic;
     bool pf_lds = false;
+    bool pipe_ret = false;                // PGSGD_PIPE_RET (experiment knob): the pipelined per-lane kernel with returning atomics
     size_t lds_bytes = 0;
     // device buffers
     uint4* d_recs = nullptr;
@@ -230,21 +231,22 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
 }
 
 // the software-pipelined instance of the default configuration (pgsgd_kernels.hpp: sgd_iteration_kernel_piped)
+template <bool RET>
 static iter_kernel_t select_piped(bool pf_lds, bool plain, int upd) {
     using namespace pgsgd;
     if (upd == kUpdStore) {
-        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore> : sgd_iteration_kernel_piped<true, 1, kUpdStore>;
-        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore> : sgd_iteration_kernel_piped<false, 1, kUpdStore>;
+        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore, RET> : sgd_iteration_kernel_piped<true, 1, kUpdStore, RET>;
+        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore, RET> : sgd_iteration_kernel_piped<false, 1, kUpdStore, RET>;
     }
-    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic>;
-    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic>;
+    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic, RET> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic, RET>;
+    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic, RET> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic, RET>;
 }
 // which per-lane kernel a session launches: the pipelined one for fixed-point coordinates, one term per first step,
 // fewer than 2^32 path steps and no hot-node cap; the general one otherwise
 static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t abl) {
     const bool grouped = s->params.terms_per_anchor > 1;
     if (s->fmt == pgsgd::kFmtQ32 && !grouped && !abl && s->n_steps < 0xffffffffull && !(s->params.flags & (PGSGD_FLAG_HOT_NODE_CAP | PGSGD_FLAG_NO_PIPELINE)))
-        return select_piped(s->pf_lds, plain, s->upd);
+        return s->pipe_ret ? select_piped<true>(s->pf_lds, plain, s->upd) : select_piped<false>(s->pf_lds, plain, s->upd);
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
@@ -557,6 +559,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     S_TRY(hipGetDeviceProperties(&prop, dev));
 
     s->pf_lds = (g->n_paths + 1) <= pgsgd::kPathLdsCap;
+    s->pipe_ret = pgsgd::debug_env("PGSGD_PIPE_RET") != nullptr;
     s->lds_bytes = s->pf_lds ? (size_t)(g->n_paths + 1) * sizeof(uint64_t) : 0;
 
     // stream count
@@ -617,7 +620,13 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 const uint64_t last = g->path_first[q + 1] - 1;
                 short_paths = g->step_pos[last] + g->node_len[g->step_handle[last] >> 1] < (1ull << 52);
             }
-        if ((force || cap >= 4 * cu_lanes) && short_paths && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
+        // A schedule of fewer than 15 iterations runs the per-lane kernel.  The tile kernel gives long-range pairs gentle,
+        // averaged pulls while the learning rate is above their distance and needs the schedule's length to bring them
+        // home: final sampled stress at config 4, tile kernel / per-lane kernel (the reference's rule), for -x 3 / 5 /
+        // 8 / 10 / 12 / 15 / 20 / 30: 1374 / 17, 1.07 / 0.31, 0.40 / 0.186, 0.32 / 0.22, 0.265 / 0.225, 0.240 / 0.2285,
+        // 0.234 / 0.228, 0.238 / 0.245 (profiles/r03/short_schedules_tile_vs_per_lane.jsonl).
+        const bool long_schedule = p->iter_max >= 15;
+        if ((force || (cap >= 4 * cu_lanes && long_schedule)) && short_paths && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
             std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);

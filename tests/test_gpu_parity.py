@@ -456,6 +456,7 @@ def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
     out = []
     with oa.LayoutSession(g, p) as s:
         s.upload(X0, Y0)
+        w0 = s.download_words()
         for it in range(p.iter_max):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             s.sync()
@@ -464,6 +465,11 @@ def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
                 assert np.isfinite(X).all() and np.isfinite(Y).all()
                 out.append(orc.path_stress_sampled(og, X, Y, pairs, eval_seed))
         assert s.outbox_overflow() == 0
+        # 1.4e10 terms later (the tile kernel's LDS atomics, plain window stores, messages and drains; the per-lane kernel's
+        # global atomics): the sums of the Xq and the Yq fields are what they were — every term moved two ends by -/+ the same step
+        w1 = s.download_words()
+        _FRAME_DOUBLINGS[0] = s.frame_status()[1]
+        assert _words_conserved(w0, w1)
     return out
 
 
@@ -556,44 +562,30 @@ def _config5_graph(oa):
 def test_config5_size_properties(oa, tmp_path):
     """BASELINE config 5 size (1e7 nodes, ~4.7e8 path steps), three iterations with a snapshot each: exact term
     accounting, coordinate checksums conserved over 1.4e10 concurrent updates, finite coordinates, snapshots readable,
-    and the layout after these three iterations against the per-lane kernel's (the reference's rule term by term) after
-    the same three: the reference itself makes the `-N d` layout worse in its first iterations (full projections of
-    every sampled pair, section 4a of DESIGN.md); the tile kernel's excursion must stay within 5x of the initial layout's stress."""
-    from odgi_amd import _lib
+    a better layout than it started from.  A schedule this short runs the per-lane kernel (fewer than 15 iterations: the
+    tile kernel's gentle treatment of long-range pairs needs the schedule's length — at this size and `-x 3` it left the
+    layout at 2.3x its initial stress where the per-lane kernel reaches 0.005x; pgsgd_session.hip); the
+    tile kernel at this size is the next test's."""
     g, (X0, Y0) = _config5_graph(oa)
     assert g.n_nodes == 10_000_000 and 4.4e8 < g.n_steps < 5.2e8
     p = _params(oa, g, iter_max=3)
     etas = oa.path_linear_sgd_layout_schedule(p)
     with oa.LayoutSession(g, p) as s:
-        assert s.tile_info()["tiled"]
+        assert not s.tile_info()["tiled"]
         s.upload(X0, Y0)
         w0 = s.download_words()
         for it in range(p.iter_max):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             assert s.sync() > 0
-        Xs, Ys = s.download_f64(flush=False)     # what a snapshot after iteration 3 sees
-        w1 = s.download_words()                  # (flushed: every term's two sides applied)
+        w1 = s.download_words()
         X, Y = s.download_f64()
         ms, launches = s.kernel_time()
         _FRAME_DOUBLINGS[0] = s.frame_status()[1]
-        assert s.outbox_overflow() == 0
     assert _words_conserved(w0, w1) and np.count_nonzero(w0 != w1) > 19_000_000
     assert np.isfinite(X).all() and np.isfinite(Y).all()
-    pl = _params(oa, g, iter_max=3, flags=_lib.FLAG_NO_TILES)
-    with oa.LayoutSession(g, pl) as s:
-        s.upload(X0, Y0)
-        for it in range(pl.iter_max):
-            s.iteration(etas[it], False, pl.min_term_updates)
-            s.sync()
-        Xl, Yl = s.download_f64()
-    s0, s1, s1f, sl = (oa.path_stress(g, a, b, 500_000) for a, b in ((X0, Y0), (Xs, Ys), (X, Y), (Xl, Yl)))
-    print(f"config 5 size: {3 * p.min_term_updates} terms in {ms:.0f} ms of update kernels ({launches} launches); stress {s0:.0f} -> "
-          f"{s1:.1f} as a snapshot sees it ({s1f:.1f} flushed); per-lane kernel (reference rule) {sl:.1f}")
-    # Measured (round 3): 39071 -> 89596 (2.3x the initial layout; round 2: 1.04e6), the per-lane kernel 211.  A schedule
-    # this short (`-x 3`: full projections, then one iteration at a learning rate of 1e6, then eps) ends inside the tile
-    # kernel's gentle start, where the reference's rule is far ahead: stated in INTEGRATION.md; asserted: the excursion is
-    # bounded by 5x the initial layout's stress.
-    assert np.isfinite(s1) and s1 <= 5.0 * s0
+    s0, s1 = oa.path_stress(g, X0, Y0, 500_000), oa.path_stress(g, X, Y, 500_000)
+    print(f"config 5 size: {3 * p.min_term_updates} terms in {ms:.0f} ms of update kernels ({launches} launches); stress {s0:.0f} -> {s1:.1f}")
+    assert s1 < 0.05 * s0        # measured 39071 -> 211
     # one-call form with snapshots: <prefix>1, <prefix>2 readable and of full size (path_sgd_layout.cpp:379-408)
     import dataclasses
     X, Y = X0.copy(), Y0.copy()
@@ -618,6 +610,7 @@ def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
         with oa.LayoutSession(g, p) as s:
             s.upload(X0, Y0)
             assert s.tile_info()["tiled"] == (name == "tile")
+            w0 = s.download_words()
             for it in range(p.iter_max):
                 s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
                 s.sync()
@@ -627,6 +620,9 @@ def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
                     out.append(oa.path_stress(g, X, Y, 2_000_000, seed=1))
             ms[name] = s.kernel_time()[0] + sum(s.aux_time())
             assert s.outbox_overflow() == 0
+            w1 = s.download_words()    # 1.4e11 terms later: coordinate checksums conserved, every node end moved
+            _FRAME_DOUBLINGS[0] = s.frame_status()[1]
+            assert _words_conserved(w0, w1) and np.count_nonzero(w0 != w1) > 19_000_000
         curves[name] = out
     print(f"config 5 size, whole schedule: stress after iterations 10/20/30 tile {curves['tile']} ({ms['tile']:.0f} ms of kernels), "
           f"per-lane {curves['per_lane']} ({ms['per_lane']:.0f} ms)")
@@ -743,7 +739,7 @@ def test_outbox_overflow_falls_back_to_direct_atomics(oa, monkeypatch):
     direct atomic adds.  Coordinate sums conserved exactly, layout as good as with the full pool."""
     g = oa.Graph.synthetic(300_000, 24, seed=7)
     X0, Y0 = oa.initial_layout(g, "d", seed=7)
-    p = _params(oa, g, min_term_updates=3 * g.n_steps, iter_max=12)
+    p = _params(oa, g, min_term_updates=3 * g.n_steps, iter_max=15)   # (shorter schedules run the per-lane kernel)
     res = {}
     etas = oa.path_linear_sgd_layout_schedule(p)
     for name, frac in (("full", None), ("tiny", "0.02")):
@@ -957,12 +953,13 @@ def test_cpp_multi_gpu_run_writes_snapshots(oa, graphs, tmp_path, monkeypatch):
     for name, g, kw in (("tiled", oa.Graph.synthetic(100_000, 12, seed=3), dict(min_term_updates=200_000)), ("lanes", graphs("DRB1-3123"), {})):
         X, Y = oa.initial_layout(g, "d", seed=4)
         pre = str(tmp_path / f"{name}_")
-        p = _params(oa, g, n_devices=2, iter_max=5, snapshot_prefix=pre, **kw)
+        n_it = 16 if name == "tiled" else 5   # (a schedule of fewer than 15 iterations runs the per-lane kernel)
+        p = _params(oa, g, n_devices=2, iter_max=n_it, snapshot_prefix=pre, **kw)
         st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
-        assert st["iterations"] == 5
-        files = sorted(f for f in os.listdir(tmp_path) if f.startswith(name))
-        assert files == [f"{name}_{k}" for k in (1, 2, 3, 4)], files
-        lay = oa.Layout.load(pre + "4")
+        assert st["iterations"] == n_it
+        files = sorted((f for f in os.listdir(tmp_path) if f.startswith(name)), key=lambda f: int(f.split("_")[-1]))
+        assert files == [f"{name}_{k}" for k in range(1, n_it)], files
+        lay = oa.Layout.load(pre + str(n_it - 1))
         assert lay.size() == 2 * g.n_nodes and np.isfinite(lay.X).all() and np.isfinite(lay.Y).all()
         # the last snapshot is one (small-eta) iteration away from the result
         assert np.abs(lay.X - X).max() < 0.25 * (X.max() - X.min())
