@@ -509,12 +509,10 @@ struct PipeS3 {            // both ends known; their coordinate words on their w
 // its ends before the first one's atomics go out, so the window between reading an end and moving it holds two terms
 // per lane, twice the concurrency the stream-count rule allows: DRB1-3123, LPA and chr6.C4 diverge; and issuing every
 // load of the loop on every path (an empty slot asking for entry 0), which spares the compiler its waits inside the
-// stages' branches but measured 10-20 % slower on three of the four fixture graphs than the loop below.
-// RET (experiment, PGSGD_PIPE_RET): the atomics RETURN the old word (checked against the frame guard, otherwise unused).
-// Returning atomics come back in order with the loads, so everything in flight is of one kind and the compiler can wait
-// for exactly the request a stage needs (counted waits) instead of for everything the last trip issued; the forced wait
-// at the top of the trip is then left out.
-template <bool PF_LDS, int COORD_LOAD, int UPD, bool RET = false>
+// stages' branches but measured 10-20 % slower on three of the four fixture graphs than the loop below; and that variant
+// with RETURNING atomics (which come back in order with the loads, so the compiler can wait for exactly the request a
+// stage needs instead of for everything): the empty slots' atomics all add zero to word 0 — 1.4-3x slower.
+template <bool PF_LDS, int COORD_LOAD, int UPD>
 __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c, IterArgs a) {
     extern __shared__ uint64_t s_pf[];
     if (PF_LDS) {
@@ -540,7 +538,6 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
     // (the generator state has to be here before the loop: the compiler would otherwise wait for it at its first use
     // inside the loop — a counted wait that, executed every trip, also waits for the loads the trip has just issued)
     asm volatile("" ::"v"(rng.s0), "v"(rng.s1), "v"(rng.s2), "v"(rng.s3));
-    uint64_t ret_a = 0x8000000080000000ull, ret_b = 0x8000000080000000ull;  // (mid-frame: no guard hit)
     p1.ra = make_uint4(0, 0, 0, 0);
     p1.zd = make_double2(0.0, 0.0);
     p2.rb = make_uint4(0, 0, 0, 0);
@@ -549,10 +546,7 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
         // The trip's one wait.  Everything the last trip requested is used here, by every lane, before this trip's atomics
         // go out: with a use only inside the stages' branches the compiler has to wait again after the atomics (a branch
         // may have been skipped), and that wait — loads and atomics share a counter — would be for the atomics' round trip.
-        if (!RET) asm volatile("" ::"v"(p3.wa), "v"(p3.wb), "v"(p2.rb.x), "v"(p2.rb.w), "v"(p1.ra.x), "v"(p1.ra.w), "v"(p1.zd.x), "v"(p1.zd.y));
-        if (RET) {  // the words the last trip's atomics found: a trip old by now
-            guard |= in_frame_guard(ret_b) || in_frame_guard(ret_a);
-        }
+        asm volatile("" ::"v"(p3.wa), "v"(p3.wb), "v"(p2.rb.x), "v"(p2.rb.w), "v"(p1.ra.x), "v"(p1.ra.w), "v"(p1.zd.x), "v"(p1.zd.y));
         // ---- S4: term j - 3 (path_sgd_layout.cpp:280-363) ----
         if (p3.flags & 1u) {
             const uint64_t wa = p3.wa, wb = p3.wb;
@@ -585,15 +579,8 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
                 if (UPD == kUpdAtomic) {
                     if ((qx | qy) != 0) {  // a step that rounds to no quantum adds zero: nothing to send
                         const uint64_t delta = (uint64_t)qx + ((uint64_t)qy << 32);
-                        if (RET) {
-                            const uint64_t ob = atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_b), (unsigned long long)delta);
-                            const uint64_t oa = atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_a), (unsigned long long)(0 - delta));
-                            ret_b = ob;
-                            ret_a = oa;
-                        } else {
-                            atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_b), (unsigned long long)delta);
-                            atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_a), (unsigned long long)(0 - delta));
-                        }
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_b), (unsigned long long)delta);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(c.coords + p3.end_a), (unsigned long long)(0 - delta));
                     }
                 } else {
                     __hip_atomic_store(c.coords + p3.end_b, q32_shift(wb, qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

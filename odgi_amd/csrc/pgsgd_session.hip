@@ -42,7 +42,6 @@ struct pgsgd_session {
     int fmt = pgsgd::kFmtQ32;
     int upd = pgsgd::kUpdAtomic;
     bool pf_lds = false;
-    bool pipe_ret = false;                // PGSGD_PIPE_RET (experiment knob): the pipelined per-lane kernel with returning atomics
     size_t lds_bytes = 0;
     // device buffers
     uint4* d_recs = nullptr;
@@ -231,22 +230,21 @@ static iter_kernel_t select_kernel(bool pf_lds, bool plain, int fmt, int upd, bo
 }
 
 // the software-pipelined instance of the default configuration (pgsgd_kernels.hpp: sgd_iteration_kernel_piped)
-template <bool RET>
 static iter_kernel_t select_piped(bool pf_lds, bool plain, int upd) {
     using namespace pgsgd;
     if (upd == kUpdStore) {
-        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore, RET> : sgd_iteration_kernel_piped<true, 1, kUpdStore, RET>;
-        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore, RET> : sgd_iteration_kernel_piped<false, 1, kUpdStore, RET>;
+        if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdStore> : sgd_iteration_kernel_piped<true, 1, kUpdStore>;
+        return plain ? sgd_iteration_kernel_piped<false, 0, kUpdStore> : sgd_iteration_kernel_piped<false, 1, kUpdStore>;
     }
-    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic, RET> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic, RET>;
-    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic, RET> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic, RET>;
+    if (pf_lds) return plain ? sgd_iteration_kernel_piped<true, 0, kUpdAtomic> : sgd_iteration_kernel_piped<true, 1, kUpdAtomic>;
+    return plain ? sgd_iteration_kernel_piped<false, 0, kUpdAtomic> : sgd_iteration_kernel_piped<false, 1, kUpdAtomic>;
 }
 // which per-lane kernel a session launches: the pipelined one for fixed-point coordinates, one term per first step,
 // fewer than 2^32 path steps and no hot-node cap; the general one otherwise
 static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t abl) {
     const bool grouped = s->params.terms_per_anchor > 1;
     if (s->fmt == pgsgd::kFmtQ32 && !grouped && !abl && s->n_steps < 0xffffffffull && !(s->params.flags & (PGSGD_FLAG_HOT_NODE_CAP | PGSGD_FLAG_NO_PIPELINE)))
-        return s->pipe_ret ? select_piped<true>(s->pf_lds, plain, s->upd) : select_piped<false>(s->pf_lds, plain, s->upd);
+        return select_piped(s->pf_lds, plain, s->upd);
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
@@ -559,7 +557,6 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     S_TRY(hipGetDeviceProperties(&prop, dev));
 
     s->pf_lds = (g->n_paths + 1) <= pgsgd::kPathLdsCap;
-    s->pipe_ret = pgsgd::debug_env("PGSGD_PIPE_RET") != nullptr;
     s->lds_bytes = s->pf_lds ? (size_t)(g->n_paths + 1) * sizeof(uint64_t) : 0;
 
     // stream count
