@@ -447,7 +447,7 @@ def test_synthetic_million_node_properties(oa, orc):
 
 
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
-TILE_CURVE = {5: 9139.0, 10: 8.54, 15: 6.56}
+TILE_CURVE = {5: 9130.0, 10: 8.59, 15: 6.55}
 
 
 def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
@@ -542,9 +542,9 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
             assert 0.80 * cpu_mean[k] <= tile[k] <= band * cpu_mean[k], msg
         elif it >= 5:
             assert tile[k] <= band * cpu_mean[k], msg                    # milder transient, never worse
-            # and two-sided against the tile kernel's own committed curve (+-25 %... a factor 2: these points fall three
-            # orders of magnitude within five iterations), so that a change of the transient is at least detected
-            assert 0.5 * TILE_CURVE[it] <= tile[k] <= 2.0 * TILE_CURVE[it], msg
+            # and two-sided, +-25 %, against the tile kernel's own committed curve, so that a change of the transient is
+            # detected (five runs of this test in round 3: 9065..9165, 8.54..8.66, 6.53..6.57)
+            assert 0.75 * TILE_CURVE[it] <= tile[k] <= 1.25 * TILE_CURVE[it], msg
         else:
             assert tile[k] <= 3.0 * cpu_mean[k], msg                     # the first iteration: measured 0.85x the reference's
 
