@@ -868,6 +868,10 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     pgsgd::clear_error();
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
+    if (s->ob_pending) {  // far pulls of an earlier layout must not reach the new one (their drain also resets the counters)
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     const uint64_t n_ends = 2 * s->n_nodes;
     if (s->fmt == pgsgd::kFmtQ32) {
         const int rc = choose_xform(s, X, Y);
@@ -1094,6 +1098,10 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
 static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     const uint64_t per_call = n_terms / std::max<uint32_t>(1, n_parts * s->tile_substeps * s->tshard_world * s->shard_world) + 1;
     if (s->ob.pool && per_call <= s->ob_budget_terms) return PGSGD_OK;
+    if (s->ob_pending) {  // the pool is about to be replaced: deliver what the last launch left in it first
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->ob.pool) { (void)hipFree(s->ob.pool); s->ob.pool = nullptr; }
     if (s->ob.fill) { (void)hipFree(s->ob.fill); s->ob.fill = nullptr; }

@@ -769,6 +769,35 @@ def test_outbox_overflow_falls_back_to_direct_atomics(oa, monkeypatch):
     assert res["tiny"] <= 1.10 * res["full"]   # measured 0.1603 against 0.1604
 
 
+def test_pending_far_pulls_survive_a_larger_message_pool_and_a_new_upload(oa):
+    """A tile launch's far pulls wait in the outbox until the next launch.  An iteration call that asks for more terms
+    than the message pool was sized for replaces the pool — what waits in the old one is delivered first; a new upload of
+    coordinates must not receive pulls computed for the old ones.  Coordinate checksums tell: every term moved two ends
+    by -/+ the same step."""
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    X0, Y0 = oa.initial_layout(g, "d", seed=7)
+    p = _params(oa, g, min_term_updates=g.n_steps)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        assert s.tile_info()["tiled"]
+        s.upload(X0, Y0)
+        w0 = s.download_words()
+        s.iteration(etas[0], False, g.n_steps)
+        s.iteration(etas[1], False, 6 * g.n_steps)      # six times the terms the pool was made for: a new pool
+        s.sync()
+        w1 = s.download_words()                          # (flushes)
+        _FRAME_DOUBLINGS[0] = s.frame_status()[1]
+        assert _words_conserved(w0, w1) and s.outbox_overflow() == 0 and np.count_nonzero(w0 != w1) > 500_000
+        s.iteration(etas[2], False, g.n_steps)           # leaves pulls waiting
+        s.upload(X0, Y0)                                 # the same layout again: its words are exactly w0 ...
+        assert np.array_equal(s.download_words(flush=False), w0)
+        s.iteration(etas[3], True, g.n_steps)
+        s.sync()
+        w2 = s.download_words()
+        _FRAME_DOUBLINGS[0] = s.frame_status()[1]
+        assert _words_conserved(w0, w2)                  # ... and stay balanced: nothing of the old run leaked in
+
+
 def test_small_and_hub_graphs_run_the_per_lane_kernel(oa, graphs):
     for name in ("DRB1-3123", "LPA", "chr6.C4", "DRB1-3123_unsorted"):
         g = graphs(name)
