@@ -87,6 +87,9 @@ typedef struct pgsgd_graph_view {
 #define PGSGD_FLAG_NO_PIPELINE       0x80u /* per-lane kernel: the plain term loop (one term per lane in flight) instead of the    */
                                            /* software-pipelined one (four terms per lane in different stages); same terms, same   */
                                            /* arithmetic, A/B and parity                                                            */
+#define PGSGD_FLAG_NO_SPLIT        0x1000u /* per-lane kernel: never run an iteration in two passes (what small lane-bound graphs     */
+                                           /* run by default: every stream the GPU holds samples, one workgroup with the lanes the   */
+                                           /* busiest node allows moves the ends in LDS); same streams, same arithmetic, A/B, parity  */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -227,6 +230,10 @@ int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int
  * 0.1 — and the iterations before cooling therefore run the per-lane kernel, the cooling ones the tile kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
+/* How the session's per-lane launches run: 0 one pass (a lane samples a term and moves its ends), 1 two passes (a small
+ * lane-bound graph whose 2N coordinate words fit one compute unit's LDS: pgsgd_session_n_streams() streams sample, one
+ * workgroup of *apply_lanes lanes moves the ends in LDS). */
+int pgsgd_session_split_info(const pgsgd_session* s, uint32_t* apply_lanes);
 /* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.
  *   mark : remember the current coordinates as the exchange base (call once, after upload);
  *   begin: buf[2e..2e+1] = (dx, dy) node end e moved since the base, in bp; buf[4N+e] = dx^2+dy^2;

@@ -661,6 +661,140 @@ __global__ __launch_bounds__(kBlock) void sgd_iteration_kernel_piped(DevConst c,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small lane-bound graphs: the iteration in two passes, sampling apart from moving, the layout in one CU's LDS.
+//
+// On a graph whose busiest node bounds the lanes to a few hundred or thousand (auto_streams: every fixture graph of
+// the reference) a lane is alone on its SIMD, and what a trip of the loops above costs is not memory but the wave's
+// own instruction stream: ~700 vector instructions per term, most of them the sampler (generator steps on 32-bit
+// lanes, the path search, two fp64 divisions and the approximate pow of the Zipf draw) — 1.8 us per term and lane with
+// 128 lanes whatever the memory system does (the single-pass kernel with the whole layout in LDS measured 92 ms
+// against 98 on DRB1-3123_unsorted: profiles/r03/split_experiments.txt) — and then the round trip of two atomics to L2.
+// But only MOVING node ends is bounded by the busiest node; the sampler reads nothing a term writes.  And such a graph
+// is small: its 2N coordinate words (16 bytes per node) fit the 160 KB of LDS a gfx950 compute unit has.  So:
+//   sample_terms_kernel          every stream the GPU holds (not the lanes the graph allows) draws its terms of the
+//                                iteration — the per-lane kernel's streams, draws and arithmetic (sample_anchor /
+//                                sample_partner, the reference's order: trace_kernel describes them) — and writes each
+//                                as a 16-byte record {end a, end b, path distance, dither} at the term's index;
+//   apply_terms_resident_kernel  ONE workgroup with the lanes the graph allows stages the coordinates in LDS; lane l
+//                                takes terms l, l + L, ... in order: a coalesced 16-byte load requested four trips
+//                                ahead (nothing else comes from global memory — no store, no atomic shares the
+//                                counter — so the records are waited for one by one), two LDS loads, the
+//                                displacement, two LDS atomics; a hundred-odd instructions and a round trip of a
+//                                hundred-odd cycles per term; the coordinates go back with plain stores (the only
+//                                writer).
+// One stream and one lane are the sequential program: the same bits as the loops above (tests).  Moving the ends in
+// global memory from the term records (the same two passes for graphs beyond the LDS) was built and dropped: a trip
+// is then the round trip of the atomics plus that of the streamed records, slower than the pipelined loop above from
+// 1 500 lanes on (profiles/r03/split_experiments.txt).
+struct TermRec {  // 16 bytes
+    uint32_t end_a, end_b;  // end_a = kNoEnd: no term
+    float d;                // path distance of the two ends, (float)|pos_a - pos_b|
+    uint32_t dither;
+};
+constexpr uint32_t kNoEnd = 0xffffffffu;
+
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void sample_terms_kernel(DevConst c, uint32_t cooling, uint64_t n_terms, uint4* out) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    for (uint64_t q = g; q < n_terms; q += L) {  // terms g, g + L, ... of the call, as in sgd_iteration_kernel
+        const Anchor an = sample_anchor(c, pf, rng);
+        const Term t = sample_partner(c, an, cooling, rng, GlobalRecs{c.recs});
+        const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
+        const float d = (float)(uint64_t)(diff < 0 ? -diff : diff);
+        out[q] = make_uint4(t.end_a, t.end_b, __float_as_uint(d), t.dither);
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+}
+
+// What a term adds to its partner's coordinate word (the first end gets the negative): term_displacement() and the
+// stochastic rounding of sgd_iteration_kernel, the same operations in the same order.
+__device__ __forceinline__ uint64_t term_step_q32(const DevConst& c, float eta, uint64_t wa, uint64_t wb, float d, uint32_t dither, float& dmax) {
+    const float dx0 = (float)((int64_t)(uint32_t)wa - (int64_t)(uint32_t)wb) * c.xf.inv_scale;  // exact integer differences
+    const float dy = (float)((int64_t)(wa >> 32) - (int64_t)(wb >> 32)) * c.xf.inv_scale;
+    if (d == 0.0f) d = 1e-9f;
+    const float w = 1.0f / d;
+    float mu = eta * w;
+    if (mu > 1.0f) mu = 1.0f;
+    float dx = dx0;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    const float mag = sqrtf(dx2 + dy2);
+    const float Delta = (mu * (mag - d)) / 2.0f;
+    dmax = fmaxf(dmax, fabsf(Delta));
+    const float r = Delta / mag;
+    const float r_x = r * dx, r_y = r * dy;
+    const float ux = (float)(dither & 0xffffu) * (1.0f / 65536.0f);
+    const float uy = (float)(dither >> 16) * (1.0f / 65536.0f);
+    float fx = r_x * c.xf.scale;
+    float fy = r_y * c.xf.scale;
+    fx = fminf(fmaxf(fx + ux, -2147483520.0f), 2147483520.0f);
+    fy = fminf(fmaxf(fy + uy, -2147483520.0f), 2147483520.0f);
+    const int64_t qx = (int64_t)floorf(fx), qy = (int64_t)floorf(fy);
+    return (uint64_t)qx + ((uint64_t)qy << 32);  // 0: the step rounds to no quantum
+}
+
+// One workgroup, the 2N coordinate words in its LDS; term records requested kResidentAhead trips before they are used.
+constexpr int kResidentBlock = 1024;
+constexpr int kResidentAhead = 4;
+__global__ __launch_bounds__(kResidentBlock) void apply_terms_resident_kernel(DevConst c, IterArgs a, const uint4* terms, uint32_t lanes) {
+    extern __shared__ uint64_t s_win[];
+    const uint32_t n_ends = 2 * c.n_nodes;
+    for (uint32_t i = threadIdx.x; i < n_ends; i += blockDim.x) s_win[i] = c.coords[i];
+    __syncthreads();
+    const uint32_t l = threadIdx.x;
+    const uint64_t n_mine = l < lanes && a.n_terms > l ? (a.n_terms - l + lanes - 1) / lanes : 0;
+    float dmax = 0.0f;
+    if (n_mine) {  // (lanes differ by at most one trip: nothing in the loop is wave-cooperative)
+        uint4 t[kResidentAhead];
+#pragma unroll
+        for (int k = 0; k < kResidentAhead; ++k) t[k] = terms[l + (uint64_t)(k < (int64_t)n_mine ? k : 0) * lanes];
+        for (uint64_t j = 0; j < n_mine; j += kResidentAhead) {
+#pragma unroll
+            for (int k = 0; k < kResidentAhead; ++k) {
+                const uint4 r = t[k];
+                const uint64_t nxt = j + k + kResidentAhead;
+                t[k] = terms[l + (nxt < n_mine ? nxt : 0) * lanes];  // (every slot asks: the requests in flight are the same on every path)
+                if (j + k < n_mine) {
+                    const uint64_t wa = s_win[r.x], wb = s_win[r.y];
+                    const uint64_t delta = term_step_q32(c, a.eta, wa, wb, __uint_as_float(r.z), r.w, dmax);
+                    if (delta != 0) {
+                        atomicAdd(reinterpret_cast<unsigned long long*>(s_win + r.y), (unsigned long long)delta);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(s_win + r.x), (unsigned long long)(0 - delta));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    bool guard = false;
+    for (uint32_t i = threadIdx.x; i < n_ends; i += blockDim.x) {  // the only writer since the words were staged: plain stores
+        const uint64_t w = s_win[i];
+        c.coords[i] = w;
+        guard |= in_frame_guard(w);
+    }
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1D path-guided SGD of `odgi sort -Y` (reference src/algorithms/path_sgd.cpp:12-500): the layout's
 // sibling — same first-step/partner sampler, one coordinate per node, no end choice.  Differences:
 // the Zipf draw uses adj_theta = 0.001 once cooling starts while the zeta cache keeps the user's theta

@@ -43,6 +43,13 @@ struct pgsgd_session {
     int upd = pgsgd::kUpdAtomic;
     bool pf_lds = false;
     size_t lds_bytes = 0;
+    // small lane-bound graphs (pgsgd_kernels.hpp: sample_terms_kernel / apply_terms_resident_kernel): n_streams streams
+    // sample, apply_lanes lanes of one workgroup move the ends in LDS
+    bool split = false;
+    uint32_t apply_lanes = 0;             // the stream-count rule's number, at most one workgroup
+    size_t resident_lds = 0;
+    uint4* d_terms = nullptr;             // [terms_cap] term records of one chunk of an iteration
+    uint64_t terms_cap = 0;
     // device buffers
     uint4* d_recs = nullptr;
     uint64_t* d_path_first = nullptr;
@@ -187,6 +194,11 @@ static uint32_t capped_streams(const pgsgd_session* s, int cus, int blocks_per_c
     if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
     return (uint32_t)n;
 }
+
+// two-pass iterations of small lane-bound graphs: taken, with an automatic stream count, when the coordinates fit one
+// compute unit's LDS and the stream-count rule allows at most kSplitMaxLanes lanes
+constexpr uint64_t kSplitMaxLanes = 2048;
+constexpr uint64_t kSplitChunkTerms = 8ull << 20;  // term records of at most this many terms (128 MB) are held at once
 
 static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
     // Full residency of the update kernel, unless the graph cannot take that many concurrent terms.
@@ -570,6 +582,42 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->n_streams = (p->flags & PGSGD_FLAG_HOT_NODE_CAP) ? capped_streams(s, prop.multiProcessorCount, bpc, p->min_term_updates)
                                                             : auto_streams(s, prop.multiProcessorCount, bpc);
     }
+    // Small lane-bound graphs run an iteration in two passes (pgsgd_kernels.hpp): every stream the GPU holds samples, one
+    // workgroup with the lanes the busiest node allows moves the ends in LDS.  Taken with an automatic stream count when
+    // the 2N coordinate words fit a compute unit's LDS and the rule allows at most kSplitMaxLanes lanes (beyond, one
+    // compute unit's instruction issue is slower than the single-pass kernel's memory round trips: DRB1-3123, 5 632
+    // lanes, 9.3 against 6.7 ms; 3 584 lanes 4.4 against 4.2; LPA and chr6.C4, 1 536 / 1 792 lanes, 50 / 42 against
+    // 104 / 81; DRB1-3123_unsorted, 128 lanes, 19 against 98: profiles/r03/split_vs_piped.jsonl).
+    if (s->fmt == pgsgd::kFmtQ32 && s->upd == pgsgd::kUpdAtomic && p->terms_per_anchor <= 1 && g->n_steps < 0xffffffffull &&
+        !(p->flags & (PGSGD_FLAG_HOT_NODE_CAP | PGSGD_FLAG_NO_PIPELINE | PGSGD_FLAG_NO_SPLIT | PGSGD_FLAG_COORD_LOAD_PLAIN | PGSGD_FLAG_ABLATE(15)))) {
+        uint64_t max_lanes = kSplitMaxLanes;
+        if (const char* e = pgsgd::debug_env("PGSGD_SPLIT_MAX_LANES")) max_lanes = (uint64_t)std::max(0L, atol(e));  // experiment knob
+        // parity knob: an explicit stream count takes the two passes too (one stream, one lane = the sequential program)
+        const bool forced = p->n_streams && p->n_streams <= (uint32_t)pgsgd::kResidentBlock && pgsgd::debug_env("PGSGD_SPLIT_FORCE");
+        const size_t need = (size_t)2 * g->n_nodes * sizeof(uint64_t);
+        const size_t have = std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor);
+        if ((forced || (!p->n_streams && s->n_streams <= max_lanes)) && need <= have) {
+            bool ok = true;
+            if (need > 48 * 1024)  // (an LDS request the device turns down is no error: the graph runs the single-pass kernel)
+                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            if (ok) {
+                s->split = true;
+                s->resident_lds = need;
+                s->apply_lanes = std::min<uint32_t>(s->n_streams, (uint32_t)pgsgd::kResidentBlock);
+                if (!forced) {  // sampler streams: what the GPU holds, at least eight terms per stream and iteration
+                    int bpc = 0;
+                    if (s->pf_lds) S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sample_terms_kernel<true>, pgsgd::kBlock, s->lds_bytes));
+                    else S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sample_terms_kernel<false>, pgsgd::kBlock, 0));
+                    const uint64_t full = (uint64_t)prop.multiProcessorCount * (uint64_t)std::max(1, bpc) * pgsgd::kBlock;
+                    uint64_t ls = std::min<uint64_t>(full, std::max<uint64_t>(s->apply_lanes, p->min_term_updates / 8));
+                    ls = std::max<uint64_t>(64, (ls / 64) * 64);
+                    if (ls >= (uint64_t)pgsgd::kBlock) ls = (ls / pgsgd::kBlock) * pgsgd::kBlock;
+                    s->n_streams = (uint32_t)std::max<uint64_t>(ls, s->apply_lanes);
+                }
+            }
+        }
+    }
 
     // region-exclusive tiles: with the default coordinate format, update mode and term stream, an
     // automatic stream count, and a graph that is big enough and whose hottest node does not ask for
@@ -816,6 +864,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_path_first) (void)hipFree(s->d_path_first);
     if (s->d_zetas) (void)hipFree(s->d_zetas);
     if (s->d_zeta_denom) (void)hipFree(s->d_zeta_denom);
+    if (s->d_terms) (void)hipFree(s->d_terms);
     if (s->d_zipf_tab) (void)hipFree(s->d_zipf_tab);
     if (s->d_node_steps) (void)hipFree(s->d_node_steps);
     if (s->d_coords) (void)hipFree(s->d_coords);
@@ -1091,6 +1140,12 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
     return s->tiled ? (s->warm_per_lane ? 2 : 1) : 0;
 }
 
+extern "C" int pgsgd_session_split_info(const pgsgd_session* s, uint32_t* apply_lanes) {
+    if (!s) return PGSGD_E_INVALID;
+    if (apply_lanes) *apply_lanes = s->split ? s->apply_lanes : 0;
+    return s->split ? 1 : 0;
+}
+
 // The outbox's message pool, sized for calls of n_terms terms: one launch (one colour of one part) sends at most one
 // message per term of its tiles (two for window-less tiles), i.e. about 0.5 * n_terms / n_parts when every partner is
 // far; shares go to the buckets in proportion to the path steps on their nodes (where partners land), plus one open
@@ -1357,7 +1412,32 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     const uint32_t block = s->n_streams >= (uint32_t)pgsgd::kBlock ? pgsgd::kBlock : ((s->n_streams + 63) / 64) * 64;
     const uint32_t grid = (s->n_streams + block - 1) / block;
     HIP_TRY(hipEventRecord(ev.e[0], s->stream));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
+    if (s->split) {
+        // chunks of whole rounds of the sampler streams, so that a stream's terms are the same however the call is cut
+        const uint64_t chunk = std::max<uint64_t>(s->n_streams, (kSplitChunkTerms / s->n_streams) * s->n_streams);
+        const uint64_t want = std::min<uint64_t>(n_terms, chunk);
+        if (want > s->terms_cap) {
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            if (s->d_terms) (void)hipFree(s->d_terms);
+            s->d_terms = nullptr;
+            s->terms_cap = 0;
+            HIP_TRY(hipMalloc(&s->d_terms, want * sizeof(uint4)));
+            s->terms_cap = want;
+        }
+        const uint32_t L = s->apply_lanes;
+        for (uint64_t t0 = 0; t0 < n_terms; t0 += chunk) {
+            a.n_terms = std::min<uint64_t>(chunk, n_terms - t0);
+            if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sample_terms_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a.cooling, a.n_terms, s->d_terms);
+            else hipLaunchKernelGGL((pgsgd::sample_terms_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, a.cooling, a.n_terms, s->d_terms);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(pgsgd::apply_terms_resident_kernel, dim3(1), dim3(((L + 63) / 64) * 64), s->resident_lds, s->stream, s->dc, a, s->d_terms, L);
+            HIP_TRY(hipGetLastError());
+            s->n_kernels += 2;
+        }
+        s->n_kernels--;  // (counted once more below)
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, a);
+    }
     s->n_kernels++;
     s->snap_stale = true;
     HIP_TRY(hipGetLastError());
@@ -1678,7 +1758,7 @@ extern "C" int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_param
 
 static int sort_session(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** s) {
     pgsgd_params q = *p;
-    q.flags |= PGSGD_FLAG_NO_TILES;  // the 1D path has a per-lane kernel only
+    q.flags |= PGSGD_FLAG_NO_TILES | PGSGD_FLAG_NO_SPLIT;  // the 1D path has a per-lane kernel only
     q.flags &= ~PGSGD_FLAG_HOT_NODE_CAP;
     q.terms_per_anchor = 1;
     q.snapshot = 0;

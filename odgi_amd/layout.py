@@ -198,6 +198,13 @@ class LayoutSession:
         on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
         return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
 
+    def split_info(self):
+        """dict(split, apply_lanes): whether per-lane iterations run in two passes (a small lane-bound graph: n_streams
+        streams sample, one workgroup of apply_lanes lanes moves the ends in LDS)."""
+        lanes = C.c_uint32()
+        mode = lib.pgsgd_session_split_info(self._h, C.byref(lanes))
+        return dict(split=mode > 0, apply_lanes=int(lanes.value))
+
     def tile_table(self):
         """Tiles in work order: dict of arrays t0, cum, n, path, lanes (lanes that work on the tile at once, one term
         stream each), and steps_total."""

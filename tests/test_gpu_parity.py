@@ -181,6 +181,63 @@ def test_one_stream_run_is_bit_exact_with_oracle_mirrors(oa, orc, graphs, ograph
     assert st["last_delta_max"] == dmax
 
 
+def test_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ographs, monkeypatch):
+    """A small graph whose busiest node bounds the lanes runs an iteration in two passes: every stream the GPU holds
+    samples (the per-lane kernel's streams and draws), one workgroup with the lanes the graph allows moves the ends with
+    the coordinates in LDS.  Which graphs take them; one stream and one lane reproduce the oracle's sequential mirror
+    and the single-pass kernel bit for bit; the sampler streams are the ones trace_terms describes; a full run
+    conserves the coordinate sums exactly and lays the hub graph out as well as the single-pass kernel does."""
+    import dataclasses
+    from odgi_amd import _lib
+    for name, want in (("DRB1-3123", False), ("DRB1-3123_unsorted", True), ("LPA", True), ("chr6.C4", True)):
+        g = graphs(name)
+        with oa.LayoutSession(g, _params(oa, g)) as s:
+            info = s.split_info()
+            assert info["split"] == want, (name, info)
+            if want:
+                assert 64 <= info["apply_lanes"] <= 1024 and s.n_streams >= info["apply_lanes"]
+                got = s.trace_terms(False, 4)   # the sampler streams are ordinary streams
+                og = ographs(name)
+                p = _params(oa, g)
+                assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p), p.seed, s.n_streams, 0, False, 4))
+        with oa.LayoutSession(g, _params(oa, g, flags=_lib.FLAG_NO_SPLIT)) as s:
+            assert not s.split_info()["split"]
+    # one stream, one lane
+    g, og = graphs("chr6.C4"), ographs("chr6.C4")   # loops: some terms hit the same node end twice
+    X0, Y0 = oa.initial_layout(g, "d", seed=5)
+    p = _params(oa, g, n_streams=1, iter_max=6, min_term_updates=3001)
+    Xs, Ys, dmax_s, fmt_s, _, w_single = _run_session(oa, g, p, X0, Y0)
+    monkeypatch.setenv("PGSGD_SPLIT_FORCE", "1")
+    with oa.LayoutSession(g, p) as s:
+        assert s.split_info() == dict(split=True, apply_lanes=1)
+    Xg, Yg, dmax_g, fmt, w0, w1 = _run_session(oa, g, p, X0, Y0)
+    monkeypatch.delenv("PGSGD_SPLIT_FORCE")
+    Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p), p.seed, 1, X0, Y0, fmt[1], fmt[2], fmt[3])
+    assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo) and dmax_g == dmax_o
+    assert np.array_equal(w1, w_single) and dmax_g == dmax_s
+    # a full run of the hub graph (one node carries 268 of 21 882 steps: 128 lanes)
+    g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
+    res = {}
+    for form, flags in (("two passes", 0), ("single pass", _lib.FLAG_NO_SPLIT)):
+        vals = []
+        for i, seed in enumerate(_INIT_SEEDS):
+            X0, Y0 = oa.initial_layout(g, "d", seed=seed)
+            pp = dataclasses.replace(_params(oa, g, flags=flags), seed=9399220 + 7919 * i)
+            if i == 0 and not flags:
+                Xq, Yq, _, _, wq0, wq1 = _run_session(oa, g, pp, X0, Y0)
+                sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
+                assert sums(wq0) == sums(wq1) and not np.array_equal(wq0, wq1)
+            X, Y = X0.copy(), Y0.copy()
+            st = oa.path_linear_sgd_layout_gpu(g, pp, X, Y)
+            assert st["iterations"] == pp.iter_max and st["term_updates"] == pp.iter_max * pp.min_term_updates
+            vals.append((orc.path_stress_sampled(og, X, Y, 1_000_000), st["kernel_ms"]))
+        res[form] = vals
+    a, b = float(np.mean([v[0] for v in res["two passes"]])), float(np.mean([v[0] for v in res["single pass"]]))
+    print(f"DRB1-3123_unsorted: stress two passes {[round(v[0], 4) for v in res['two passes']]} single pass {[round(v[0], 4) for v in res['single pass']]}; "
+          f"kernel ms {np.mean([v[1] for v in res['two passes']]):.1f} / {np.mean([v[1] for v in res['single pass']]):.1f}")
+    assert 0.90 * b <= a <= 1.10 * b
+
+
 def test_fixed_point_frame_widens_before_a_coordinate_wraps(oa, orc, graphs, ographs, monkeypatch):
     """The fixed-point frame is 8x the layout's extent; a coordinate that reaches its outer quarter makes the session
     double it (same centre, half the resolution) before the next iteration.  With a frame as tight as the layout itself
@@ -272,15 +329,18 @@ def _gpu_runs(oa, orc, g, og, p, init="d"):
     return runs
 
 
-@pytest.mark.parametrize("name,flags,m", [("DRB1-3123", 0, 1), ("LPA", 0, 1), ("chr6.C4", 0, 1), ("LPA", 2, 1), ("LPA", 4, 1),
-                                          ("DRB1-3123", 6, 1), ("LPA", 0, 4), ("chr6.C4", 0, 4)])
+@pytest.mark.parametrize("name,flags,m", [("DRB1-3123", 0, 1), ("LPA", 0, 1), ("chr6.C4", 0, 1), ("LPA", 0x1000, 1), ("chr6.C4", 0x1000, 1),
+                                          ("LPA", 2, 1), ("LPA", 4, 1), ("DRB1-3123", 6, 1), ("LPA", 0, 4), ("chr6.C4", 0, 4)])
 def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, flags, m):
     """BASELINE configs 1-3 with reference defaults: mean sampled path stress of three GPU layouts within the band
     stated above of the median of three CPU-restatement layouts from the same initial layouts; the same for the
-    `odgi stats -s` 2D path distance."""
+    `odgi stats -s` 2D path distance.  (LPA and chr6.C4 with the defaults run their iterations in two passes — the
+    moving pass in one workgroup's LDS; 0x1000 = PGSGD_FLAG_NO_SPLIT is the pipelined single-pass kernel on them.)"""
     from odgi_amd import _lib
     g, og = graphs(name), ographs(name)
     p = _params(oa, g, flags=flags, terms_per_anchor=m)  # 0 default; 2 fp32 atomics; 4 Hogwild stores; 6 fp32 + stores
+    with oa.LayoutSession(g, p) as s:
+        assert s.split_info()["split"] == (name != "DRB1-3123" and flags == 0 and m == 1)
     gpu, cpu = _gpu_runs(oa, orc, g, og, p), _cpu_runs(oa, orc, g, og, name, p)
     s_gpu, s_cpu = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu]))
     d_gpu, d_cpu = float(np.mean([r[1] for r in gpu])), float(np.median([r[1] for r in cpu]))
