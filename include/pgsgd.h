@@ -134,7 +134,7 @@ typedef struct pgsgd_stats {
     uint32_t n_streams;       /* streams actually used                                             */
     uint32_t early_stop;      /* 1 if Delta_max <= delta ended the run (path_sgd_layout.cpp:142)    */
     uint32_t frame_doublings; /* times the fixed-point coordinate frame was widened during the run  */
-    uint32_t reserved;
+    uint32_t apply_lanes;     /* iterations in two passes (a small lane-bound graph): the lanes that moved node ends; else 0 */
 } pgsgd_stats;
 
 /* Fill every field of *p with the reference defaults derived from the path index

@@ -44,7 +44,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("iterations", u64), ("term_updates", u64), ("last_delta_max", f64),
                 ("kernel_ms", f64), ("wall_ms", f64), ("n_streams", u32), ("early_stop", u32),
-                ("frame_doublings", u32), ("reserved", u32)]
+                ("frame_doublings", u32), ("apply_lanes", u32)]
 
 
 FLAG_COORD_LOAD_PLAIN = 0x1

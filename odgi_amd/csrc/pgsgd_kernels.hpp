@@ -893,6 +893,85 @@ __global__ __launch_bounds__(kBlock) void sort_iteration_kernel(DevConst c, Sort
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
 }
 
+// The two passes of small lane-bound graphs (sample_terms_kernel / apply_terms_resident_kernel above), 1D.  A term record is
+// {node a, node b, path distance as fp64}; bit 31 of a node word says the node is frozen (target sorting).
+constexpr uint32_t kFrozenBit = 0x80000000u;
+template <bool PF_LDS>
+__global__ __launch_bounds__(kBlock) void sort_sample_terms_kernel(DevConst c, SortArgs sa, uint4* out) {
+    extern __shared__ uint64_t s_pf[];
+    if (PF_LDS) {
+        for (uint32_t i = threadIdx.x; i <= c.n_paths; i += blockDim.x) s_pf[i] = c.path_first[i];
+        __syncthreads();
+    }
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= c.n_streams) return;
+    const uint64_t* pf = PF_LDS ? s_pf : c.path_first;
+    Xoshiro256Plus rng;
+    const size_t L = c.n_streams;
+    rng.s0 = c.rng[g];
+    rng.s1 = c.rng[L + g];
+    rng.s2 = c.rng[2 * L + g];
+    rng.s3 = c.rng[3 * L + g];
+    for (uint64_t ti = g; ti < sa.n_terms; ti += L) {
+        const Term1D t = sample_term_1d(c, pf, sa, rng);
+        const int64_t diff = (int64_t)t.pos_a - (int64_t)t.pos_b;
+        const uint64_t dist = (uint64_t)__double_as_longlong((double)(uint64_t)(diff < 0 ? -diff : diff));  // :316-318
+        out[ti] = make_uint4(t.node_a | (t.move_a ? 0u : kFrozenBit), t.node_b | (t.move_b ? 0u : kFrozenBit), (uint32_t)dist, (uint32_t)(dist >> 32));
+    }
+    c.rng[g] = rng.s0;
+    c.rng[L + g] = rng.s1;
+    c.rng[2 * L + g] = rng.s2;
+    c.rng[3 * L + g] = rng.s3;
+}
+
+// one workgroup, the N position words in its LDS; lane l moves the nodes of terms l, l + lanes, ... in order: the
+// arithmetic of sort_iteration_kernel (path_sgd.cpp:316-363)
+__global__ __launch_bounds__(kResidentBlock) void sort_apply_terms_resident_kernel(DevConst c, SortArgs sa, const uint4* terms, uint32_t lanes) {
+    extern __shared__ uint64_t s_win[];
+    long long* x = reinterpret_cast<long long*>(s_win);
+    for (uint32_t i = threadIdx.x; i < c.n_nodes; i += blockDim.x) x[i] = sa.X[i];
+    __syncthreads();
+    const uint32_t l = threadIdx.x;
+    const uint64_t n_mine = l < lanes && sa.n_terms > l ? (sa.n_terms - l + lanes - 1) / lanes : 0;
+    float dmax = 0.0f;
+    if (n_mine) {
+        uint4 t[kResidentAhead];
+#pragma unroll
+        for (int k = 0; k < kResidentAhead; ++k) t[k] = terms[l + (uint64_t)(k < (int64_t)n_mine ? k : 0) * lanes];
+        for (uint64_t j = 0; j < n_mine; j += kResidentAhead) {
+#pragma unroll
+            for (int k = 0; k < kResidentAhead; ++k) {
+                const uint4 r = t[k];
+                const uint64_t nxt = j + k + kResidentAhead;
+                t[k] = terms[l + (nxt < n_mine ? nxt : 0) * lanes];  // (every slot asks: the requests in flight are the same on every path)
+                const bool move_a = !(r.x & kFrozenBit), move_b = !(r.y & kFrozenBit);
+                if (j + k < n_mine && (move_a || move_b)) {
+                    const uint32_t node_a = r.x & ~kFrozenBit, node_b = r.y & ~kFrozenBit;
+                    const long long qa = x[node_a], qb = x[node_b];
+                    const double term_dist = __longlong_as_double((long long)((uint64_t)r.z | ((uint64_t)r.w << 32)));
+                    double mu = sa.eta * (1.0 / term_dist);                                   // :328-332
+                    if (mu > 1.0) mu = 1.0;
+                    double dx = (double)(qa - qb) * sa.inv_scale;
+                    if (dx == 0.0) dx = 1e-9;
+                    const double mag = fabs(dx);
+                    const double Delta = mu * (mag - term_dist) / 2.0;                        // :355
+                    const double r_x = (Delta / mag) * dx;
+                    const long long dq = __double2ll_rn(r_x * sa.scale);
+                    dmax = fmaxf(dmax, (float)fabs(Delta));
+                    if (dq != 0) {
+                        if (move_b) atomicAdd(reinterpret_cast<unsigned long long*>(x + node_b), (unsigned long long)dq);
+                        if (move_a) atomicAdd(reinterpret_cast<unsigned long long*>(x + node_a), (unsigned long long)(-dq));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < c.n_nodes; i += blockDim.x) sa.X[i] = x[i];
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
+}
+
 template <bool PF_LDS>
 __global__ __launch_bounds__(kBlock) void sort_trace_kernel(DevConst c, SortArgs sa, uint64_t seed_base, uint64_t terms_per_stream, uint64_t* out) {
     extern __shared__ uint64_t s_pf[];

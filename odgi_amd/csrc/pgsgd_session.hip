@@ -1714,6 +1714,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         stats->n_streams = pgsgd_session_n_streams(s);
         stats->early_stop = early;
         stats->frame_doublings = s->frame_doublings;
+        stats->apply_lanes = s->split && !s->tiled ? s->apply_lanes : 0;
         pgsgd_session_kernel_time(s, &stats->kernel_ms, nullptr, 0);
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -1758,7 +1759,7 @@ extern "C" int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_param
 
 static int sort_session(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** s) {
     pgsgd_params q = *p;
-    q.flags |= PGSGD_FLAG_NO_TILES | PGSGD_FLAG_NO_SPLIT;  // the 1D path has a per-lane kernel only
+    q.flags |= PGSGD_FLAG_NO_TILES;  // the 1D path has per-lane kernels only (one pass, or two on a small lane-bound graph)
     q.flags &= ~PGSGD_FLAG_HOT_NODE_CAP;
     q.terms_per_anchor = 1;
     q.snapshot = 0;
@@ -1840,6 +1841,14 @@ extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_par
         T_TRY(hipMemcpyAsync(d_frozen, target_nodes, N, hipMemcpyHostToDevice, s->stream));
         sa.frozen = d_frozen;
     }
+    const uint64_t chunk = std::max<uint64_t>(s->n_streams, (kSplitChunkTerms / s->n_streams) * s->n_streams);  // whole rounds of the sampler streams
+    if (s->split) {
+        if (N * sizeof(long long) > 48 * 1024)
+            T_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::sort_apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(N * sizeof(long long))));
+        s->terms_cap = std::min<uint64_t>(p->min_term_updates, chunk);
+        T_TRY(hipMalloc(&s->d_terms, std::max<uint64_t>(1, s->terms_cap) * sizeof(uint4)));
+    }
     hipEvent_t e0, e1;
     T_TRY(hipEventCreate(&e0));
     T_TRY(hipEventCreate(&e1));
@@ -1852,7 +1861,17 @@ extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_par
         sa.cooling = it > first_cooling ? 1u : 0u;
         T_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));
         T_TRY(hipEventRecord(e0, s->stream));
-        if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sort_iteration_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, sa);
+        if (s->split) {  // a small lane-bound graph: sampling apart from moving, as in the layout (pgsgd_kernels.hpp)
+            for (uint64_t t0 = 0; t0 < p->min_term_updates; t0 += chunk) {
+                sa.n_terms = std::min<uint64_t>(chunk, p->min_term_updates - t0);
+                if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sort_sample_terms_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, sa, s->d_terms);
+                else hipLaunchKernelGGL((pgsgd::sort_sample_terms_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, sa, s->d_terms);
+                T_TRY(hipGetLastError());
+                hipLaunchKernelGGL(pgsgd::sort_apply_terms_resident_kernel, dim3(1), dim3(((s->apply_lanes + 63) / 64) * 64), N * sizeof(long long), s->stream,
+                                   s->dc, sa, s->d_terms, s->apply_lanes);
+                T_TRY(hipGetLastError());
+            }
+        } else if (s->pf_lds) hipLaunchKernelGGL((pgsgd::sort_iteration_kernel<true>), dim3(grid), dim3(block), s->lds_bytes, s->stream, s->dc, sa);
         else hipLaunchKernelGGL((pgsgd::sort_iteration_kernel<false>), dim3(grid), dim3(block), 0, s->stream, s->dc, sa);
         T_TRY(hipGetLastError());
         T_TRY(hipEventRecord(e1, s->stream));
@@ -1883,6 +1902,7 @@ extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_par
         stats->last_delta_max = dmax;
         stats->kernel_ms = kernel_ms;
         stats->n_streams = s->n_streams;
+        stats->apply_lanes = s->split ? s->apply_lanes : 0;
         stats->early_stop = early;
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

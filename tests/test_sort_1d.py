@@ -73,15 +73,41 @@ def test_1d_sampler_streams_bit_exact(oa, orc, graphs, ographs):
 
 
 @pytest.mark.gpu
-def test_1d_one_stream_run_bit_exact(oa, orc, graphs, ographs):
+def test_1d_one_stream_run_bit_exact(oa, orc, graphs, ographs, monkeypatch):
     from odgi_amd.sort import path_linear_sgd, sort_params_defaults
     g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
     p = sort_params_defaults(g, n_streams=1, iter_max=8, min_term_updates=2000, device=0)
-    Xg, st = path_linear_sgd(g, p)
     Xo, dmax = orc.sort_streams(og, orc.params_from(p), p.seed, 1, orc.sort_initial(og))
-    assert st["iterations"] == 9 and st["term_updates"] == 9 * 2000
-    assert np.array_equal(Xg, Xo)
-    assert st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
+    for two_passes in (False, True):   # (the parity knob sends an explicit stream count through the two passes of small lane-bound graphs)
+        if two_passes:
+            monkeypatch.setenv("PGSGD_SPLIT_FORCE", "1")
+        Xg, st = path_linear_sgd(g, p)
+        assert st["iterations"] == 9 and st["term_updates"] == 9 * 2000 and st["apply_lanes"] == (1 if two_passes else 0)
+        assert np.array_equal(Xg, Xo)
+        assert st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_1d_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ographs):
+    """`odgi sort -Y` defaults on the reference's fixture graphs: the hub graph and the deep ones sample with every stream
+    the GPU holds and move the nodes in one workgroup's LDS; the layout is as good as the single-pass kernel's
+    (PGSGD_FLAG_NO_SPLIT) and the CPU restatement's."""
+    from odgi_amd import _lib
+    from odgi_amd.sort import path_linear_sgd, sort_params_defaults
+    for name, want in (("DRB1-3123", False), ("DRB1-3123_unsorted", True), ("LPA", True)):
+        g, og = graphs(name), ographs(name)
+        res = {}
+        for form, flags in (("two passes", 0), ("single pass", _lib.FLAG_NO_SPLIT)):
+            p = sort_params_defaults(g, device=0, flags=flags)
+            X, st = path_linear_sgd(g, p)
+            assert (st["apply_lanes"] > 0) == (want and not flags), (name, form, st)
+            assert st["iterations"] == p.iter_max + 1 and st["term_updates"] == (p.iter_max + 1) * p.min_term_updates
+            res[form] = (orc.sort_stress(og, X, 300000), st["kernel_ms"], st["n_streams"], st["apply_lanes"])
+        Xo, _ = orc.sort_hogwild(og, orc.params_from(sort_params_defaults(g)), 4, orc.sort_initial(og))
+        s_cpu = orc.sort_stress(og, Xo, 300000)
+        print(f"1D {name}: stress two passes {res['two passes'][0]:.4f} single pass {res['single pass'][0]:.4f} cpu {s_cpu:.4f}; "
+              f"kernel ms {res['two passes'][1]:.1f} / {res['single pass'][1]:.1f}; streams {res['two passes'][2]} lanes {res['two passes'][3]}")
+        assert res["two passes"][0] <= 1.15 * res["single pass"][0] + 0.01 and res["two passes"][0] <= 1.25 * s_cpu + 0.02
 
 
 @pytest.mark.gpu
@@ -120,17 +146,22 @@ def test_oracle_1d_target_nodes_stay_put(oa, orc):
 
 
 @pytest.mark.gpu
-def test_1d_target_nodes_bit_exact_and_frozen(oa, orc, graphs, ographs):
+def test_1d_target_nodes_bit_exact_and_frozen(oa, orc, graphs, ographs, monkeypatch):
     from odgi_amd.sort import path_linear_sgd, sort_params_defaults
     g, og = graphs("DRB1-3123"), ographs("DRB1-3123")
     frozen = np.zeros(g.n_nodes, dtype=np.uint8)
     frozen[np.random.RandomState(4).rand(g.n_nodes) < 0.3] = 1
     p = sort_params_defaults(g, n_streams=1, iter_max=8, min_term_updates=2000, device=0)
-    Xg, st = path_linear_sgd(g, p, target_nodes=frozen)
     X0 = orc.sort_initial(og)
     Xo, dmax = orc.sort_streams(og, orc.params_from(p), p.seed, 1, X0, frozen=frozen)
-    assert np.array_equal(Xg, Xo) and st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
-    assert np.array_equal(Xg[frozen == 1], X0[frozen == 1]) and not np.array_equal(Xg, X0)
+    for two_passes in (False, True):
+        if two_passes:
+            monkeypatch.setenv("PGSGD_SPLIT_FORCE", "1")
+        Xg, st = path_linear_sgd(g, p, target_nodes=frozen)
+        assert st["apply_lanes"] == (1 if two_passes else 0)
+        assert np.array_equal(Xg, Xo) and st["last_delta_max"] == pytest.approx(dmax, rel=1e-6)
+        assert np.array_equal(Xg[frozen == 1], X0[frozen == 1]) and not np.array_equal(Xg, X0)
+    monkeypatch.delenv("PGSGD_SPLIT_FORCE")
     # full-width run: frozen nodes still exactly in place
     p = sort_params_defaults(g, device=0)
     Xf, _ = path_linear_sgd(g, p, target_nodes=frozen)
