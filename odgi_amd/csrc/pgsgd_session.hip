@@ -198,6 +198,7 @@ static uint32_t capped_streams(const pgsgd_session* s, int cus, int blocks_per_c
 // two-pass iterations of small lane-bound graphs: taken, with an automatic stream count, when the coordinates fit one
 // compute unit's LDS and the stream-count rule allows at most kSplitMaxLanes lanes
 constexpr uint64_t kSplitMaxLanes = 2048;
+constexpr uint32_t kSplitApplyLanes = 1024;  // lanes of the moving workgroup, at most
 constexpr uint64_t kSplitChunkTerms = 8ull << 20;  // term records of at most this many terms (128 MB) are held at once
 
 static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu) {
@@ -604,7 +605,9 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (ok) {
                 s->split = true;
                 s->resident_lds = need;
-                s->apply_lanes = std::min<uint32_t>(s->n_streams, (uint32_t)pgsgd::kResidentBlock);
+                uint32_t lane_cap = kSplitApplyLanes;
+                if (const char* e = pgsgd::debug_env("PGSGD_SPLIT_APPLY_LANES")) lane_cap = (uint32_t)std::min<long>(pgsgd::kResidentBlock, std::max(64L, atol(e)));  // experiment knob
+                s->apply_lanes = std::min<uint32_t>(s->n_streams, lane_cap);
                 if (!forced) {  // sampler streams: what the GPU holds, at least eight terms per stream and iteration
                     int bpc = 0;
                     if (s->pf_lds) S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, pgsgd::sample_terms_kernel<true>, pgsgd::kBlock, s->lds_bytes));

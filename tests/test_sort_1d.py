@@ -89,25 +89,31 @@ def test_1d_one_stream_run_bit_exact(oa, orc, graphs, ographs, monkeypatch):
 
 @pytest.mark.gpu
 def test_1d_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ographs):
-    """`odgi sort -Y` defaults on the reference's fixture graphs: the hub graph and the deep ones sample with every stream
+    """`odgi sort -Y` defaults on the reference's fixture graphs: the hub graph and the deep one sample with every stream
     the GPU holds and move the nodes in one workgroup's LDS; the layout is as good as the single-pass kernel's
-    (PGSGD_FLAG_NO_SPLIT) and the CPU restatement's."""
+    (PGSGD_FLAG_NO_SPLIT) and the CPU restatement's (means of three seeds; five seeds of either form scatter by 2-3 % on
+    these two graphs, profiles/r03/split_apply_lanes.jsonl — LPA's 1D stress scatters by 20 % with the seed and is left out)."""
     from odgi_amd import _lib
     from odgi_amd.sort import path_linear_sgd, sort_params_defaults
-    for name, want in (("DRB1-3123", False), ("DRB1-3123_unsorted", True), ("LPA", True)):
+    for name, want in (("DRB1-3123", False), ("DRB1-3123_unsorted", True), ("chr6.C4", True)):
         g, og = graphs(name), ographs(name)
         res = {}
         for form, flags in (("two passes", 0), ("single pass", _lib.FLAG_NO_SPLIT)):
-            p = sort_params_defaults(g, device=0, flags=flags)
-            X, st = path_linear_sgd(g, p)
-            assert (st["apply_lanes"] > 0) == (want and not flags), (name, form, st)
-            assert st["iterations"] == p.iter_max + 1 and st["term_updates"] == (p.iter_max + 1) * p.min_term_updates
-            res[form] = (orc.sort_stress(og, X, 300000), st["kernel_ms"], st["n_streams"], st["apply_lanes"])
+            vals = []
+            for rep in range(3):
+                p = sort_params_defaults(g, device=0, flags=flags, seed=9399220 + 7919 * rep)
+                X, st = path_linear_sgd(g, p)
+                assert (st["apply_lanes"] > 0) == (want and not flags), (name, form, st)
+                assert st["iterations"] == p.iter_max + 1 and st["term_updates"] == (p.iter_max + 1) * p.min_term_updates
+                vals.append((orc.sort_stress(og, X, 300000), st["kernel_ms"], st["n_streams"], st["apply_lanes"]))
+            res[form] = vals
         Xo, _ = orc.sort_hogwild(og, orc.params_from(sort_params_defaults(g)), 4, orc.sort_initial(og))
         s_cpu = orc.sort_stress(og, Xo, 300000)
-        print(f"1D {name}: stress two passes {res['two passes'][0]:.4f} single pass {res['single pass'][0]:.4f} cpu {s_cpu:.4f}; "
-              f"kernel ms {res['two passes'][1]:.1f} / {res['single pass'][1]:.1f}; streams {res['two passes'][2]} lanes {res['two passes'][3]}")
-        assert res["two passes"][0] <= 1.15 * res["single pass"][0] + 0.01 and res["two passes"][0] <= 1.25 * s_cpu + 0.02
+        a, b = float(np.mean([v[0] for v in res["two passes"]])), float(np.mean([v[0] for v in res["single pass"]]))
+        print(f"1D {name}: stress two passes {[round(v[0], 3) for v in res['two passes']]} single pass {[round(v[0], 3) for v in res['single pass']]} cpu {s_cpu:.3f}; "
+              f"kernel ms {np.mean([v[1] for v in res['two passes']]):.1f} / {np.mean([v[1] for v in res['single pass']]):.1f}; "
+              f"streams {res['two passes'][0][2]} lanes {res['two passes'][0][3]}")
+        assert 0.90 * b <= a <= 1.10 * b and a <= 1.25 * s_cpu + 0.02
 
 
 @pytest.mark.gpu
