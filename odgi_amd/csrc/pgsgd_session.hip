@@ -261,6 +261,27 @@ static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
+// Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within 7 %) for which the work items of a launch (one per region
+// of a colour: ceil(regions / 2)) fill their rounds over `slots` resident workgroups best; 256 when one round or more
+// than eight are needed either way (see the caller).
+static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
+    auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
+    const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;
+    if (rounds256 < 2 || rounds256 > 8) return 256;
+    uint32_t best = 256;
+    double best_fill = (double)items_of(256) / (double)(rounds256 * slots);
+    for (uint32_t r = 240; r <= 272; r += 8) {
+        const uint64_t items = items_of(r), rounds = (items + slots - 1) / slots;
+        const double fill = (double)items / (double)(rounds * slots);
+        const bool nearer = (r > 256 ? r - 256 : 256 - r) < (best > 256 ? best - 256 : 256 - best);
+        if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && nearer)) {
+            best = r;
+            best_fill = fill;
+        }
+    }
+    return best;
+}
+
 // Host side of the tiled kernel: cut paths into tiles, bind tiles to region windows, order the work.
 struct HostTiles {
     std::vector<pgsgd::Tile> tiles;
@@ -632,13 +653,17 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // (300k nodes: 1.97e10 terms/s against 1.33e10 with R = 512) and cost nothing on large ones (1e6 nodes, five
         // seeds each: 3.10e10 terms/s, stress 0.246 against 2.98e10, 0.255 with R = 512;
         // profiles/r01/tiles_region_256_vs_512.jsonl).  R = 128 with 256 lanes diverges.
-        if (const char* e = pgsgd::debug_env("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (power of two)
+        bool region_given = false;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (a multiple of 8)
             const long r = atol(e);
-            if (r >= 32 && r <= 2048 && (r & (r - 1)) == 0) {
+            if (r >= 32 && r <= 2048 && r % 8 == 0) {
                 s->region = (uint32_t)r;
                 s->tile_steps = (uint32_t)(r - r / 8);
+                region_given = true;
             }
         }
+        long steps_given = 0;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_STEPS")) steps_given = atol(e);  // experiment knob: steps per tile (at most the region size)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_SUBSTEPS")) {  // experiment knob: window refreshes per iteration
             const long k = atol(e);
             if (k >= 1 && k <= 64) s->tile_substeps = (uint32_t)k;
@@ -655,6 +680,31 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // the hottest node must leave room for at least four workgroups per CU (the occupancy the kernel
         // was validated at); between that and full residency the grid is cut to the hot-node cap
         const uint64_t cu_lanes = (uint64_t)prop.multiProcessorCount * s->tile_block;
+        if (steps_given >= 16 && steps_given <= (long)s->region && region_given) s->tile_steps = (uint32_t)steps_given;
+        if (!region_given) {
+            // A launch's work items are handed to the resident workgroups in rounds, and a launch of a few rounds lasts
+            // a whole number of them: at config 4 (1e6 nodes, 1024 workgroups) R = 256 makes 1 953 items per colour
+            // — two rounds, the second 91 % full — R = 248 makes 2 017, R = 240 makes 2 084: a third round for 36
+            // items (measured, tile kernel's roofline fraction: 0.488 / 0.493 / 0.420;
+            // profiles/r03/bench_variants_call25_region.txt).  So R is the multiple of 8 in [240, 272] that fills the
+            // rounds best; graphs of a single round or of more than eight keep 256.
+            const uint64_t slots = (uint64_t)prop.multiProcessorCount * std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
+            const uint32_t r = choose_region(g->n_nodes, slots);
+            if (r != s->region) {
+                s->region = r;
+                s->tile_steps = r - r / 8;
+                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+                int bpc_r = 0;
+                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_r, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
+                if (bpc_r < bpc) {  // (cannot happen at 272 nodes per region with the default bucket count; keep the validated size if it does)
+                    s->region = 256;
+                    s->tile_steps = 224;
+                    s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+                }
+            }
+            if (steps_given >= 16 && steps_given <= (long)s->region) s->tile_steps = (uint32_t)steps_given;
+        }
+        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
         // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
@@ -676,9 +726,73 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool long_schedule = p->iter_max >= 15;
         if ((force || (cap >= 4 * cu_lanes && long_schedule)) && short_paths && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
-            std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
-            rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
-            if (rc) return fail(rc);
+            // Steps per tile.  A tile's share of an iteration is q = terms / steps terms per step, drawn by the workgroup's
+            // lanes in trips of `lanes` terms: T = lanes * k / q steps make k full trips.  T is R - R / 8 rounded DOWN to
+            // such a number (q = 10, 256 lanes: 204 steps = eight trips, where 224 made 8.75 and 217, at R = 248, 8.5).
+            // Measured at config 4, R = 248, roofline fraction of the tile kernel for T = 128 / 153 / 179 / 192 / 204 / 217 /
+            // 230: 0.478 / 0.491 / 0.494 / 0.498 / 0.497-0.500 / 0.492 / 0.479 — and 0.494 for 230 with the 500 of 202 927
+            // tiles that no longer fit a window cut in two: longer is not better; a tile that does not fit is a work item
+            // without a window in a launch of its own, and a launch costs a round whatever it holds
+            // (profiles/r03/bench_variants_call26_tile_steps.txt).  A few misfits (at most 1 %) are cut in two, more send
+            // the choice to the next smaller T; graphs with unsorted stretches (no candidate is free of such tiles) and
+            // runs with q < 1 keep T = R - R / 8.
+            std::vector<RawTile> raw;
+            if (!region_given && !steps_given) {
+                const double q = (double)p->min_term_updates / (double)g->n_steps;
+                const uint32_t lanes = s->tile_block;
+                const uint32_t kmax = q >= 1.0 ? (uint32_t)((double)(s->region - s->region / 8) * q / (double)lanes) : 0;
+                for (uint32_t k = kmax, tries = 0; k >= 4 && tries < 3; --k, ++tries) {
+                    const uint32_t T = (uint32_t)((double)lanes * (double)k / q);
+                    if (T < s->region / 2 || T > s->region) break;
+                    std::vector<RawTile> cand = cut_tiles(g, T);
+                    rc = device_tile_stats(s->stream, d_handle, T, cand);
+                    if (rc) return fail(rc);
+                    // a few tiles that do not fit (the first step sits late in its region and the path skips nodes) are cut in
+                    // two; more than 1 % of them means the tile is too long for the graph: the next candidate
+                    auto fits = [&](const RawTile& t) { return (uint64_t)t.rmax < ((uint64_t)(t.rmin / s->region) + 2) * s->region; };
+                    uint64_t misfits = 0;
+                    for (const RawTile& t : cand) misfits += fits(t) ? 0 : 1;
+                    bool all_fit = misfits == 0;
+                    if (!all_fit && misfits * 100 <= cand.size()) {
+                        std::vector<RawTile> split;
+                        split.reserve(cand.size() + misfits);
+                        all_fit = true;
+                        std::vector<uint32_t> ranks;
+                        for (const RawTile& t : cand) {
+                            if (fits(t) || t.n < 2) { split.push_back(t); all_fit = all_fit && fits(t); continue; }
+                            for (int half = 0; half < 2; ++half) {
+                                RawTile h = t;
+                                h.t0 = t.t0 + (half ? t.n / 2 : 0);
+                                h.n = half ? t.n - t.n / 2 : t.n / 2;
+                                ranks.resize(h.n);
+                                for (uint32_t i = 0; i < h.n; ++i) ranks[i] = g->step_handle[h.t0 + i] >> 1;
+                                std::sort(ranks.begin(), ranks.end());
+                                h.rmin = ranks.front();
+                                h.rmax = ranks.back();
+                                h.maxmult = 1;
+                                for (uint32_t i = 0, run = 1; i + 1 < h.n; ++i) {
+                                    run = ranks[i + 1] == ranks[i] ? run + 1 : 1;
+                                    h.maxmult = std::max(h.maxmult, run);
+                                }
+                                all_fit = all_fit && fits(h);
+                                split.push_back(h);
+                            }
+                        }
+                        if (all_fit) cand.swap(split);
+                    }
+                    if (all_fit) {
+                        raw = std::move(cand);
+                        s->tile_steps = T;
+                        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+                        break;
+                    }
+                }
+            }
+            if (raw.empty()) {
+                raw = cut_tiles(g, s->tile_steps);
+                rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
+                if (rc) return fail(rc);
+            }
             // experiment knob: "region" = work items in node order, one run per XCD (TileArgs::chunk); measured slower, see group_tiles
             const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");
             HostTiles ht = group_tiles(raw, g->n_nodes, s->region, !(order && !strcmp(order, "region")));
