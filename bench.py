@@ -182,8 +182,8 @@ def main():
                                     "per-lane kernel until cooling, tile kernel after" if info["warm_per_lane"] else
                                     "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
     # HBM bytes per launch: NOT measured in this run — read from the committed rocprofv3 PMC passes of this same
-    # command (tools/profile_bench.sh + tools/summarize_prof.py -> profiles/r03/pmc_traffic_r03.json), labelled as such
-    prof = os.path.join(ROOT, "profiles", "r03", "pmc_traffic_r03.json")
+    # command (tools/profile_bench.sh + tools/summarize_prof.py -> profiles/r03/pmc_traffic_r03final.json), labelled as such
+    prof = os.path.join(ROOT, "profiles", "r03", "pmc_traffic_r03final.json")
     same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
     if os.path.exists(prof) and same_workload:
         try:
