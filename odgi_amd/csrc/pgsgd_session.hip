@@ -47,6 +47,7 @@ struct pgsgd_session {
     // sample, apply_lanes lanes of one workgroup move the ends in LDS
     bool split = false;
     uint32_t apply_lanes = 0;             // the stream-count rule's number, at most one workgroup
+    uint64_t split_chunk = 0;             // terms sampled and moved per pair of launches: whole rounds of the sampler streams
     size_t resident_lds = 0;
     uint4* d_terms = nullptr;             // [terms_cap] term records of one chunk of an iteration
     uint64_t terms_cap = 0;
@@ -626,6 +627,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (ok) {
                 s->split = true;
                 s->resident_lds = need;
+                s->split_chunk = kSplitChunkTerms;
+                if (const char* e = pgsgd::debug_env("PGSGD_SPLIT_CHUNK")) s->split_chunk = (uint64_t)std::max(1L, atol(e));  // test knob: terms per chunk
                 uint32_t lane_cap = kSplitApplyLanes;
                 if (const char* e = pgsgd::debug_env("PGSGD_SPLIT_APPLY_LANES")) lane_cap = (uint32_t)std::min<long>(pgsgd::kResidentBlock, std::max(64L, atol(e)));  // experiment knob
                 s->apply_lanes = std::min<uint32_t>(s->n_streams, lane_cap);
@@ -1531,7 +1534,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     HIP_TRY(hipEventRecord(ev.e[0], s->stream));
     if (s->split) {
         // chunks of whole rounds of the sampler streams, so that a stream's terms are the same however the call is cut
-        const uint64_t chunk = std::max<uint64_t>(s->n_streams, (kSplitChunkTerms / s->n_streams) * s->n_streams);
+        const uint64_t chunk = std::max<uint64_t>(s->n_streams, (s->split_chunk / s->n_streams) * s->n_streams);
         const uint64_t want = std::min<uint64_t>(n_terms, chunk);
         if (want > s->terms_cap) {
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1958,7 +1961,7 @@ extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_par
         T_TRY(hipMemcpyAsync(d_frozen, target_nodes, N, hipMemcpyHostToDevice, s->stream));
         sa.frozen = d_frozen;
     }
-    const uint64_t chunk = std::max<uint64_t>(s->n_streams, (kSplitChunkTerms / s->n_streams) * s->n_streams);  // whole rounds of the sampler streams
+    const uint64_t chunk = std::max<uint64_t>(s->n_streams, (std::max<uint64_t>(1, s->split_chunk) / s->n_streams) * s->n_streams);  // whole rounds of the sampler streams
     if (s->split) {
         if (N * sizeof(long long) > 48 * 1024)
             T_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::sort_apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -215,6 +215,17 @@ def test_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ographs
     Xo, Yo, dmax_o, ck = orc.layout_streams_q32(og, orc.params_from(p), p.seed, 1, X0, Y0, fmt[1], fmt[2], fmt[3])
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo) and dmax_g == dmax_o
     assert np.array_equal(w1, w_single) and dmax_g == dmax_s
+    # an iteration cut into chunks (whole rounds of the sampler streams; 8M terms in production, 7 and 640 here): the same
+    # terms in the same order — one stream bit for bit, 64 streams on 64 lanes too (a wave is in lock step)
+    for streams, chunk in ((1, 7), (64, 640)):
+        pc = _params(oa, g, n_streams=streams, iter_max=4, min_term_updates=3001)
+        monkeypatch.setenv("PGSGD_SPLIT_FORCE", "1")
+        whole = _run_session(oa, g, pc, X0, Y0)[5]
+        monkeypatch.setenv("PGSGD_SPLIT_CHUNK", str(chunk))
+        cut = _run_session(oa, g, pc, X0, Y0)[5]
+        monkeypatch.delenv("PGSGD_SPLIT_CHUNK")
+        monkeypatch.delenv("PGSGD_SPLIT_FORCE")
+        assert np.array_equal(whole, cut), (streams, chunk)
     # a full run of the hub graph (one node carries 268 of 21 882 steps: 128 lanes)
     g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
     res = {}
