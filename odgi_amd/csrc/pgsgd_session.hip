@@ -262,9 +262,9 @@ static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
-// Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within 7 %) for which the work items of a launch (one per region
-// of a colour: ceil(regions / 2)) fill their rounds over `slots` resident workgroups best; 256 when one round or more
-// than eight are needed either way (see the caller).
+// Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within
+// 7 %) for which the work items of a launch (one per region of a colour: ceil(regions / 2)) fill their rounds over
+// `slots` resident workgroups best; 256 when one round or more than eight are needed either way (see the caller).
 static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
     auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
     const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;
@@ -620,9 +620,11 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const size_t need = (size_t)2 * g->n_nodes * sizeof(uint64_t);
         const size_t have = std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor);
         if ((forced || (!p->n_streams && s->n_streams <= max_lanes)) && need <= have) {
-            bool ok = true;
-            if (need > 48 * 1024)  // (an LDS request the device turns down is no error: the graph runs the single-pass kernel)
-                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess;
+            // (the attribute belongs to the kernel, not to the session: it is set to what the device has, so that sessions of
+            // different graphs do not lower it under each other; a request the device turns down is no error — the graph runs
+            // the single-pass kernel)
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)have) == hipSuccess &&
+                            hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::sort_apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)have) == hipSuccess;
             if (!ok) (void)hipGetLastError();
             if (ok) {
                 s->split = true;
@@ -848,9 +850,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
                 S_TRY(hipMalloc(&s->d_queue, 3 * pgsgd::kItemQueues * sizeof(uint32_t)));
                 S_TRY(hipMemset(s->d_queue, 0, 3 * pgsgd::kItemQueues * sizeof(uint32_t)));
-                if ((sizeof(uint64_t) << s->ob_part_shift) > 48 * 1024)
-                    S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(sizeof(uint64_t) << s->ob_part_shift)));
+                // (the attribute belongs to the kernel, not to the session: always the widest part a drain workgroup accumulates,
+                // so that sessions of different graphs do not lower it under each other)
+                S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(sizeof(uint64_t) << 14)));
                 S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
@@ -1962,10 +1965,7 @@ extern "C" int pgsgd_sort_run_targets(const pgsgd_graph_view* g, const pgsgd_par
         sa.frozen = d_frozen;
     }
     const uint64_t chunk = std::max<uint64_t>(s->n_streams, (std::max<uint64_t>(1, s->split_chunk) / s->n_streams) * s->n_streams);  // whole rounds of the sampler streams
-    if (s->split) {
-        if (N * sizeof(long long) > 48 * 1024)
-            T_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::sort_apply_terms_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(N * sizeof(long long))));
+    if (s->split) {  // (the moving kernel's LDS attribute was set when the session was created)
         s->terms_cap = std::min<uint64_t>(p->min_term_updates, chunk);
         T_TRY(hipMalloc(&s->d_terms, std::max<uint64_t>(1, s->terms_cap) * sizeof(uint4)));
     }

@@ -202,6 +202,28 @@ def test_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ographs
                 assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p), p.seed, s.n_streams, 0, False, 4))
         with oa.LayoutSession(g, _params(oa, g, flags=_lib.FLAG_NO_SPLIT)) as s:
             assert not s.split_info()["split"]
+    # two sessions of different sizes alive at once: the LDS the moving kernel may use is a property of the kernel, and the
+    # smaller session must not lower it under the larger one (9 000 nodes: 144 KB of LDS; hub node: 600 lanes by the rule)
+    rs = np.random.RandomState(5)
+    big_h = [2 * np.sort(rs.choice(9000, 8000, replace=False)).astype(np.uint32) for _ in range(6)]
+    big_h.append(np.tile(np.array([2 * 4500, 2 * 4501], dtype=np.uint32), 80))   # a path that visits one node 80 times
+    first = np.concatenate([[0], np.cumsum([len(h) for h in big_h])]).astype(np.uint64)
+    gb = oa.Graph.from_arrays(rs.randint(1, 30, 9000).astype(np.uint32), first, np.concatenate(big_h))
+    pb = _params(oa, gb, iter_max=3, min_term_updates=20000)
+    etas = oa.path_linear_sgd_layout_schedule(pb)
+    with oa.LayoutSession(gb, pb) as big:
+        assert big.split_info()["split"], big.split_info()
+        big.upload(*oa.initial_layout(gb, "d", seed=1))
+        gl = graphs("LPA")
+        with oa.LayoutSession(gl, _params(oa, gl, iter_max=2, min_term_updates=5000)) as small:
+            assert small.split_info()["split"]
+            small.upload(*oa.initial_layout(gl, "d", seed=1))
+            small.iteration(1.0, False, 5000)
+            small.sync()
+        big.iteration(etas[0], False, pb.min_term_updates)
+        big.sync()
+        Xb, Yb = big.download()
+        assert np.isfinite(Xb).all() and np.isfinite(Yb).all()
     # one stream, one lane
     g, og = graphs("chr6.C4"), ographs("chr6.C4")   # loops: some terms hit the same node end twice
     X0, Y0 = oa.initial_layout(g, "d", seed=5)
