@@ -297,9 +297,12 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
             fprintf(stderr, "[odgi::layout] error: %s: %s\n", pgsgd_strerror(rc), pgsgd_last_error());
             return finish(1);
         }
-        if (p.progress)
-            fprintf(stderr, "[odgi::layout] %llu term updates in %.1f ms of kernel time (%.3g terms/s) on %u GPU streams\n",
+        if (p.progress) {
+            fprintf(stderr, "[odgi::layout] %llu term updates in %.1f ms of kernel time (%.3g terms/s) on %u GPU streams",
                     (unsigned long long)st.term_updates, st.kernel_ms, st.kernel_ms > 0 ? 1e3 * (double)st.term_updates / st.kernel_ms : 0.0, st.n_streams);
+            if (st.apply_lanes) fprintf(stderr, " (sampling; %u lanes of one workgroup moved the node ends)", st.apply_lanes);
+            fprintf(stderr, "\n");
+        }
     }
 
     if (a.has("stress")) {
