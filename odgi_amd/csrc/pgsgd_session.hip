@@ -731,73 +731,16 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool long_schedule = p->iter_max >= 15;
         if ((force || (cap >= 4 * cu_lanes && long_schedule)) && short_paths && g->n_nodes >= 8ull * s->region && g->n_steps < 0xffffffffull && g->n_nodes < 0x7fffffffull) {
             bpc = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
-            // Steps per tile.  A tile's share of an iteration is q = terms / steps terms per step, drawn by the workgroup's
-            // lanes in trips of `lanes` terms: T = lanes * k / q steps make k full trips.  T is R - R / 8 rounded DOWN to
-            // such a number (q = 10, 256 lanes: 204 steps = eight trips, where 224 made 8.75 and 217, at R = 248, 8.5).
-            // Measured at config 4, R = 248, roofline fraction of the tile kernel for T = 128 / 153 / 179 / 192 / 204 / 217 /
-            // 230: 0.478 / 0.491 / 0.494 / 0.498 / 0.497-0.500 / 0.492 / 0.479 — and 0.494 for 230 with the 500 of 202 927
-            // tiles that no longer fit a window cut in two: longer is not better; a tile that does not fit is a work item
-            // without a window in a launch of its own, and a launch costs a round whatever it holds
-            // (profiles/r03/bench_variants_call26_tile_steps.txt).  A few misfits (at most 1 %) are cut in two, more send
-            // the choice to the next smaller T; graphs with unsorted stretches (no candidate is free of such tiles) and
-            // runs with q < 1 keep T = R - R / 8.
-            std::vector<RawTile> raw;
-            if (!region_given && !steps_given) {
-                const double q = (double)p->min_term_updates / (double)g->n_steps;
-                const uint32_t lanes = s->tile_block;
-                const uint32_t kmax = q >= 1.0 ? (uint32_t)((double)(s->region - s->region / 8) * q / (double)lanes) : 0;
-                for (uint32_t k = kmax, tries = 0; k >= 4 && tries < 3; --k, ++tries) {
-                    const uint32_t T = (uint32_t)((double)lanes * (double)k / q);
-                    if (T < s->region / 2 || T > s->region) break;
-                    std::vector<RawTile> cand = cut_tiles(g, T);
-                    rc = device_tile_stats(s->stream, d_handle, T, cand);
-                    if (rc) return fail(rc);
-                    // a few tiles that do not fit (the first step sits late in its region and the path skips nodes) are cut in
-                    // two; more than 1 % of them means the tile is too long for the graph: the next candidate
-                    auto fits = [&](const RawTile& t) { return (uint64_t)t.rmax < ((uint64_t)(t.rmin / s->region) + 2) * s->region; };
-                    uint64_t misfits = 0;
-                    for (const RawTile& t : cand) misfits += fits(t) ? 0 : 1;
-                    bool all_fit = misfits == 0;
-                    if (!all_fit && misfits * 100 <= cand.size()) {
-                        std::vector<RawTile> split;
-                        split.reserve(cand.size() + misfits);
-                        all_fit = true;
-                        std::vector<uint32_t> ranks;
-                        for (const RawTile& t : cand) {
-                            if (fits(t) || t.n < 2) { split.push_back(t); all_fit = all_fit && fits(t); continue; }
-                            for (int half = 0; half < 2; ++half) {
-                                RawTile h = t;
-                                h.t0 = t.t0 + (half ? t.n / 2 : 0);
-                                h.n = half ? t.n - t.n / 2 : t.n / 2;
-                                ranks.resize(h.n);
-                                for (uint32_t i = 0; i < h.n; ++i) ranks[i] = g->step_handle[h.t0 + i] >> 1;
-                                std::sort(ranks.begin(), ranks.end());
-                                h.rmin = ranks.front();
-                                h.rmax = ranks.back();
-                                h.maxmult = 1;
-                                for (uint32_t i = 0, run = 1; i + 1 < h.n; ++i) {
-                                    run = ranks[i + 1] == ranks[i] ? run + 1 : 1;
-                                    h.maxmult = std::max(h.maxmult, run);
-                                }
-                                all_fit = all_fit && fits(h);
-                                split.push_back(h);
-                            }
-                        }
-                        if (all_fit) cand.swap(split);
-                    }
-                    if (all_fit) {
-                        raw = std::move(cand);
-                        s->tile_steps = T;
-                        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
-                        break;
-                    }
-                }
-            }
-            if (raw.empty()) {
-                raw = cut_tiles(g, s->tile_steps);
-                rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
-                if (rc) return fail(rc);
-            }
+            // Steps per tile: T = R - R / 8.  A tile's share of an iteration is drawn by the workgroup's lanes in trips of 256
+            // terms, and T = 204 (eight full trips at ten terms per step, where 217 makes 8.5 and 224 made 8.75) measured 1 %
+            // faster (tile kernel's roofline fraction at config 4, R = 248, T = 128 / 153 / 179 / 192 / 204 / 217 / 230: 0.478 /
+            // 0.491 / 0.494 / 0.498 / 0.497-0.500 / 0.492 / 0.479, the last with 500 of 202 927 tiles no longer fitting a
+            // window; profiles/r03/bench_variants_call26_tile_steps.txt) — and laid the graphs out 1-4 % worse: 256 lanes on
+            // 408 node ends instead of 448 are denser concurrent updates (final stress at config 4 0.2177 against 0.2148, at
+            // 1e7 nodes 1.08x the per-lane kernel's against 1.04x).  Not taken; PGSGD_TILE_STEPS is the experiment's knob.
+            std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
+            rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
+            if (rc) return fail(rc);
             // experiment knob: "region" = work items in node order, one run per XCD (TileArgs::chunk); measured slower, see group_tiles
             const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");
             HostTiles ht = group_tiles(raw, g->n_nodes, s->region, !(order && !strcmp(order, "region")));
