@@ -537,6 +537,12 @@ def test_synthetic_million_node_properties(oa, orc):
     with oa.LayoutSession(g, p2) as s:
         got = s.trace_terms(True, 4)
     assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p2), p2.seed, 256, 0, True, 4))
+    # the default schedule runs the tile kernel, every tile with a window, and the region size is fitted to the launch: on
+    # MI355X (256 CUs x 4 workgroups) R = 248 makes 2017 / 2016 work items per colour — two full rounds (R = 256: 1953)
+    with oa.LayoutSession(g, _params(oa, g)) as s:
+        info = s.tile_info()
+    assert info["tiled"] and not info["warm_per_lane"] and info["n_nonlocal_tiles"] == 0
+    assert (info["region_nodes"], info["tile_steps"], info["n_work_items"]) == (248, 217, 4033), info
 
 
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
