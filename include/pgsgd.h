@@ -230,6 +230,10 @@ int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int
  * 0.1 — and the iterations before cooling therefore run the per-lane kernel, the cooling ones the tile kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
+/* Region size (nodes) a tiled session takes for a graph of n_nodes nodes when a launch has resident_workgroups workgroups
+ * on the device (MI355X: 256 CUs x 4): the multiple of 8 in [240, 272] whose work items (one per region of a colour) fill
+ * their rounds best, 256 when a launch is a single round or more than eight.  Pure host arithmetic. */
+uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups);
 /* How the session's per-lane launches run: 0 one pass (a lane samples a term and moves its ends), 1 two passes (a small
  * lane-bound graph whose 2N coordinate words fit one compute unit's LDS: pgsgd_session_n_streams() streams sample, one
  * workgroup of *apply_lanes lanes moves the ends in LDS). */

@@ -103,6 +103,7 @@ SIGNATURES = [
     ("pgsgd_session_set_shard", C.c_int, [C.c_void_p, u32, u32, C.c_int]),
     ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_split_info", C.c_int, [C.c_void_p, P(u32)]),
+    ("pgsgd_tile_region_for", u32, [u64, u64]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_from_og", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),

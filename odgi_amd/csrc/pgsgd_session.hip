@@ -265,6 +265,10 @@ static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t
 // Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within
 // 7 %) for which the work items of a launch (one per region of a colour: ceil(regions / 2)) fill their rounds over
 // `slots` resident workgroups best; 256 when one round or more than eight are needed either way (see the caller).
+static uint32_t choose_region(uint64_t n_nodes, uint64_t slots);
+extern "C" uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups) {
+    return n_nodes && resident_workgroups ? choose_region(n_nodes, resident_workgroups) : 256;
+}
 static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
     auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
     const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;

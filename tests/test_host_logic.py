@@ -480,3 +480,20 @@ def test_gfa_lowering_is_the_same_on_one_thread_and_on_many(oa, tmp_path):
     assert np.array_equal(a.node_len, lens)
     assert a.edges.shape == (N - 1, 2) and np.array_equal(a.edges, b.edges)
     assert np.array_equal(a.edges[:3], [[0, 3], [2, 4], [4, 6]])   # 1+ -> 2- (every 97th edge), 2+ -> 3+, 3+ -> 4+
+
+
+def test_tile_region_size_fills_the_rounds_of_a_launch(oa):
+    """A tiled launch hands one work item per region of a colour to the resident workgroups in rounds; the region size is
+    the multiple of 8 near 256 that fills them best (1 953 items at R = 256 are two rounds with the second
+    91 % full, 2 084 at R = 240 a third round for 36 items).  Pure host arithmetic: no GPU."""
+    from odgi_amd._lib import lib
+    f = lib.pgsgd_tile_region_for
+    items = lambda n, r: ((n + r - 1) // r + 1) // 2
+    assert f(1_000_000, 1024) == 248 and items(1_000_000, 248) == 2017           # BASELINE config 4 on MI355X
+    assert f(300_000, 1024) == 256 and f(10_000_000, 1024) == 256                # one round; twenty rounds
+    assert f(0, 1024) == 256 and f(1_000_000, 0) == 256
+    for n in (600_000, 1_500_000, 2_000_000, 3_000_000, 4_000_000):
+        r = f(n, 1024)
+        assert 240 <= r <= 272 and r % 8 == 0
+        fill = lambda rr: items(n, rr) / (1024 * -(-items(n, rr) // 1024))
+        assert all(fill(r) >= fill(c) - 1e-9 for c in range(240, 273, 8)), (n, r)
