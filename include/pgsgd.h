@@ -90,6 +90,10 @@ typedef struct pgsgd_graph_view {
 #define PGSGD_FLAG_NO_SPLIT        0x1000u /* per-lane kernel: never run an iteration in two passes (what small lane-bound graphs     */
                                            /* run by default: every stream the GPU holds samples, one workgroup with the lanes the   */
                                            /* busiest node allows moves the ends in LDS); same streams, same arithmetic, A/B, parity  */
+#define PGSGD_FLAG_EXACT_MATH      0x2000u /* tile kernel: IEEE divisions, the correctly rounded square root and 64-bit path positions   */
+                                           /* in a term's geometry instead of the hardware's reciprocal / reciprocal square root (1 ulp) */
+                                           /* and 32-bit positions: the instance the CPU oracle's mirror reproduces bit for bit (parity  */
+                                           /* tests).  Chosen automatically when a path is 2^32 bp long or longer                        */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -238,6 +242,14 @@ uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups);
  * lane-bound graph whose 2N coordinate words fit one compute unit's LDS: pgsgd_session_n_streams() streams sample, one
  * workgroup of *apply_lanes lanes moves the ends in LDS). */
 int pgsgd_session_split_info(const pgsgd_session* s, uint32_t* apply_lanes);
+/* Which instance of the tile kernel the session runs: 1 = fast math (hardware reciprocal / reciprocal square root, 32-bit
+ * path positions; the default), 0 = exact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more). */
+int pgsgd_session_tile_math(const pgsgd_session* s);
+/* Parity hook: the displacement of n terms by both instances of the tile kernel's geometry, on device `device`:
+ * inputs eta, d[i] (path distance), dx[i], dy[i] (layout difference, bp), cap[i] (learning-rate cap); out_fast / out_exact
+ * [3n] = {r_x, r_y, |Delta|} per term.  The exact form is the oracle's (path_sgd_layout.cpp:280-352 in fp32). */
+int pgsgd_debug_tile_displacement(int device, uint64_t n, float eta, const float* d, const float* dx, const float* dy,
+                                  const float* cap, float* out_fast, float* out_exact);
 /* Multi-GPU exchange between eta steps (or sub-steps); all three run on the session stream.
  *   mark : remember the current coordinates as the exchange base (call once, after upload);
  *   begin: buf[2e..2e+1] = (dx, dy) node end e moved since the base, in bp; buf[4N+e] = dx^2+dy^2;

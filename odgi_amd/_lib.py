@@ -56,6 +56,7 @@ FLAG_ONE_SIDED_FAR = 0x20
 FLAG_HOT_NODE_CAP = 0x40
 FLAG_NO_PIPELINE = 0x80
 FLAG_NO_SPLIT = 0x1000
+FLAG_EXACT_MATH = 0x2000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
@@ -103,6 +104,8 @@ SIGNATURES = [
     ("pgsgd_session_set_shard", C.c_int, [C.c_void_p, u32, u32, C.c_int]),
     ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_split_info", C.c_int, [C.c_void_p, P(u32)]),
+    ("pgsgd_session_tile_math", C.c_int, [C.c_void_p]),
+    ("pgsgd_debug_tile_displacement", C.c_int, [C.c_int, u64, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]),
     ("pgsgd_tile_region_for", u32, [u64, u64]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),

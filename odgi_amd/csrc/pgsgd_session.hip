@@ -110,6 +110,8 @@ struct pgsgd_session {
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
+    uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
+    int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
     // kernel timing: e[0..1] bracket the update kernel; a tile launch also has e[2] (before the drain of the launch
     // before it) and e[3] (after that drain, before its snapshot kernel)
@@ -296,14 +298,17 @@ struct HostTiles {
 };
 
 typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::TileSampler, pgsgd::IterArgs);
-template <int FAR>
+template <int FAR, int MATH>
 static tile_kernel_t tile_kernel_f(bool cooling, bool local) {
     using namespace pgsgd;
-    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true> : sgd_tile_kernel<1, FAR, false, true>;
-    return cooling ? sgd_tile_kernel<1, FAR, true, false> : sgd_tile_kernel<1, FAR, false, false>;
+    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH> : sgd_tile_kernel<1, FAR, false, true, MATH>;
+    return cooling ? sgd_tile_kernel<1, FAR, true, false, MATH> : sgd_tile_kernel<1, FAR, false, false, MATH>;
 }
-static tile_kernel_t tile_kernel(int far, bool cooling = false, bool local = true) {
-    return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided>(cooling, local);
+// math: pgsgd::kMathFast (what sessions run) or kMathExact (PGSGD_FLAG_EXACT_MATH, paths of 2^32 bp and more)
+static tile_kernel_t tile_kernel(int far, int math, bool cooling = false, bool local = true) {
+    if (math == pgsgd::kMathExact)
+        return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathExact>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathExact>(cooling, local);
+    return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathFast>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathFast>(cooling, local);
 }
 
 struct RawTile { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
@@ -684,7 +689,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
         s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
         int bpc = 0;
-        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
         // the hottest node must leave room for at least four workgroups per CU (the occupancy the kernel
         // was validated at); between that and full residency the grid is cut to the hot-node cap
@@ -704,7 +709,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 s->tile_steps = r - r / 8;
                 s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
                 int bpc_r = 0;
-                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_r, tile_kernel(pgsgd::kFarTwoSided), (int)s->tile_block, s->tile_lds));
+                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_r, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
                 if (bpc_r < bpc) {  // (cannot happen at 272 nodes per region with the default bucket count; keep the validated size if it does)
                     s->region = 256;
                     s->tile_steps = 224;
@@ -720,13 +725,17 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool force = pgsgd::debug_env("PGSGD_TILE_FORCE") != nullptr;
         s->tile_forced = force;
         s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
-        bool short_paths = true;
+        bool short_paths = true, paths_32 = true;  // (the fast instance keeps positions as 32-bit words: every path shorter than 2^32 bp)
         for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
             if (g->path_first[q + 1] > g->path_first[q]) {
                 const uint64_t last = g->path_first[q + 1] - 1;
-                short_paths = g->step_pos[last] + g->node_len[g->step_handle[last] >> 1] < (1ull << 52);
+                const uint64_t path_end = g->step_pos[last] + g->node_len[g->step_handle[last] >> 1];
+                short_paths = path_end < (1ull << 52);
+                paths_32 = paths_32 && path_end < (1ull << 32);
             }
+        s->tile_math = ((p->flags & PGSGD_FLAG_EXACT_MATH) || !paths_32) ? pgsgd::kMathExact : pgsgd::kMathFast;
         // A schedule of fewer than 15 iterations runs the per-lane kernel.  The tile kernel gives long-range pairs gentle,
         // averaged pulls while the learning rate is above their distance and needs the schedule's length to bring them
         // home: final sampled stress at config 4, tile kernel / per-lane kernel (the reference's rule), for -x 3 / 5 /
@@ -1210,6 +1219,48 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
     return s->tiled ? (s->warm_per_lane ? 2 : 1) : 0;
 }
 
+extern "C" int pgsgd_session_tile_math(const pgsgd_session* s) {
+    if (!s) return PGSGD_E_INVALID;
+    return s->tile_math;
+}
+
+namespace pgsgd {
+__global__ void tile_displacement_probe_kernel(uint64_t n, float eta, const float* d, const float* dx, const float* dy, const float* cap, float* out_fast, float* out_exact) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float rx, ry, ad;
+    tile_displacement<kMathFast>(eta, d[i], dx[i], dy[i], cap[i], rx, ry, ad);
+    out_fast[3 * i] = rx; out_fast[3 * i + 1] = ry; out_fast[3 * i + 2] = ad;
+    tile_displacement<kMathExact>(eta, d[i], dx[i], dy[i], cap[i], rx, ry, ad);
+    out_exact[3 * i] = rx; out_exact[3 * i + 1] = ry; out_exact[3 * i + 2] = ad;
+}
+}  // namespace pgsgd
+
+extern "C" int pgsgd_debug_tile_displacement(int device, uint64_t n, float eta, const float* d, const float* dx, const float* dy, const float* cap,
+                                             float* out_fast, float* out_exact) {
+    pgsgd::clear_error();
+    if (!n || !d || !dx || !dy || !cap || !out_fast || !out_exact) return PGSGD_E_INVALID;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { set_error("no HIP device"); return PGSGD_E_NODEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    float* buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, 10 * n * sizeof(float)));
+    int rc = PGSGD_OK;
+    const float* in[4] = {d, dx, dy, cap};
+    for (int k = 0; k < 4 && rc == PGSGD_OK; ++k)
+        if (hipMemcpy(buf + k * n, in[k], n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = PGSGD_E_HIP;
+    if (rc == PGSGD_OK) {
+        hipLaunchKernelGGL(pgsgd::tile_displacement_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, eta, buf, buf + n, buf + 2 * n, buf + 3 * n,
+                           buf + 4 * n, buf + 7 * n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = PGSGD_E_HIP;
+    }
+    if (rc == PGSGD_OK && (hipMemcpy(out_fast, buf + 4 * n, 3 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(out_exact, buf + 7 * n, 3 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) rc = PGSGD_E_HIP;
+    (void)hipFree(buf);
+    if (rc) set_error("tile displacement probe failed on the device");
+    return rc;
+}
+
 extern "C" int pgsgd_session_split_info(const pgsgd_session* s, uint32_t* apply_lanes) {
     if (!s) return PGSGD_E_INVALID;
     if (apply_lanes) *apply_lanes = s->split ? s->apply_lanes : 0;
@@ -1400,6 +1451,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
+            ta.wq_threshold = s->tile_wq_threshold;
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;
@@ -1436,7 +1488,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             HIP_TRY(hipEventRecord(ev.e[0], s->stream));
             if (ta.n_items) {
-                hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, true), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, true), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, ta, ts, a);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());
@@ -1448,7 +1500,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
                 tw.queue = s->d_queue + 2 * pgsgd::kItemQueues;
                 tw.chunk[0] = 0;
                 for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) tw.chunk[q] = windowless;  // one run: every workgroup ends up pulling from it
-                hipLaunchKernelGGL(tile_kernel(s->tile_far, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, tw, ts, a);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());

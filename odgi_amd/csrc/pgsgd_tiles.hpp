@@ -99,7 +99,15 @@ __device__ __forceinline__ uint64_t outbox_delta(int32_t qx, int32_t qy) { retur
 __device__ __forceinline__ bool outbox_pack(const Outbox& ob, uint32_t end, int32_t qx, int32_t qy, uint64_t& msg) {
     const uint32_t lim = 1u << (ob.qbits - 1);
     const uint32_t mask = (1u << ob.qbits) - 1u;  // qbits <= 25
-    msg = (uint64_t)(end & ((1u << ob.shift) - 1u)) | ((uint64_t)((uint32_t)qx & mask) << ob.shift) | ((uint64_t)((uint32_t)qy & mask) << (ob.shift + ob.qbits));
+    const uint32_t fx = (uint32_t)qx & mask, fy = (uint32_t)qy & mask, off = end & ((1u << ob.shift) - 1u);
+    if (ob.shift + ob.qbits >= 32u) {  // (wave-uniform; always, but for the experiment knob that narrows the fields) the y field lies
+        // in the high word: five 32-bit operations with scalar shift counts instead of two variable 64-bit shifts
+        const uint32_t lo = off | (fx << ob.shift);
+        const uint32_t hi = (fx >> (32u - ob.shift)) | (fy << (ob.shift + ob.qbits - 32u));
+        msg = (uint64_t)lo | ((uint64_t)hi << 32);
+    } else {
+        msg = (uint64_t)off | ((uint64_t)fx << ob.shift) | ((uint64_t)fy << (ob.shift + ob.qbits));
+    }
     return (((uint32_t)qx + lim) | ((uint32_t)qy + lim)) >> ob.qbits == 0;  // both in [-lim, lim)
 }
 __device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg, uint32_t& end_off) {
@@ -142,6 +150,7 @@ struct TileArgs {
     uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
                                        // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
+    uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
 };
 
@@ -169,24 +178,33 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 // LDS of one workgroup's outbox.  Every bucket has a ring of staged lines: one line for an ordinary bucket, kObRingLines
 // for the kObRings buckets around the workgroup's current window ("hot" rings; ring index kObHot + r).  Slots are claimed
 // from a monotonic head counter: slot s lives in line (s / kObLine) % lines of the ring, round s / (kObLine * lines); a
-// lane may write it once the line is back from its previous round (gen), and the writer that completes a line
-// (done == kObLine) writes it out and reopens it.
+// lane may write it once the line is back from its previous round, and the writer that completes a line writes it out
+// and reopens it.  A line's state word is (rounds completed << kObStateShift) | slots written in the open round.
+//
+// In front of the rings every WAVE keeps a private queue of packed messages (kWqCap entries: message word + bucket byte).
+// A term appends its message there — a ballot, a prefix count and two LDS stores, the fill count lives in a scalar
+// register — and the ring protocol below runs only when 64 messages are waiting, one per lane: its cost does not depend
+// on how many lanes take part (about a hundred vector instructions per call), and in most iterations only a third of the
+// lanes have a message per trip (a step that rounds to no quantum sends nothing).
+constexpr uint32_t kObStateShift = 4;                 // (kObLine = 8 slots < 1 << 4)
+constexpr uint32_t kWqCap = 128;                      // fewer than 64 waiting + at most 64 appended per call
 struct OutboxLds {
     uint64_t* stage;  // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
     uint32_t* head;   // [B + kObRings] slots claimed
-    uint32_t* done;   // [B + kObRings * kObRingLines] slots written, per line
-    uint32_t* gen;    // [B + kObRings * kObRingLines] rounds completed, per line
+    uint32_t* state;  // [B + kObRings * kObRingLines] per line: (rounds completed << kObStateShift) | slots written
     uint32_t* line;   // [B] (first chunk of the open group << 10) | lines claimed in the group
     uint32_t* chunk0; // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
     uint2* list;      // [waves][64] lines completed in one round of one wave: {staged line, global line index}
+    uint64_t* wq_msg; // [waves][kWqCap] the waves' private queues: packed messages ...
+    uint8_t* wq_b;    // [waves][kWqCap] ... and their buckets
     uint32_t n_buckets;
     uint32_t ring_b0; // bucket of hot ring 0 (the window's), wave-uniform
 };
 
 __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
     const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
-    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * 64 * sizeof(uint2) +
-           ((size_t)n_buckets + kObRings + 2 * lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
+    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * 64 * sizeof(uint2) + (size_t)kTileWaves * kWqCap * (sizeof(uint64_t) + 1) +
+           ((size_t)n_buckets + kObRings + lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
 }
 
 // The next line of bucket b in the workgroup's current group of chunks (a new group when that one is full).  Several
@@ -226,15 +244,10 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
     }
 }
 
-// Append one message per lane that has one.  Called by all 64 lanes of a wave together (converged).
-__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t end, int32_t qx, int32_t qy) {
+// Stage one packed message per lane that has one (bucket b), writing out every line this completes.  Called by all 64
+// lanes of a wave together (converged).
+__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t b, uint64_t packed) {
     if (!__ballot(has)) return;
-    const uint32_t b = end >> ob.shift;
-    uint64_t packed = 0;
-    if (has && !outbox_pack(ob, end, qx, qy, packed)) {  // a step too wide for the packed form (never seen with the far cap): the
-        atomicAdd(ob.spill + end, (unsigned long long)outbox_delta(qx, qy));  // spill words, which the drain adds with the messages
-        has = false;
-    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     const uint32_t r = b - L.ring_b0;  // hot ring of the bucket, if it has one
@@ -262,10 +275,10 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
     do {
         bool completes = false;
         // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out)
-        if (pending && __hip_atomic_load(L.gen + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == round) {
+        if (pending && (__hip_atomic_load(L.state + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kObStateShift) == (round & (0xffffffffu >> kObStateShift))) {
             L.stage[src * kObLine + slot % kObLine] = packed;
             pending = false;
-            completes = atomicAdd(L.done + src, 1u) + 1 == kObLine;  // the last of the line's writers writes it out
+            completes = ((atomicAdd(L.state + src, 1u) + 1u) & ((1u << kObStateShift) - 1u)) == kObLine;  // the last of the line's writers writes it out
         } else if (pending) {
             __builtin_amdgcn_s_sleep(2);  // waiting for another wave to write a line out: leave it the issue slots
         }
@@ -297,12 +310,48 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            if (completes) {  // reopen the line for its next round
-                __hip_atomic_store(L.done + src, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(L.gen + src, round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            if (completes)  // reopen the line for its next round
+                __hip_atomic_store(L.state + src, (round + 1u) << kObStateShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } while (__ballot(pending));
+}
+
+// A wave's private message queue in front of outbox_push (see OutboxLds).  `n` is the wave's fill count: wave-uniform,
+// kept in a scalar register by its callers (it only ever changes by ballot counts).
+struct WaveQueue {
+    uint64_t* msg;
+    uint8_t* b;
+};
+// append one message per lane that has one; a step too wide for the packed form (never seen with the far cap) goes
+// straight to the spill words, which the drain adds with the messages
+__device__ __forceinline__ void wq_append(const Outbox& ob, const WaveQueue& q, uint32_t& n, bool has, uint32_t end, int32_t qx, int32_t qy) {
+    if (!__ballot(has)) return;
+    uint64_t packed = 0;
+    const bool fits = outbox_pack(ob, end, qx, qy, packed);
+    if (has && !fits) atomicAdd(ob.spill + end, (unsigned long long)outbox_delta(qx, qy));
+    has = has && fits;
+    const uint64_t m = __ballot(has);  // (taken by the whole wave, outside the branch: the fill count must stay wave-uniform)
+    const uint32_t idx = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (has) {
+        q.msg[idx] = packed;
+        q.b[idx] = (uint8_t)(end >> ob.shift);
+    }
+    n += (uint32_t)__popcll(m);
+}
+// hand the last min(n, 64) queued messages to the rings, one per lane (the wave's LDS operations execute in order: what
+// wq_append stored is what this reads)
+__device__ __forceinline__ void wq_push(const Outbox& ob, const OutboxLds& L, const WaveQueue& q, uint32_t& n) {
+    const uint32_t take = n < 64u ? n : 64u, lane = threadIdx.x & 63u;
+    const bool has = lane < take;
+    const uint32_t idx = n - take + lane;
+    uint64_t packed = 0;
+    uint32_t b = 0;
+    if (has) {
+        packed = q.msg[idx];
+        b = q.b[idx];
+    }
+    n -= take;
+    outbox_push(ob, L, has, b, packed);
 }
 
 // Write out the partly filled line of every ring in [first, first + count) (ring index: bucket, or n_buckets + r for a
@@ -341,13 +390,9 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
         const uint32_t ring = first + i;
         L.head[ring] = 0;
         if (ring < L.n_buckets) {
-            L.done[ring] = 0;
-            L.gen[ring] = 0;
+            L.state[ring] = 0;
         } else {
-            for (uint32_t l = 0; l < kObRingLines; ++l) {
-                L.done[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
-                L.gen[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
-            }
+            for (uint32_t l = 0; l < kObRingLines; ++l) L.state[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
         }
     }
 }
@@ -441,6 +486,65 @@ __device__ __forceinline__ uint32_t zipf_tile(Xoshiro256Plus& g, const TileSampl
     return r;
 }
 
+// The Zipf/uniform coin of a warm iteration (path_sgd_layout.cpp:205) is drawn once per WAVE and TRIP, not per lane:
+// the 64 terms a wave draws in one trip all take a Zipf partner or all a uniform one, so the wave runs one of the two
+// partner paths instead of both under divergence (the Zipf draw is ~55 vector instructions, the uniform one ~40, and the
+// kernel is bound by vector issue).  Every term is still a Zipf term with probability 1/2, independently of every term
+// outside its wave's trip and of its own other draws — the reference's marginal distribution of terms; bit 31 of the
+// term's first word, the per-lane coin of rounds 2 and 3, is ignored.  The coins of wave w of a tile are a SplitMix64
+// stream seeded like a lane's generator with lane id 1023 - w (lane ids stop at 255): trip j takes bit j % 64 of output
+// number j / 64.  The oracle draws the same coins (orc_tile_wave_coin).
+static_assert(kTileBlock <= 1020, "lane ids must stay clear of the wave coin streams");
+__host__ __device__ inline uint64_t tile_coin_seed(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave) {
+    return seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (1023u - wave));
+}
+
+// MATH: kMathFast is the instance sessions run — the term's geometry with the hardware's reciprocal and reciprocal
+// square root (1 ulp each, tile_displacement) and path positions as 32-bit words (every path shorter than 2^32 bp);
+// kMathExact keeps the IEEE divisions and the correctly rounded square root of the per-lane kernel and 64-bit
+// positions: bit for bit the oracle's mirror (PGSGD_FLAG_EXACT_MATH; the one-lane mirror tests; paths of 2^32 bp or more).
+constexpr int kMathExact = 0, kMathFast = 1;
+// The displacement of one term of the tile kernel (path_sgd_layout.cpp:280-352) from its path distance d, already a
+// float, and dx, dy = p_a - p_b in bp.  kMathExact: the operations of term_displacement(), bit for bit.  kMathFast:
+//   mu = min(eta * rcp(d), cap),  r = Delta / mag = (mu / 2) * (1 - d * rsq(dx^2 + dy^2)),  |Delta| = |r| * mag
+// — one v_rcp_f32 and one v_rsq_f32 (1 ulp each) where the exact form takes two IEEE divisions and a correctly rounded
+// square root (38 instructions).  r differs from the exact form's by at most ~4e-7 * mu / 2 in absolute terms (the
+// cancellation in 1 - d / mag is taken in fp32 in both forms), i.e. a displacement error below 2^-21 of the pair's
+// layout distance — tests/test_gpu_parity.py measures it on the device against the exact instance.
+template <int MATH>
+__device__ __forceinline__ void tile_displacement(float eta, float d, float dx, float dy, float mu_cap, float& r_x, float& r_y, float& abs_delta) {
+    if (d == 0.0f) d = 1e-9f;
+    if (dx == 0.0f) dx = 1e-9f;
+    const float dx2 = dx * dx;
+    const float dy2 = dy * dy;
+    if (MATH == kMathFast) {
+        float mu = eta * __builtin_amdgcn_rcpf(d);
+        if (mu > mu_cap) mu = mu_cap;
+        const float s = dx2 + dy2;
+        const float rs = __builtin_amdgcn_rsqf(s);
+        const float r = (0.5f * mu) * __builtin_fmaf(-d, rs, 1.0f);
+        abs_delta = fabsf(r) * (s * rs);
+        r_x = r * dx;
+        r_y = r * dy;
+    } else {
+        const float w = 1.0f / d;
+        float mu = eta * w;
+        if (mu > mu_cap) mu = mu_cap;
+        const float mag = sqrtf(dx2 + dy2);
+        const float Delta = (mu * (mag - d)) / 2.0f;
+        abs_delta = fabsf(Delta);
+        const float r = Delta / mag;
+        r_x = r * dx;
+        r_y = r * dy;
+    }
+}
+// (float)(a - b) of two unsigned 32-bit fields: magnitude and sign apart — the difference is exact as an unsigned
+// integer and is rounded once, to nearest even, which is symmetric in the sign: the bits of (float)((int64_t)a - (int64_t)b)
+__device__ __forceinline__ float field_diff(uint32_t a, uint32_t b) {
+    const float m = (float)(a > b ? a - b : b - a);
+    return a >= b ? m : -m;
+}
+
 // The stage registers of the term loop.  Every VGPR a stage keeps across a trip is held twice (two alternating sets, see the
 // loop), and the kernel's occupancy is set by its VGPRs (round 2: 110 -> 4 waves per SIMD), so a stage keeps only
 // what cannot be had again for a few instructions: step offsets instead of step records (the records are re-read from
@@ -473,7 +577,7 @@ struct PendingTerm {
 #ifndef PGSGD_TILE_WAVES
 #define PGSGD_TILE_WAVES 5
 #endif
-template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int ABL = 0>
+template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, int ABL = 0>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
@@ -483,14 +587,21 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     {
         const size_t lines = (size_t)L.n_buckets + kObRings * kObRingLines;
         L.stage = reinterpret_cast<uint64_t*>(trec + ta.tile_steps);
-        L.list = reinterpret_cast<uint2*>(L.stage + lines * kObLine);
+        L.wq_msg = L.stage + lines * kObLine;
+        L.list = reinterpret_cast<uint2*>(L.wq_msg + kTileWaves * kWqCap);
         L.head = reinterpret_cast<uint32_t*>(L.list + kTileWaves * 64);
-        L.done = L.head + L.n_buckets + kObRings;
-        L.gen = L.done + lines;
-        L.line = L.gen + lines;
+        L.state = L.head + L.n_buckets + kObRings;
+        L.line = L.state + lines;
         L.chunk0 = L.line + L.n_buckets;
-        for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + 2 * lines; i += blockDim.x) L.head[i] = 0;
+        L.wq_b = reinterpret_cast<uint8_t*>(L.chunk0 + L.n_buckets);
+        for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + lines; i += blockDim.x) L.head[i] = 0;
     }
+    // this wave's message queue; its fill count is wave-uniform and lives in a scalar register
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveQueue wq;
+    wq.msg = L.wq_msg + wave * kWqCap;
+    wq.b = L.wq_b + wave * kWqCap;
+    uint32_t wq_n = 0;
     L.ring_b0 = 0x7fffffffu;
     __shared__ uint32_t s_item;
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
@@ -558,6 +669,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
             if (worker) rng.seed(tile_stream_seed(ta.seed_base, a.epoch, ti, threadIdx.x));
+            uint64_t coin_x = tile_coin_seed(ta.seed_base, a.epoch, ti, wave);   // (scalar registers: the wave's coin stream)
+            uint64_t coin_cur = COOLING ? 0ull : Xoshiro256Plus::splitmix64(coin_x);
             // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and two trips more
             // than the longest lane needs.  Every trip finishes term j - 2, draws the partner of term j - 1 (and requests
             // its record) and picks the first step of term j (and requests its Zipf table entry): whatever a trip loads
@@ -589,8 +702,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 Kw.ka = kNoTerm;
                 Kw.flags = 0;
                 if (worker && j < trips && threadIdx.x + j * lanes < n_tile_terms) {
-                    // first step: uniform inside the tile; the reference's coins (path_sgd_layout.cpp:205-206) from the same word
+                    // first step: uniform inside the tile; the reference's coins (path_sgd_layout.cpp:206,253,262) from the same word
                     Kw.ka = below32_hi(rng, t.n, Kw.flags);
+                    // the Zipf/uniform coin (:205) is the wave's for this trip (tile_coin_seed); it rides in bit 31 of the flags
+                    if (!COOLING) Kw.flags = (Kw.flags & 0x7fffffffu) | ((uint32_t)(coin_cur >> (j & 63u)) << 31);
                     uint32_t s_rank;
                     bool zipf, back;
                     const uint32_t jump = jump_of(Kw.ka, Kw.flags, s_rank, zipf, back);
@@ -638,10 +753,21 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     const uint4 ra = trec[Qr.ka];
                     uint4 rb = Qr.rb_g;
                     if (!from_global) rb = trec[Qr.kb_off];
-                    // the path position moves to the chosen end of each node (:242-269)
-                    uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32), pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
-                    if (flip_a) pos_a += ra.y;
-                    if (flip_b) pos_b += rb.y;
+                    // the path position moves to the chosen end of each node (:242-269); d = |pos_a - pos_b| as a float
+                    float d;
+                    if (MATH == kMathFast) {  // every path is shorter than 2^32 bp: 32-bit positions, the same float
+                        const uint32_t pa = ra.z + (flip_a ? ra.y : 0u), pb = rb.z + (flip_b ? rb.y : 0u);
+                        d = (float)(pa > pb ? pa - pb : pb - pa);
+                    } else {
+                        uint64_t pos_a = (uint64_t)ra.z | ((uint64_t)ra.w << 32), pos_b = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+                        if (flip_a) pos_a += ra.y;
+                        if (flip_b) pos_b += rb.y;
+                        // positions are below 2^52 (checked when the session is created), so the distance converts to fp64 exactly
+                        // from its two halves and is rounded once on the way to fp32: the bits of (float)(uint64_t)
+                        const int64_t diff = (int64_t)pos_a - (int64_t)pos_b;
+                        const uint64_t ad = (uint64_t)(diff < 0 ? -diff : diff);
+                        d = (float)((double)(uint32_t)(ad >> 32) * 4294967296.0 + (double)(uint32_t)ad);
+                    }
                     end_a = ra.x ^ flip_a;
                     end_b = rb.x ^ flip_b;
                     // ends inside the staged window live in LDS (unsigned compare covers "below the window")
@@ -658,13 +784,11 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         wa = load_word<COORD_LOAD>(c.coords, end_a);
                         wb = from_global ? Qr.snapw : load_word<COORD_LOAD>(c.coords, end_b);
                     }
-                    // (float)(a - b) of two 32-bit fields, through fp64: the difference is exact there and is rounded once, as
-                    // the conversion from a 64-bit integer is — four instructions instead of fifteen
-                    const float dx = (float)((double)(uint32_t)wa - (double)(uint32_t)wb) * c.xf.inv_scale;
-                    const float dy = (float)((double)(uint32_t)(wa >> 32) - (double)(uint32_t)(wb >> 32)) * c.xf.inv_scale;
+                    const float dx = field_diff((uint32_t)wa, (uint32_t)wb) * c.xf.inv_scale;
+                    const float dy = field_diff((uint32_t)(wa >> 32), (uint32_t)(wb >> 32)) * c.xf.inv_scale;
                     float r_x, r_y, abs_delta;
                     const bool one_sided = FAR == kFarExclusive && !in_b;
-                    term_displacement<true>(a.eta, pos_a, pos_b, dx, dy, r_x, r_y, abs_delta, (in_b || one_sided) ? 1.0f : far_mu_cap);
+                    tile_displacement<MATH>(a.eta, d, dx, dy, (in_b || one_sided) ? 1.0f : far_mu_cap, r_x, r_y, abs_delta);
                     if (one_sided) {
                         r_x *= 2.0f;
                         r_y *= 2.0f;
@@ -694,11 +818,17 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 if (ABL == 1) msg_a = msg_b = false;  // profiling instance: far updates are dropped (results invalid)
                 return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
             };
+            // messages wait in the wave's queue; the rings' protocol runs when 64 are there, one per lane
             auto send = [&](const FarMessages m) {
-                outbox_push(ta.ob, L, m.to_b, m.end_b, m.qx, m.qy);
-                if (!LOCAL) outbox_push(ta.ob, L, m.to_a, m.end_a, -m.qx, -m.qy);
+                wq_append(ta.ob, wq, wq_n, m.to_b, m.end_b, m.qx, m.qy);
+                if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
+                if (!LOCAL) {
+                    wq_append(ta.ob, wq, wq_n, m.to_a, m.end_a, -m.qx, -m.qy);
+                    if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
+                }
             };
             for (uint32_t j = 0; j <= trips + 1; j += 2) {  // (a trip past the end finds nothing valid and does nothing)
+                if (!COOLING && j && !(j & 63u)) coin_cur = Xoshiro256Plus::splitmix64(coin_x);  // the wave's next 64 coins
                 // one trip: everything the previous trip requested is consumed FIRST (one wait, for loads that have been
                 // in flight for a whole trip), then this trip's requests go out, then its messages
                 FarMessages m = finish_stage(Q1);   // term j - 2
@@ -733,6 +863,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 }
             }
         }
+        // what still waits in the wave's queue goes to the rings while the hot ones are bound to this window
+        while (wq_n) wq_push(ta.ob, L, wq, wq_n);
         __syncthreads();
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
@@ -877,12 +1009,15 @@ __global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile
     if (lane >= lanes) return;
     Xoshiro256Plus rng;
     rng.seed(tile_stream_seed(seed_base, a.epoch, tile_index, lane));
-    for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
+    uint64_t coin_x = tile_coin_seed(seed_base, a.epoch, tile_index, lane >> 6), coin_cur = 0;  // the coins of the lane's wave
+    uint64_t j = 0;
+    for (uint64_t q = term_begin + lane; q < term_end; q += lanes, ++j) {
+        if (!(j & 63u)) coin_cur = Xoshiro256Plus::splitmix64(coin_x);
         uint32_t flags;
         const uint64_t k = t.t0 + below32_hi(rng, t.n, flags);
         const uint64_t s_rank = k - pstart;
         uint64_t b_rank;
-        if (a.cooling || (flags >> 31)) {
+        if (a.cooling || ((coin_cur >> (j & 63u)) & 1u)) {
             const bool back = (s_rank > 0 && ((flags >> 30) & 1u)) || s_rank == cnt - 1;
             const uint64_t room = back ? s_rank : cnt - s_rank - 1;
             const uint64_t jump = c.space < room ? c.space : room;

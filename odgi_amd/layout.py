@@ -196,7 +196,8 @@ class LayoutSession:
         structure, so the iterations before cooling run the per-lane kernel)."""
         a, b, c_, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
         on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
-        return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value)
+        return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value,
+                    fast_math=lib.pgsgd_session_tile_math(self._h) == 1)
 
     def split_info(self):
         """dict(split, apply_lanes): whether per-lane iterations run in two passes (a small lane-bound graph: n_streams

@@ -204,8 +204,17 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
     return X, Y, d.value, ck
 
 
-TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS = 1, 2, 4, 8, 16
-TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS   # the launch order and far-pull policy of round 2
+TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN = 1, 2, 4, 8, 16, 32
+TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN   # the launch order, far-pull policy and per-lane coin of round 2
+TILE_ROUND3 = TILE_LANE_COIN   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane
+
+
+def tile_wave_coin(seed_base, epoch, tile, wave, trip):
+    """The Zipf/uniform coin that the lanes of one wave of a tile share in one trip of a warm iteration."""
+    f = lib().orc_tile_wave_coin
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]
+    f.restype = C.c_int
+    return int(f(int(seed_base), int(epoch), int(tile), int(wave), int(trip)))
 
 
 def tile_layout_q32(g, p, seed_base, tiles, items, region, X, Y, x_off, y_off, quanta_per_bp, policy=0, stop_after=0):

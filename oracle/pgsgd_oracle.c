@@ -212,9 +212,32 @@ static void orc_sample_partner(const orc_graph* g, const orc_params* p, const do
  *           bits 27..14 / 13..0 rounding dither of the x / y step
  *   word 2  Zipf: the generate_canonical variate; uniform partner (:235-237): Lemire on bits 63..32 over the path's
  *           step count
- * A lane's stream yields its terms' words in term order.  tests/test_oracle.py compares the distribution of these
- * terms with orc_sample_partner's. */
+ * A lane's stream yields its terms' words in term order.  tests/test_oracle_pins.py compares the distribution of these
+ * terms with orc_sample_partner's.
+ * Round 4: the Zipf/uniform coin (:205) is no longer bit 31 of the lane's word but the WAVE's coin for the trip — the
+ * 64 terms that lanes 64w .. 64w+63 of a tile draw in their j-th trip share it (pgsgd_tiles.hpp: tile_coin_seed), so that
+ * a wavefront runs one of the two partner paths.  Every term is still a Zipf term with probability 1/2.  The coins of
+ * wave w are a SplitMix64 stream seeded like a lane's generator with lane id 1023 - w: trip j takes bit j % 64 of output
+ * number j / 64.  coin < 0 (ORC_TILE_LANE_COIN, the vectors committed in rounds 2 and 3): the lane's own bit 31. */
 typedef struct orc_tile_pick { orc_anchor an; int zipf, back; uint64_t jump; uint32_t flags; } orc_tile_pick;
+
+static uint64_t orc_splitmix64(uint64_t* x) {
+    uint64_t z = (*x += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+int orc_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip) {
+    uint64_t x = seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (uint64_t)(1023u - wave));
+    uint64_t w = 0;
+    for (uint64_t k = 0; k <= trip / 64; ++k) w = orc_splitmix64(&x);
+    return (int)((w >> (trip % 64)) & 1u);
+}
+/* the same coins in trip order without the restart: *x is the stream's state (start it at the seed), *w the current word */
+static int orc_tile_wave_coin_next(uint64_t* x, uint64_t* w, uint64_t trip) {
+    if (trip % 64 == 0) *w = orc_splitmix64(x);
+    return (int)((*w >> (trip % 64)) & 1u);
+}
 
 static uint32_t orc_below32_hi(uint64_t s[4], uint32_t range, uint32_t* low_half) {
     uint64_t w = orc_rng_next(s);
@@ -230,13 +253,13 @@ static uint32_t orc_below32_hi(uint64_t s[4], uint32_t range, uint32_t* low_half
     return (uint32_t)(m >> 32);
 }
 
-static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int cooling, uint64_t t0, uint32_t tn, uint32_t path,
+static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int cooling, int coin, uint64_t t0, uint32_t tn, uint32_t path,
                                 uint64_t s[4], orc_tile_pick* pk) {
     pk->an.pstart = g->path_first[path];
     pk->an.cnt = g->path_first[path + 1] - pk->an.pstart;
     pk->an.k = t0 + orc_below32_hi(s, tn, &pk->flags);
     pk->an.s_rank = pk->an.k - pk->an.pstart;
-    pk->zipf = cooling || (pk->flags >> 31);                                                  /* :205 */
+    pk->zipf = cooling || (coin < 0 ? (int)(pk->flags >> 31) : coin);                          /* :205 */
     pk->back = 0;
     pk->jump = 0;
     if (pk->zipf) {
@@ -472,9 +495,10 @@ uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_b
     for (uint32_t lane = 0; lane < lanes; ++lane) {
         uint64_t s[4];
         orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | lane), s);
-        for (uint64_t q = term_begin + lane; q < term_end; q += lanes) {
+        uint64_t cx = seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (uint64_t)(1023u - lane / 64)), cw = 0, trip = 0;
+        for (uint64_t q = term_begin + lane; q < term_end; q += lanes, ++trip) {
             orc_tile_pick cur;
-            orc_tile_pick_first(g, p, cooling, t0, n, path, s, &cur);
+            orc_tile_pick_first(g, p, cooling, orc_tile_wave_coin_next(&cx, &cw, trip), t0, n, path, s, &cur);
             orc_term t;
             orc_tile_partner(g, p, zetas, &cur, s, &t);
             uint64_t* o = out + (q - term_begin) * 4;
@@ -1193,6 +1217,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *   ORC_TILE_SNAPSHOT_PASS  partners outside a window are read from a snapshot of ALL coordinates taken once per iteration
  *                           (sharded sessions; round 2), not from words the tiles rewrite for their own steps
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
+ *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
  * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
 void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
@@ -1286,9 +1311,11 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                     for (uint32_t l = 0; l < lanes; ++l)
                         orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + (((uint64_t)ti << 10) | l), streams + 4 * (size_t)l);
                     for (uint64_t q = term_begin; q < term_end; ++q) {
-                        uint64_t* s = streams + 4 * (size_t)((q - term_begin) % lanes);
+                        const uint32_t lane = (uint32_t)((q - term_begin) % lanes);
+                        uint64_t* s = streams + 4 * (size_t)lane;
                         orc_tile_pick cur;
-                        orc_tile_pick_first(g, p, cooling, t0[ti], tn[ti], tpath[ti], s, &cur);
+                        const int coin = (policy & ORC_TILE_LANE_COIN) ? -1 : orc_tile_wave_coin(seed_base, epoch, ti, lane / 64, (q - term_begin) / lanes);
+                        orc_tile_pick_first(g, p, cooling, coin, t0[ti], tn[ti], tpath[ti], s, &cur);
                         orc_term t;
                         orc_tile_partner(g, p, zetas, &cur, s, &t);
                         const uint64_t ea = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;

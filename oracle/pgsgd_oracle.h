@@ -76,6 +76,8 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
 uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
                         uint64_t steps_total, uint64_t tile, uint32_t lanes, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path,
                         int cooling, uint64_t* out);
+/* the Zipf/uniform coin the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration */
+int orc_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip);
 /* fp32 mirror of the device arithmetic; bit-exact with the GPU for n_streams == 1 */
 void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t seed,
                             uint32_t n_streams, uint32_t stream_offset, int hogwild_stores, uint32_t terms_per_anchor,
@@ -89,6 +91,7 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 #define ORC_TILE_NO_FLUSH 4u
 #define ORC_TILE_CONSTANT_RELAX 8u
 #define ORC_TILE_SNAPSHOT_PASS 16u
+#define ORC_TILE_LANE_COIN 32u
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
                          const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,

@@ -47,5 +47,17 @@ out.update({f"tile_mirror/{k}": v for k, v in tile_mirror_case(orc, pyref).items
 # the same case in round 2's launch order (far pulls delivered right after their launch, two snapshots per warm
 # iteration): the vectors committed in round 2 as tile_mirror/*, unchanged
 out.update({f"tile_mirror_r2/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_ROUND2).items()})
-np.savez_compressed(os.path.join(GOLDEN, "golden_vectors.npz"), **out)
+# ... and with round 3's pipeline (today's launch order, the Zipf/uniform coin of a warm term per lane instead of per
+# wave and trip): the vectors committed in round 3 as tile_mirror/*, unchanged
+out.update({f"tile_mirror_r3/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_ROUND3).items()})
+# a regeneration may add arrays and replace tile_mirror/* when the shipped pipeline changes; everything else must come
+# out as committed
+path = os.path.join(GOLDEN, "golden_vectors.npz")
+if os.path.exists(path):
+    old = np.load(path)
+    for k in old.files:
+        if k.startswith("tile_mirror/"):
+            continue
+        assert k in out and np.array_equal(old[k], out[k]), f"{k} changed"
+np.savez_compressed(path, **out)
 print("wrote", len(out), "arrays")

@@ -8,6 +8,8 @@ stress tolerance stated in each test.
 import os
 import sys
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -1195,11 +1197,14 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     g = oa.Graph.synthetic(3000, 4, seed=3) if graph_name == "synthetic" else _ragged_graph(oa) if graph_name == "ragged" else graphs("DRB1-3123")
     og = orc.Graph.from_product(g)
     X0, Y0 = oa.initial_layout(g, "d", seed=5)
-    p = _params(oa, g, iter_max=6, min_term_updates=(20 if graph_name == "ragged" else 2) * g.n_steps)
+    from odgi_amd import _lib
+    # the exact instance of the kernel's geometry (IEEE divisions, correctly rounded square root): the mirror's bits.  The
+    # instance sessions run by default differs from it by an ulp here and there: test_tile_kernel_fast_math_* below
+    p = _params(oa, g, iter_max=6, min_term_updates=(20 if graph_name == "ragged" else 2) * g.n_steps, flags=_lib.FLAG_EXACT_MATH)
     etas = oa.path_linear_sgd_layout_schedule(p)
     with oa.LayoutSession(g, p) as s:
         info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
-        assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64
+        assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64 and not info["fast_math"]
         assert (info["n_nonlocal_tiles"] == 0) == (graph_name != "DRB1-3123")
         assert len(items["local"]) == info["n_work_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
         # the product's tile table and work items are exactly the independent restatement's (tests/pyref.py)
@@ -1234,6 +1239,89 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     assert dmax_g == dmax_o
     sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
     assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1])) == (int(ck[2]), int(ck[3]))
+
+
+def test_tile_kernel_fast_math_displacement_within_tolerance(oa):
+    """The instance of the tile kernel sessions run computes a term's displacement with v_rcp_f32 / v_rsq_f32 (1 ulp each)
+    as r = (mu / 2) (1 - d rsq(dx^2 + dy^2)); the exact instance (the oracle's operations: two IEEE divisions, a correctly
+    rounded square root) is what the mirror tests pin.  Stated tolerance, measured here on the device over the ranges a
+    layout sees: |r_fast - r_exact| * mag <= 2^-21 * (mu / 2) * max(mag, d) per axis-free displacement, and |Delta| within
+    the same bound — i.e. a term moves its ends to within 5e-7 of the pair's own scale of where the reference's fp32
+    arithmetic would put them (the fixed-point quantum of a 3e7-bp layout is 6e-2 bp)."""
+    from odgi_amd import _lib
+    lib = _lib.lib
+    rs = np.random.RandomState(11)
+    n = 1 << 20
+    d = np.exp(rs.uniform(0, np.log(3e7), n)).astype(np.float32)
+    d[: n // 64] = np.round(d[: n // 64])                      # integers, as path distances are
+    d[n // 64: n // 32] = 1e-9                                 # the reference's stand-in for a zero distance
+    ang = rs.uniform(0, 2 * np.pi, n)
+    mag = (d.astype(np.float64) * np.exp(rs.normal(0, 1.0, n)))  # layout distance around the path distance
+    mag[n // 2:] = d[n // 2:] * (1 + rs.normal(0, 1e-3, n - n // 2))   # converged pairs: the cancellation regime
+    dx, dy = (mag * np.cos(ang)).astype(np.float32), (mag * np.sin(ang)).astype(np.float32)
+    dx[: 1000] = 0.0                                           # the reference's dx == 0 rule
+    cap = np.where(rs.rand(n) < 0.5, 1.0, rs.uniform(0.01, 1.0, n)).astype(np.float32)
+    fp = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(_lib.P(C.c_float))
+    for eta in (1e12, 1e6, 1e2, 1e-2):
+        fast, exact = np.zeros(3 * n, dtype=np.float32), np.zeros(3 * n, dtype=np.float32)
+        rc = lib.pgsgd_debug_tile_displacement(0, n, C.c_float(eta), fp(d), fp(dx), fp(dy), fp(cap), fast.ctypes.data_as(_lib.P(C.c_float)),
+                                               exact.ctypes.data_as(_lib.P(C.c_float)))
+        assert rc == 0
+        fast, exact = fast.reshape(-1, 3).astype(np.float64), exact.reshape(-1, 3).astype(np.float64)
+        assert np.all(np.isfinite(fast)) and np.all(np.isfinite(exact))
+        dd = np.where(d == 0, 1e-9, d).astype(np.float64)
+        mu = np.minimum(eta / dd, cap)
+        m = np.hypot(np.where(dx == 0, 1e-9, dx).astype(np.float64), dy.astype(np.float64))
+        scale = 0.5 * mu * np.maximum(m, dd)
+        tol = 2.0 ** -21 * scale + 1e-30
+        err_vec = np.hypot(fast[:, 0] - exact[:, 0], fast[:, 1] - exact[:, 1])
+        err_abs = np.abs(fast[:, 2] - exact[:, 2])
+        assert np.all(err_vec <= tol), (eta, float((err_vec / tol).max()))
+        assert np.all(err_abs <= tol), (eta, float((err_abs / tol).max()))
+        # and against the fp64 formula both forms are as close as fp32 allows
+        r64 = 0.5 * mu * (1 - dd / m)
+        assert np.all(np.abs(np.hypot(fast[:, 0], fast[:, 1]) - np.abs(r64) * m) <= 2.0 ** -20 * scale + 1e-30)
+        print(f"eta {eta:g}: max |fast - exact| / tolerance {float((err_vec / tol).max()):.3f}")
+
+
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123"])
+def test_tile_kernel_fast_math_one_lane_stays_within_tolerance_of_the_mirror(oa, orc, graphs, graph_name, monkeypatch):
+    """The shipped (fast-math) instance as a sequential program — one workgroup, one lane per tile — against the oracle's
+    mirror: the same terms (the sampler is integer / fp64 work and stays bit-exact), displacements that differ by an ulp
+    here and there, i.e. by a quantum in a few steps.  Tolerance: exact term accounting and checksums, every coordinate
+    within 1e-3 of the layout's extent of the mirror's, sampled stress within 1 %."""
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
+    monkeypatch.setenv("PGSGD_TILE_REGION", "64")
+    monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")
+    monkeypatch.setenv("PGSGD_TILE_GRID", "1")
+    monkeypatch.setenv("PGSGD_TILE_LANES", "1")
+    g = oa.Graph.synthetic(3000, 4, seed=3) if graph_name == "synthetic" else graphs("DRB1-3123")
+    og = orc.Graph.from_product(g)
+    X0, Y0 = oa.initial_layout(g, "d", seed=5)
+    p = _params(oa, g, iter_max=6, min_term_updates=2 * g.n_steps)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    with oa.LayoutSession(g, p) as s:
+        info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
+        assert info["tiled"] and info["fast_math"]
+        s.upload(X0, Y0)
+        fixed, x_off, y_off, q = s.coord_format()
+        w0 = s.download_words()
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            dmax_g = s.sync()
+        Xg, Yg = s.download()
+        w1 = s.download_words()
+        assert s.outbox_overflow() == 0 and s.frame_status()[1] == 0
+    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
+    sums = lambda w: (int((w & np.uint64(0xffffffff)).sum()), int((w >> np.uint64(32)).sum()))
+    assert sums(w0) == sums(w1) == (int(ck[0]), int(ck[1]))
+    extent = max(float(np.ptp(Xo)), float(np.ptp(Yo)))
+    dev = max(float(np.abs(Xg - Xo).max()), float(np.abs(Yg - Yo).max()))
+    s_g, s_o = (orc.path_stress_sampled(og, X.astype(np.float64), Y.astype(np.float64), 200000, 7) for X, Y in ((Xg, Yg), (Xo, Yo)))
+    print(f"{graph_name}: max coordinate deviation {dev:.4g} bp of extent {extent:.4g}; stress {s_g:.6g} vs mirror {s_o:.6g}; delta_max {dmax_g:.6g} vs {dmax_o:.6g}")
+    assert dev <= 1e-3 * extent
+    assert abs(s_g - s_o) <= 0.01 * s_o
+    assert abs(dmax_g - dmax_o) <= 1e-4 * dmax_o
 
 
 def test_exchange_kernels_match_the_merge_rule_word_for_word(oa, graphs):

@@ -264,12 +264,22 @@ def test_tile_mirror_golden_regression(orc):
     for k, v in old.items():
         assert np.array_equal(v, gv[f"tile_mirror_r2/{k}"]), k
     assert not np.array_equal(old["X"], got["X"])
+    # round 3's pipeline (the Zipf/uniform coin of a warm term per lane; round 4 draws it per wave and trip) likewise
+    # still gives the vectors committed in round 3
+    r3 = tile_mirror_case(orc, pyref, policy=orc.TILE_ROUND3)
+    for k, v in r3.items():
+        assert np.array_equal(v, gv[f"tile_mirror_r3/{k}"]), k
+    assert not np.array_equal(r3["X"], got["X"])
 
 
 def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
     """The tile kernel's sampler takes its coins from the bits of one word (two words per term) where the reference
-    worker draws a word per coin.  Same distribution: partner offsets and end choices of the tile sampler's terms
-    against the reference-order sampler's (path_sgd_layout.cpp:182-270) on the same path, warm and cooling."""
+    worker draws a word per coin, and (round 4) the Zipf/uniform coin of a warm term is the wave's for the trip: the 64
+    terms a wave draws together share it.  Same distribution of terms: partner offsets and end choices of the tile
+    sampler's terms against the reference-order sampler's (path_sgd_layout.cpp:182-270) on the same path, warm and
+    cooling.  Terms of one wave-trip are independent GIVEN their coin, so the warm comparison is made three ways that
+    are each a valid test: one term per wave-trip against the reference's warm terms (independent draws of the mixture);
+    all terms of the Zipf trips against the reference's cooling terms (all Zipf); and the coins themselves as fair."""
     from scipy.stats import chi2_contingency
     g = ographs("DRB1-3123")  # 12 paths of ~3000 steps
     lens = np.diff(g.path_first)
@@ -278,22 +288,45 @@ def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
     p = orc.params(iter_max=30, min_term_updates=1, eps=0.01, eta_max=1.0, theta=0.99, space=3100, space_max=1000,
                    space_quantization_step=100, cooling_start=0.5)
     edges = np.array([1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 513, 1025, 1 << 20])
-    for cooling in (False, True):
-        ref = orc.trace_terms(g, p, 77, 256, 0, cooling, 6000).reshape(-1, 4).astype(np.int64)
-        ref = ref[g.step_path[ref[:, 0]] == path]                      # first step uniform over this path's steps
-        M = 400000
-        til = orc.tile_terms(g, p, 12345, 3, M, L, 0, 64, first, 0, L, path, cooling, capacity=M).astype(np.int64)
-        assert len(til) == M and len(ref) > 50000
-        assert til[:, 0].min() >= first and til[:, 0].max() < first + L and np.array_equal(g.step_path[til[:, 1]], g.step_path[til[:, 0]])
 
-        def table(t):
-            d = t[:, 1] - t[:, 0]
-            mag = np.digitize(np.abs(d), edges)                        # 0: the same step (uniform partner only)
-            return np.bincount(mag * 2 + (d < 0), minlength=2 * (len(edges) + 1))
-        counts = np.stack([table(ref), table(til)])
+    def table(t):
+        d = t[:, 1] - t[:, 0]
+        mag = np.digitize(np.abs(d), edges)                        # 0: the same step (uniform partner only)
+        return np.bincount(mag * 2 + (d < 0), minlength=2 * (len(edges) + 1))
+
+    def same_distribution(x, y, what):
+        counts = np.stack([table(x), table(y)])
         counts = counts[:, counts.sum(axis=0) >= 20]
         chi2, pval, dof, _ = chi2_contingency(counts)
-        assert pval > 1e-3, (cooling, chi2, dof, pval)
+        assert pval > 1e-3, (what, chi2, dof, pval)
+
+    ref_zipf = None
+    for cooling in (True, False):
+        ref = orc.trace_terms(g, p, 77, 256, 0, cooling, 6000).reshape(-1, 4).astype(np.int64)
+        ref = ref[g.step_path[ref[:, 0]] == path]                      # first step uniform over this path's steps
+        lanes, M = 64, 400000 if cooling else 64 * 100000
+        til = orc.tile_terms(g, p, 12345, 3, M, L, 0, lanes, first, 0, L, path, cooling, capacity=M).astype(np.int64)
+        assert len(til) == M and len(ref) > 50000
+        assert til[:, 0].min() >= first and til[:, 0].max() < first + L and np.array_equal(g.step_path[til[:, 1]], g.step_path[til[:, 0]])
+        if cooling:
+            same_distribution(ref, til, "cooling")
+            ref_zipf = ref
+        else:
+            # term q of the tile is drawn by lane q % lanes in its trip q // lanes (one wave: lanes = 64)
+            trips = M // lanes
+            coins = np.array([orc.tile_wave_coin(12345, 3, 0, 0, j) for j in range(trips)])
+            assert abs(coins.mean() - 0.5) < 4 * 0.5 / np.sqrt(trips), coins.mean()
+            assert abs(np.mean(coins[1:] == coins[:-1]) - 0.5) < 4 * 0.5 / np.sqrt(trips)   # no serial dependence
+            one_per_trip = til[np.arange(trips) * lanes + (np.arange(trips) * 7) % lanes]
+            same_distribution(ref, one_per_trip, "warm, one term per wave-trip")
+            zipf_trips = til[np.repeat(coins == 1, lanes)]
+            same_distribution(ref_zipf, zipf_trips[:400000], "warm, the Zipf trips")
+            # a uniform trip's partners are uniform over the path's steps, whatever the first step
+            uni = til[np.repeat(coins == 0, lanes)][:400000]
+            kb = np.bincount((uni[:, 1] - first) * 16 // L, minlength=16)
+            assert np.all(np.abs(kb - len(uni) / 16) < 5 * np.sqrt(len(uni) / 16)), kb
+            til = til[:400000]
+            M = len(til)
         # first steps: uniform over the path in both
         pos = np.stack([np.bincount((t[:, 0] - first) * 16 // L, minlength=16) for t in (ref, til)])
         assert chi2_contingency(pos)[1] > 1e-3
