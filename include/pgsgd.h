@@ -94,6 +94,10 @@ typedef struct pgsgd_graph_view {
                                            /* in a term's geometry instead of the hardware's reciprocal / reciprocal square root (1 ulp) */
                                            /* and 32-bit positions: the instance the CPU oracle's mirror reproduces bit for bit (parity  */
                                            /* tests).  Chosen automatically when a path is 2^32 bp long or longer                        */
+#define PGSGD_FLAG_NO_PARTNER_PAIRS 0x4000u /* tile kernel: every lane keeps its own uniform partner (path_sgd_layout.cpp:235-237).  By default the */
+                                           /* lanes of a wave pair up in a warm iteration's uniform trips: the odd lane takes the step that shares */
+                                           /* a 64-byte unit with its even neighbour's partner (one memory request for two terms; every partner  */
+                                           /* is still uniform over the path).  A/B and parity                                                  */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

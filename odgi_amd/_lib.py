@@ -57,6 +57,7 @@ FLAG_HOT_NODE_CAP = 0x40
 FLAG_NO_PIPELINE = 0x80
 FLAG_NO_SPLIT = 0x1000
 FLAG_EXACT_MATH = 0x2000
+FLAG_NO_PARTNER_PAIRS = 0x4000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8

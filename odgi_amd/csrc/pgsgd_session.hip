@@ -110,6 +110,7 @@ struct pgsgd_session {
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
+    uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
     uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
@@ -725,6 +726,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool force = pgsgd::debug_env("PGSGD_TILE_FORCE") != nullptr;
         s->tile_forced = force;
         s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
+        s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 1u;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
         bool short_paths = true, paths_32 = true;  // (the fast instance keeps positions as 32-bit words: every path shorter than 2^32 bp)
@@ -1178,7 +1180,7 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
     a.epoch = epoch;
     const uint32_t lanes = std::min<uint32_t>(t.lanes, s->tile_block);
     hipLaunchKernelGGL(pgsgd::tile_trace_kernel, dim3((lanes + pgsgd::kTileBlock - 1) / pgsgd::kTileBlock), dim3(pgsgd::kTileBlock), 0, s->stream, s->dc, t,
-                       tile, lanes, term_begin, term_end, a, s->tile_seed_base, d_out);
+                       tile, lanes, term_begin, term_end, a, s->tile_seed_base, s->tile_pair_uniform, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, cnt * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -1452,6 +1454,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
             ta.wq_threshold = s->tile_wq_threshold;
+            ta.pair_uniform = s->tile_pair_uniform;
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;

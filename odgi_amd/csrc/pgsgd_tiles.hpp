@@ -150,6 +150,7 @@ struct TileArgs {
     uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
                                        // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
+    uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
 };
@@ -499,6 +500,23 @@ __host__ __device__ inline uint64_t tile_coin_seed(uint64_t seed_base, uint64_t 
     return seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (1023u - wave));
 }
 
+// Partner pairs.  A uniform partner (path_sgd_layout.cpp:235-237) is a random step of the path: one memory request per
+// term that nothing else shares, and the memory system retires ~50 G random 64-byte requests per second whatever their
+// size (profiles/r04/pmc_calibration*.json) — the tile kernel's warm iterations ran at that ceiling.  A 64-byte unit
+// holds the records of TWO consecutive steps, so the lanes of a wave pair up in a uniform trip: the even lane draws its
+// partner as before, the odd lane draws its own (its stream advances the same way) and then takes the step that shares
+// the even lane's unit, flat step ^ 1, when that is a step of the path (it is, but for the one step at either end of a
+// path whose first or last step has no twin: the odd lane then keeps its own draw).  Every term's partner is still
+// uniform over the path's steps (the twin of a uniform step is a uniform step; the two end steps are chosen by odd lanes
+// 1/cnt less often than the others, one part in 1e6 on a 1e6-step path); what changes is that the two terms of a pair
+// pull towards neighbouring steps instead of independent ones — half as many distinct far places per iteration.
+// Measured: warm iterations 0.475 -> 0.535 of the roofline figure, same final stress (profiles/r04/bench_pairs.txt);
+// PGSGD_FLAG_NO_PARTNER_PAIRS turns it off; the oracle draws the same pairs (orc_tile_partner).
+__host__ __device__ inline uint32_t tile_pair_partner(uint32_t lead_flat_step, uint32_t pstart, uint32_t cnt, uint32_t own_rank) {
+    const uint32_t twin = (lead_flat_step ^ 1u) - pstart;
+    return twin < cnt ? twin : own_rank;
+}
+
 // MATH: kMathFast is the instance sessions run — the term's geometry with the hardware's reciprocal and reciprocal
 // square root (1 ulp each, tile_displacement) and path positions as 32-bit words (every path shorter than 2^32 bp);
 // kMathExact keeps the IEEE divisions and the correctly rounded square root of the per-lane kernel and 64-bit
@@ -729,6 +747,12 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     } else {
                         uint32_t unused;
                         b_rank = below32_hi(rng, cnt, unused);
+                        // partner pairs (tile_pair_partner): an odd lane takes the step that shares a 64-byte unit with its even
+                        // neighbour's partner — one memory request for the two of them
+                        if (ta.pair_uniform) {
+                            const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0xA0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]: the even lane's step
+                            if (threadIdx.x & 1u) b_rank = tile_pair_partner(lead, pstart, cnt, b_rank);
+                        }
                     }
                     // the partner's record: the tile's LDS copy when it is a step of the tile (read where it is used), otherwise
                     // ONE 32-byte line: the record and, of the coordinates both ends of its node had at the last snapshot, the
@@ -1002,38 +1026,49 @@ __global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets, uint32_t
 // sampler-only replay of one tile's terms (parity hook): out[(q - first_term)*4 + {0..3}] = {ka, kb, off_a, off_b};
 // one thread per lane of the tile, terms in the lane's stream order
 __global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile t, uint64_t tile_index, uint32_t lanes, uint64_t term_begin,
-                                                                uint64_t term_end, IterArgs a, uint64_t seed_base, uint64_t* out) {
+                                                                uint64_t term_end, IterArgs a, uint64_t seed_base, uint32_t pair_uniform, uint64_t* out) {
     const uint64_t pstart = c.path_first[t.path];
     const uint64_t cnt = c.path_first[t.path + 1] - pstart;
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= lanes) return;
     Xoshiro256Plus rng;
-    rng.seed(tile_stream_seed(seed_base, a.epoch, tile_index, lane));
+    if (lane < lanes) rng.seed(tile_stream_seed(seed_base, a.epoch, tile_index, lane));
     uint64_t coin_x = tile_coin_seed(seed_base, a.epoch, tile_index, lane >> 6), coin_cur = 0;  // the coins of the lane's wave
-    uint64_t j = 0;
-    for (uint64_t q = term_begin + lane; q < term_end; q += lanes, ++j) {
+    const uint64_t n_terms = term_end - term_begin;
+    const uint64_t trips = (n_terms + lanes - 1) / lanes;   // the same trip count for every lane (the pairs talk through the wave)
+    for (uint64_t j = 0; j < trips; ++j) {
         if (!(j & 63u)) coin_cur = Xoshiro256Plus::splitmix64(coin_x);
-        uint32_t flags;
-        const uint64_t k = t.t0 + below32_hi(rng, t.n, flags);
-        const uint64_t s_rank = k - pstart;
-        uint64_t b_rank;
-        if (a.cooling || ((coin_cur >> (j & 63u)) & 1u)) {
-            const bool back = (s_rank > 0 && ((flags >> 30) & 1u)) || s_rank == cnt - 1;
-            const uint64_t room = back ? s_rank : cnt - s_rank - 1;
-            const uint64_t jump = c.space < room ? c.space : room;
-            const double2 zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
-            const uint64_t z = zipf_tabled(rng, c.zc, jump, zd.x, zd.y);
-            b_rank = back ? s_rank - z : s_rank + z;
-        } else {
-            uint32_t unused;
-            b_rank = below32_hi(rng, (uint32_t)cnt, unused);
+        const uint64_t q = term_begin + lane + j * lanes;
+        const bool live = lane < lanes && q < term_end;
+        const bool zipf_trip = a.cooling || ((coin_cur >> (j & 63u)) & 1u);   // wave-uniform
+        uint32_t flags = 0;
+        uint64_t k = 0, b_rank = 0;
+        if (live) {
+            k = t.t0 + below32_hi(rng, t.n, flags);
+            const uint64_t s_rank = k - pstart;
+            if (zipf_trip) {
+                const bool back = (s_rank > 0 && ((flags >> 30) & 1u)) || s_rank == cnt - 1;
+                const uint64_t room = back ? s_rank : cnt - s_rank - 1;
+                const uint64_t jump = c.space < room ? c.space : room;
+                const double2 zd = c.zeta_denom[zeta_index(jump, c.space_max, c.space_quant)];
+                const uint64_t z = zipf_tabled(rng, c.zc, jump, zd.x, zd.y);
+                b_rank = back ? s_rank - z : s_rank + z;
+            } else {
+                uint32_t unused;
+                b_rank = below32_hi(rng, (uint32_t)cnt, unused);
+            }
         }
-        const uint64_t kb = pstart + b_rank;
-        uint64_t* o = out + (q - term_begin) * 4;
-        o[0] = k;
-        o[1] = kb;
-        o[2] = (c.recs[k].x ^ (flags >> 29)) & 1u;   // end offsets of the two node ends the term moves
-        o[3] = (c.recs[kb].x ^ (flags >> 28)) & 1u;
+        if (!zipf_trip && pair_uniform) {   // (every lane of the wave: an odd live lane's even neighbour is live too)
+            const uint32_t lead = (uint32_t)__shfl((int)(uint32_t)(pstart + b_rank), (int)((threadIdx.x & 63u) & ~1u));
+            if (live && (lane & 1u)) b_rank = tile_pair_partner(lead, (uint32_t)pstart, (uint32_t)cnt, (uint32_t)b_rank);
+        }
+        if (live) {
+            const uint64_t kb = pstart + b_rank;
+            uint64_t* o = out + (q - term_begin) * 4;
+            o[0] = k;
+            o[1] = kb;
+            o[2] = (c.recs[k].x ^ (flags >> 29)) & 1u;   // end offsets of the two node ends the term moves
+            o[3] = (c.recs[kb].x ^ (flags >> 28)) & 1u;
+        }
     }
 }
 

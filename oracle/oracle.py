@@ -204,9 +204,9 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
     return X, Y, d.value, ck
 
 
-TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN = 1, 2, 4, 8, 16, 32
-TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN   # the launch order, far-pull policy and per-lane coin of round 2
-TILE_ROUND3 = TILE_LANE_COIN   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane
+TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN, TILE_NO_PAIRS = 1, 2, 4, 8, 16, 32, 64
+TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN | TILE_NO_PAIRS   # the launch order, far-pull policy and per-lane coin of round 2
+TILE_ROUND3 = TILE_LANE_COIN | TILE_NO_PAIRS   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane
 
 
 def tile_wave_coin(seed_base, epoch, tile, wave, trip):

@@ -269,7 +269,14 @@ static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int coo
     }
 }
 
-static void orc_tile_partner(const orc_graph* g, const orc_params* p, const double* zetas, const orc_tile_pick* pk, uint64_t s[4], orc_term* t) {
+/* Partner pairs (round 4; pgsgd_tiles.hpp: tile_pair_partner): in a uniform trip the odd lanes of a tile take the step
+ * that shares a 64-byte unit of the step records with their even neighbour's partner — flat step ^ 1 — when that is a
+ * step of the path; the odd lane still draws its own partner first (its stream advances as before) and keeps it
+ * otherwise.  pair_lead: the even neighbour's partner (flat step) for an odd lane, ORC_NO_PAIR for an even lane, a Zipf
+ * term, or the pipelines of rounds 2 and 3 (ORC_TILE_NO_PAIRS). */
+#define ORC_NO_PAIR (~(uint64_t)0)
+static void orc_tile_partner(const orc_graph* g, const orc_params* p, const double* zetas, const orc_tile_pick* pk, uint64_t pair_lead,
+                             uint64_t s[4], orc_term* t) {
     uint64_t b_rank;
     if (pk->zipf) {
         uint64_t space = pk->jump;
@@ -279,6 +286,10 @@ static void orc_tile_partner(const orc_graph* g, const orc_params* p, const doub
     } else {
         uint32_t unused;
         b_rank = orc_below32_hi(s, (uint32_t)pk->an.cnt, &unused);                             /* :235-237 */
+        if (pair_lead != ORC_NO_PAIR) {
+            const uint32_t twin = ((uint32_t)pair_lead ^ 1u) - (uint32_t)pk->an.pstart;
+            if (twin < (uint32_t)pk->an.cnt) b_rank = twin;
+        }
     }
     t->ka = pk->an.k;
     t->kb = pk->an.pstart + b_rank;
@@ -492,19 +503,28 @@ uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_b
     orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
     const uint64_t term_begin = (uint64_t)(((unsigned __int128)cum * n_terms) / steps_total);
     const uint64_t term_end = (uint64_t)(((unsigned __int128)(cum + n) * n_terms) / steps_total);
-    for (uint32_t lane = 0; lane < lanes; ++lane) {
-        uint64_t s[4];
-        orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | lane), s);
-        uint64_t cx = seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (uint64_t)(1023u - lane / 64)), cw = 0, trip = 0;
-        for (uint64_t q = term_begin + lane; q < term_end; q += lanes, ++trip) {
-            orc_tile_pick cur;
-            orc_tile_pick_first(g, p, cooling, orc_tile_wave_coin_next(&cx, &cw, trip), t0, n, path, s, &cur);
-            orc_term t;
-            orc_tile_partner(g, p, zetas, &cur, s, &t);
-            uint64_t* o = out + (q - term_begin) * 4;
-            o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
-        }
+    /* term q of the tile is drawn by lane (q - term_begin) % lanes in its trip (q - term_begin) / lanes: in term order, one
+     * generator per lane, so that an odd lane sees its even neighbour's partner of the same trip */
+    uint64_t* streams = (uint64_t*)malloc((size_t)lanes * 4 * sizeof(uint64_t));
+    for (uint32_t l = 0; l < lanes; ++l) orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | l), streams + 4 * (size_t)l);
+    uint64_t lead = ORC_NO_PAIR;
+    const uint32_t waves = (lanes + 63) / 64;
+    uint64_t* cx = (uint64_t*)malloc((size_t)waves * sizeof(uint64_t));   /* the waves' coin streams, advanced in trip order */
+    uint64_t* cw = (uint64_t*)calloc(waves, sizeof(uint64_t));
+    int* coin = (int*)calloc(waves, sizeof(int));
+    for (uint32_t w = 0; w < waves; ++w) cx[w] = seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (uint64_t)(1023u - w));
+    for (uint64_t q = term_begin; q < term_end; ++q) {
+        const uint32_t lane = (uint32_t)((q - term_begin) % lanes);
+        if (lane % 64 == 0) coin[lane / 64] = orc_tile_wave_coin_next(&cx[lane / 64], &cw[lane / 64], (q - term_begin) / lanes);
+        orc_tile_pick cur;
+        orc_tile_pick_first(g, p, cooling, coin[lane / 64], t0, n, path, streams + 4 * (size_t)lane, &cur);
+        orc_term t;
+        orc_tile_partner(g, p, zetas, &cur, (lane & 1u) ? lead : ORC_NO_PAIR, streams + 4 * (size_t)lane, &t);
+        lead = cur.zipf ? ORC_NO_PAIR : t.kb;
+        uint64_t* o = out + (q - term_begin) * 4;
+        o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
     }
+    free(streams); free(cx); free(cw); free(coin);
     free(zetas);
     return term_end - term_begin;
 }
@@ -1218,6 +1238,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *                           (sharded sessions; round 2), not from words the tiles rewrite for their own steps
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
  *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
+ *   ORC_TILE_NO_PAIRS       every lane keeps its own uniform partner (rounds 2 and 3; PGSGD_FLAG_NO_PARTNER_PAIRS)
  * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
 void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
@@ -1310,6 +1331,7 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                     uint64_t* streams = (uint64_t*)malloc((size_t)lanes * 4 * sizeof(uint64_t));
                     for (uint32_t l = 0; l < lanes; ++l)
                         orc_rng_seed(seed_base + epoch * 0xd1342543de82ef95ull + (((uint64_t)ti << 10) | l), streams + 4 * (size_t)l);
+                    uint64_t pair_lead = ORC_NO_PAIR;
                     for (uint64_t q = term_begin; q < term_end; ++q) {
                         const uint32_t lane = (uint32_t)((q - term_begin) % lanes);
                         uint64_t* s = streams + 4 * (size_t)lane;
@@ -1317,7 +1339,8 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                         const int coin = (policy & ORC_TILE_LANE_COIN) ? -1 : orc_tile_wave_coin(seed_base, epoch, ti, lane / 64, (q - term_begin) / lanes);
                         orc_tile_pick_first(g, p, cooling, coin, t0[ti], tn[ti], tpath[ti], s, &cur);
                         orc_term t;
-                        orc_tile_partner(g, p, zetas, &cur, s, &t);
+                        orc_tile_partner(g, p, zetas, &cur, ((lane & 1u) && !(policy & ORC_TILE_NO_PAIRS)) ? pair_lead : ORC_NO_PAIR, s, &t);
+                        pair_lead = cur.zipf ? ORC_NO_PAIR : t.kb;   /* (an odd lane's even neighbour drew the term before, in the same trip) */
                         const uint64_t ea = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
                         const uint64_t eb = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
                         const int in_a = local[it] && ea >= wbase && ea - wbase < win_words;

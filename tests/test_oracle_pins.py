@@ -324,7 +324,21 @@ def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
             # a uniform trip's partners are uniform over the path's steps, whatever the first step
             uni = til[np.repeat(coins == 0, lanes)][:400000]
             kb = np.bincount((uni[:, 1] - first) * 16 // L, minlength=16)
-            assert np.all(np.abs(kb - len(uni) / 16) < 5 * np.sqrt(len(uni) / 16)), kb
+            # (partner pairs: the odd lanes' partners are their even neighbours' twins — the even lanes' draws are the independent ones)
+            even = uni[0::2]
+            kb_even = np.bincount((even[:, 1] - first) * 16 // L, minlength=16)
+            assert np.all(np.abs(kb_even - len(even) / 16) < 5 * np.sqrt(len(even) / 16)), kb_even
+            assert np.all(np.abs(kb - len(uni) / 16) < 5 * np.sqrt(2 * len(uni) / 16)), kb
+            # the lanes of a wave pair up in a uniform trip (pgsgd_tiles.hpp: tile_pair_partner): the odd lane's partner shares a
+            # 64-byte unit of the step records with the even lane's (flat step ^ 1) unless that twin lies outside the path
+            odd = uni[1::2]
+            twin = even[:, 1] ^ 1
+            inside = (twin >= first) & (twin < first + L)
+            assert np.array_equal(odd[inside, 1], twin[inside]) and inside.mean() > 0.999
+            assert np.all((odd[~inside, 1] >= first) & (odd[~inside, 1] < first + L))
+            # ... and is itself uniform over the path's steps, with fair end choices of its own
+            kb_odd = np.bincount((odd[:, 1] - first) * 16 // L, minlength=16)
+            assert np.all(np.abs(kb_odd - len(odd) / 16) < 5 * np.sqrt(len(odd) / 16)), kb_odd
             til = til[:400000]
             M = len(til)
         # first steps: uniform over the path in both

@@ -212,6 +212,74 @@ __global__ void swrite(uint4* buf, uint64_t n, const uint32_t* src) {
     }
 }
 
+// round 4: kernels of KNOWN traffic for calibrating rocprofv3's memory-side counters (FETCH_SIZE, WRITE_SIZE,
+// TCC_EA0_RDREQ / _RDREQ_32B, TCC_EA0_WRREQ / _WRREQ_64B, TCC_HIT / TCC_MISS) on the access patterns of the tile kernel:
+// MICROBENCH_CAL=1 launches each once (plus a warm-up of another name) and prints what it requested.
+__global__ void cal_stream_read(const uint4* buf, uint64_t n16, uint32_t* sink) {   // coalesced 16 bytes per lane
+    uint32_t acc = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (uint64_t)gridDim.x * blockDim.x) acc += buf[k].x;
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void cal_stream_write(uint4* buf, uint64_t n16) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (uint64_t)gridDim.x * blockDim.x) buf[k] = make_uint4((uint32_t)k, 1u, 2u, 3u);
+}
+__global__ void cal_gather16(const uint4* buf, uint64_t n16, uint64_t iters, uint32_t* sink) {   // random 16-byte records
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) acc += buf[__umul64hi(xs(s), n16)].x;
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void cal_gather32(const uint4* buf, uint64_t n32, uint64_t iters, uint32_t* sink) {   // the tile kernel's far partner: 16 + 8 bytes of a 32-byte record
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s), k = __umul64hi(r, n32);
+        const uint4 a = buf[2 * k];
+        const unsigned long long w = reinterpret_cast<const unsigned long long*>(buf)[4 * k + 2 + (r & 1)];
+        acc += a.x ^ (uint32_t)w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void cal_linewrite64(uint4* buf, uint64_t n_lines, uint64_t iters) {   // the outbox: 8 lanes x 8 bytes = one 64-byte line at a random place
+    uint64_t s = 0x9E3779B97F4A7C15ull * (((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / 8) * 8 + 1);
+    const uint32_t piece = threadIdx.x & 7u;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s);
+        reinterpret_cast<unsigned long long*>(buf)[__umul64hi(r, n_lines) * 8 + piece] = r + piece;
+    }
+}
+
+// both 64-byte halves of one random 128-byte line, one after the other: one memory-side request per pair if a miss
+// fetches the whole line, two if the L2 fetches 64-byte sectors
+__global__ void cal_gather_halves(const uint4* buf, uint64_t n128, uint64_t iters, uint32_t* sink) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t k = __umul64hi(xs(s), n128);
+        const uint4 a = buf[8 * k];
+        const uint4 b = buf[8 * k + 4 + (a.x & 1u)];   // (dependent: issued after the first half is back)
+        acc += a.x ^ b.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+// 16-byte random gathers with cache-policy bits: MODE 0 plain, 1 nt, 2 sc1 (agent scope), 3 sc0 sc1 (system scope), 4 sc0 sc1 nt
+template <int MODE>
+__global__ void cal_gather16_policy(const uint4* buf, uint64_t n16, uint64_t iters, uint32_t* sink) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint4* p = buf + __umul64hi(xs(s), n16);
+        uint4 v;
+        if (MODE == 0) asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        acc += v.x;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 3) {
     hipEvent_t a, b;
@@ -235,6 +303,51 @@ int main() {
     const size_t big = 1ull << 30;  // 1 GiB
     uint4* g; CK(hipMalloc(&g, big)); CK(hipMemset(g, 1, big));
     printf("{\"lanes\": %llu}\n", (unsigned long long)lanes);
+    if (getenv("MICROBENCH_CAL")) {
+        (void)hipFree(g);
+        const size_t big2 = 3ull << 30;
+        CK(hipMalloc(&g, big2)); CK(hipMemset(g, 1, big2));
+        auto once = [&](const char* name, double bytes_read, double bytes_written, double requests, auto launch) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipDeviceSynchronize();
+            hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("{\"cal\": \"%s\", \"bytes_read\": %.0f, \"bytes_written\": %.0f, \"requests\": %.0f, \"ms\": %.4f, \"G_requests_per_s\": %.2f, \"GB_per_s\": %.1f}\n",
+                   name, bytes_read, bytes_written, requests, ms, requests / ms / 1e6, (bytes_read + bytes_written) / ms / 1e6);
+            hipEventDestroy(a); hipEventDestroy(b);
+        };
+        const uint64_t iters = 128;
+        const double req = (double)lanes * iters;
+        hipLaunchKernelGGL(cal_stream_read, dim3(4096), dim3(256), 0, 0, g, (1ull << 30) / 16, sink);   // warm-up (first-touch of the pages)
+        once("cal_stream_read", (double)(2ull << 30), 0, (double)(2ull << 30) / 64, [&] { hipLaunchKernelGGL(cal_stream_read, dim3(4096), dim3(256), 0, 0, g, (2ull << 30) / 16, sink); });
+        once("cal_stream_write", 0, (double)(2ull << 30), (double)(2ull << 30) / 64, [&] { hipLaunchKernelGGL(cal_stream_write, dim3(4096), dim3(256), 0, 0, g, (2ull << 30) / 16); });
+        once("cal_gather16", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        once("cal_gather32", req * 24, 0, req, [&] { hipLaunchKernelGGL(cal_gather32, dim3(grid), dim3(block), 0, 0, g, (1536ull << 20) / 32, iters, sink); });
+        once("cal_linewrite64", 0, req * 8, req / 8, [&] { hipLaunchKernelGGL(cal_linewrite64, dim3(grid), dim3(block), 0, 0, g, big2 / 64, iters); });
+        once("cal_gather_halves", req * 32, 0, req, [&] { hipLaunchKernelGGL(cal_gather_halves, dim3(grid), dim3(block), 0, 0, g, (1536ull << 20) / 128, iters, sink); });
+        once("cal_gather16_plain", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16_policy<0>, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        once("cal_gather16_nt", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16_policy<1>, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        once("cal_gather16_sc1", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16_policy<2>, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        once("cal_gather16_sc0sc1", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16_policy<3>, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        once("cal_gather16_sc0sc1nt", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16_policy<4>, dim3(grid), dim3(block), 0, 0, g, (768ull << 20) / 16, iters, sink); });
+        {   // the same gathers from memory the L2 does not cache (MTYPE UC): does a miss then move 32 or 64 bytes instead of a line?
+            uint4* uc = nullptr;
+            if (hipExtMallocWithFlags((void**)&uc, 1536ull << 20, hipDeviceMallocUncached) == hipSuccess && uc) {
+                hipMemset(uc, 1, 1536ull << 20);
+                once("cal_gather16_uncached", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16, dim3(grid), dim3(block), 0, 0, uc, (768ull << 20) / 16, iters, sink); });
+                once("cal_gather32_uncached", req * 24, 0, req, [&] { hipLaunchKernelGGL(cal_gather32, dim3(grid), dim3(block), 0, 0, uc, (1536ull << 20) / 32, iters, sink); });
+                (void)hipFree(uc);
+            } else {
+                printf("{\"cal\": \"uncached allocation failed\"}\n");
+            }
+            if (hipExtMallocWithFlags((void**)&uc, 1536ull << 20, hipDeviceMallocFinegrained) == hipSuccess && uc) {
+                hipMemset(uc, 1, 1536ull << 20);
+                once("cal_gather16_finegrained", req * 16, 0, req, [&] { hipLaunchKernelGGL(cal_gather16, dim3(grid), dim3(block), 0, 0, uc, (768ull << 20) / 16, iters, sink); });
+                (void)hipFree(uc);
+            }
+        }
+        return 0;
+    }
     for (uint64_t bytes : {16ull << 20, 128ull << 20, 768ull << 20}) {
         const uint64_t n = bytes / 16, iters = 256;
         double ms1 = time_ms([&] { hipLaunchKernelGGL(gather16<1>, dim3(grid), dim3(block), 0, 0, g, n, iters, sink); });
