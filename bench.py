@@ -99,6 +99,8 @@ def main():
 
     for it in range(args.warmup):
         drv.step(it)
+    if args.warmup and hasattr(eng, "flush"):
+        eng.flush()   # the warm-up's last far pulls are delivered outside the window (the next launch would deliver them first otherwise)
     eng.session.kernel_time(reset=True)
     counts0 = eng.session.launch_counts()
     fence()
@@ -110,8 +112,13 @@ def main():
         k = eng.session.kernel_time() + eng.session.aux_time()
         per_iter.append((it, k[0] - k_prev[0], k[1] - k_prev[1], k[2] - k_prev[2], k[3] - k_prev[3]))
         k_prev = k
+    # The far pulls a tile launch collects are delivered right before the NEXT launch: every timed step pays for the drain
+    # of the step before it, and the timed window closes with the flush of its own last launch (and, at world > 1, the
+    # exchange that merges it): the window holds exactly the drains of its own launches (the warm-up's were flushed above).
+    drv.finish()
     fence()
     elapsed = time.perf_counter() - t1
+    clock_mhz, clock_launch_ms = eng.session.shader_clock() if hasattr(eng.session, "shader_clock") else (0.0, 0.0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,7 +145,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (f64 sampler, q32 coords)",
         "data": "synthetic",
         "config": {"workload": f"synthetic linearised pangenome N={g.n_nodes} S={g.n_steps} P={g.n_paths} seed 42 "
                                f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
@@ -181,18 +188,25 @@ def main():
     out["config"]["kernel_plan"] = ("per-lane kernel" if not info["tiled"] else
                                     "per-lane kernel until cooling, tile kernel after" if info["warm_per_lane"] else
                                     "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
-    # HBM bytes per launch: NOT measured in this run — read from the committed rocprofv3 PMC passes of this same
-    # command (tools/profile_bench.sh + tools/summarize_prof.py -> profiles/r03/pmc_traffic_r03final.json), labelled as such
-    prof = os.path.join(ROOT, "profiles", "r03", "pmc_traffic_r03final.json")
+    # the shader clock the last tile launch of the window ran at (s_memtime against the 100 MHz s_memrealtime, read by the
+    # kernel's first workgroup): a 20-step window is 0.2 s long and every figure above moves with the clock
+    rf["shader_clock_mhz"] = clock_mhz
+    # HBM traffic per launch: NOT measured in this run — the memory-side request counters of the L2 (TCC_EA0_RDREQ by size
+    # class, TCC_EA0_WRREQ) from the committed rocprofv3 PMC passes of this same command, with the request sizes calibrated on
+    # kernels of known traffic (tools/profile_cal.sh -> profiles/r04/pmc_traffic_r04.json, pmc_calibration*.json), labelled so
+    prof = os.path.join(ROOT, "profiles", "r04", "pmc_traffic_r04.json")
     same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
     if os.path.exists(prof) and same_workload:
         try:
             with open(prof) as f:
                 pj = json.load(f)
-            out["roofline"]["traffic"] = pj.get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_raw"] = pj.get("hbm_bytes_per_launch_raw")   # FETCH_SIZE + WRITE_SIZE as reported
-            out["roofline"]["traffic_note"] = pj.get("note")
-            out["roofline"]["traffic_source"] = "profiled offline, not in this run: " + str(pj.get("source"))
+            rf["traffic"] = pj.get("hbm_bytes_per_launch")
+            rf["traffic_over_algorithmic"] = pj.get("hbm_bytes_per_launch") / (BYTES_PER_TERM * my_terms) if my_terms else None
+            rf["memory_requests_per_launch"] = pj.get("requests_per_launch")
+            rf["memory_requests_per_term"] = pj.get("requests_per_launch") / my_terms if my_terms else None
+            rf["random_request_ceiling_per_s"] = pj.get("random_request_ceiling_per_s")
+            rf["traffic_note"] = pj.get("note")
+            rf["traffic_source"] = "profiled offline, not in this run: " + str(pj.get("source"))
         except Exception as e:  # noqa: BLE001
             log(f"[bench] could not read {prof}: {e}")
 

@@ -180,12 +180,18 @@ int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd
 void pgsgd_session_destroy(pgsgd_session* s);
 /* host fp32 X,Y [2N]  <->  device coordinate words (one 8-byte word per node end) */
 int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, const float* Y);
+/* download_* return the LAYOUT: they first deliver what the last tile launch left in the outbox (pgsgd_session_flush; nothing
+ * to do in a per-lane session).  peek_* read the coordinates as they are between iterations — what the reference's
+ * per-iteration snapshots see (path_sgd_layout.cpp:379-408): without the far pulls that arrive with the next launch. */
 int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y);
 int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, double* Y); /* exact x_off + q / quanta_per_bp */
+int pgsgd_session_peek_coords(pgsgd_session* s, float* X, float* Y);
+int pgsgd_session_peek_coords_f64(pgsgd_session* s, double* X, double* Y);
+int pgsgd_session_peek_words(pgsgd_session* s, uint64_t* words /* [2N] raw coordinate words */);
 /* device pointer to the 2N coordinate words, and their format: fixed_point 1 = {u32 Xq, u32 Yq}
  * with x = x_off + Xq / quanta_per_bp (frame chosen at upload), 0 = {f32 x, f32 y} */
 void* pgsgd_session_coords_ptr(pgsgd_session* s);
-int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words /* [2N] raw coordinate words */);
+int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words /* [2N] raw coordinate words, after the flush */);
 int pgsgd_session_coord_format(const pgsgd_session* s, int* fixed_point, double* x_off, double* y_off,
                                double* quanta_per_bp);
 /* launch stream (hipStream_t as void*); set to make the session launch on a caller stream */
@@ -199,9 +205,9 @@ int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int cooling, uint
 /* Wait for the stream; returns max |Delta| of the last iteration in *delta_max (may be NULL). */
 int pgsgd_session_sync(pgsgd_session* s, double* delta_max);
 /* Tile kernel only (a no-op otherwise): what a tile launch adds to node ends outside its windows is delivered right
- * before the NEXT launch, so between iterations the coordinates lack the far pulls of the last launch.  A caller that
- * drives iterations itself calls this before it reads the final coordinates (pgsgd_layout_run does); per-iteration
- * snapshots (path_sgd_layout.cpp:379-408) are taken without it. */
+ * before the NEXT launch, so between iterations the coordinates lack the far pulls of the last launch.  The download_*
+ * entry points call this themselves; a caller that reads the device words directly (pgsgd_session_coords_ptr) calls it
+ * first; per-iteration snapshots (path_sgd_layout.cpp:379-408) are taken without it (peek_*). */
 int pgsgd_session_flush(pgsgd_session* s);
 /* The fixed-point coordinate frame (2^32 quanta per axis, 8x the layout's extent at upload).  Kernels flag any
  * coordinate they see in the outer quarter of the frame; pgsgd_session_sync then doubles the frame (same centre, half
@@ -218,6 +224,10 @@ int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, double* drain_
 /* kernel launches and memset/copy operations the iteration calls have put on the stream so far (what a step costs
  * besides its dominant kernel: bench.py reports them per step) */
 int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launches, uint64_t* copies);
+/* Measurement: the shader clock (MHz) the last tile-kernel launch ran at and that launch's duration as its first
+ * workgroup saw it (s_memtime against the constant 100 MHz s_memrealtime); blocks until the stream is idle; 0 when the
+ * session has run no tile launch. */
+int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double* launch_ms);
 /* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
  * direct atomic adds instead (0 in normal operation; the pool is sized from the tile table). */
 int64_t pgsgd_session_outbox_overflow(pgsgd_session* s);

@@ -80,6 +80,9 @@ SIGNATURES = [
     ("pgsgd_session_download_coords_f64", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_coords_ptr", C.c_void_p, [C.c_void_p]),
     ("pgsgd_session_download_words", C.c_int, [C.c_void_p, P(u64)]),
+    ("pgsgd_session_peek_coords", C.c_int, [C.c_void_p, P(C.c_float), P(C.c_float)]),
+    ("pgsgd_session_peek_coords_f64", C.c_int, [C.c_void_p, P(f64), P(f64)]),
+    ("pgsgd_session_peek_words", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_coord_format", C.c_int, [C.c_void_p, P(C.c_int), P(f64), P(f64), P(f64)]),
     ("pgsgd_session_stream", C.c_void_p, [C.c_void_p]),
     ("pgsgd_session_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -92,6 +95,7 @@ SIGNATURES = [
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
     ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_launch_counts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
+    ("pgsgd_session_shader_clock", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),

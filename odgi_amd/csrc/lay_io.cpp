@@ -128,7 +128,7 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
             block_bits[(size_t)b + 1] = bits;
         }
     });
-    if (!threads_ok) return PGSGD_E_NOMEM;
+    if (!threads_ok) { pgsgd::set_error("out of memory while encoding the layout"); return PGSGD_E_NOMEM; }
     for (uint64_t b = 0; b < samples; ++b) {
         if (max_sample < vals[b * dens]) max_sample = vals[b * dens];
         block_bits[(size_t)b + 1] += block_bits[(size_t)b];  // -> bit offset of block b + 1
@@ -161,7 +161,7 @@ int encode_lay(uint64_t n_ends, const double* X, const double* Y, std::vector<ui
                 for (uint64_t i = b * dens + 1; i < e; ++i) delta_put(w, vals[i] - vals[i - 1]);
             }
         });
-        if (!threads_ok) return PGSGD_E_NOMEM;
+        if (!threads_ok) { pgsgd::set_error("out of memory while encoding the layout"); return PGSGD_E_NOMEM; }
         for (unsigned t = 0; t < nt; ++t) {
             const auto [b0, b1] = range(t);
             if (b0 == b1) continue;
@@ -217,7 +217,7 @@ extern "C" int pgsgd_lay_buffer(uint64_t n_ends, const double* X, const double* 
     int rc = encode_lay(n_ends, X, Y, out);
     if (rc) return rc;
     *buf = (uint8_t*)malloc(out.size() ? out.size() : 1);
-    if (!*buf) return PGSGD_E_NOMEM;
+    if (!*buf) { pgsgd::set_error("out of memory while encoding the layout"); return PGSGD_E_NOMEM; }
     memcpy(*buf, out.data(), out.size());
     *len = out.size();
     return PGSGD_OK;
@@ -280,7 +280,7 @@ extern "C" int pgsgd_read_lay(const char* path, uint64_t* n_ends, double** Xo, d
     const uint64_t ends = n / 2;
     double* X = (double*)malloc((ends ? ends : 1) * 8);
     double* Y = (double*)malloc((ends ? ends : 1) * 8);
-    if (!X || !Y) { free(X); free(Y); return PGSGD_E_NOMEM; }
+    if (!X || !Y) { free(X); free(Y); pgsgd::set_error("out of memory while decoding the layout"); return PGSGD_E_NOMEM; }
     BitReader br{z.data(), zbits, 0};
     uint64_t v = 0;
     auto corrupt = [&](const char* what) {

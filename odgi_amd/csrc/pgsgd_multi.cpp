@@ -20,7 +20,23 @@
 // device); PGSGD_MULTI_FORCE=1 sends an n_devices = 1 run through this driver — one rank, a one-rank communicator, the
 // same ncclAllReduce calls — which is how the RCCL binding is executed on a single-GPU box.
 #include <hip/hip_runtime_api.h>
+// RCCL's declarations come from its header when the development package is there; a build box without it still builds
+// the library (single-GPU users need RCCL neither at build nor at run time): the few declarations the exchange uses are
+// then restated here, with the values rccl.h gives them (ncclFloat32 = 7, ncclSum = 0, ncclSuccess = 0).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <dlfcn.h>
 
@@ -265,7 +281,7 @@ void rank_main(Shared& sh, int r) {
         if (r == 0 && p0.snapshot && p0.snapshot_prefix && !sh.rc[r]) {  // :379-408: snapshot k after iteration k, k = 1..iter_max-1
             sx.resize(2 * N);
             sy.resize(2 * N);
-            R_TRY(pgsgd_session_download_coords(s, sx.data(), sy.data()));  // rank 0's copy = the merged coordinates
+            R_TRY(pgsgd_session_peek_coords(s, sx.data(), sy.data()));  // rank 0's copy = the merged coordinates, as they are between iterations
             const std::string name = std::string(p0.snapshot_prefix) + std::to_string(it + 1);
             fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");
             if (!sh.rc[r]) R_TRY(pgsgd_write_lay_f32(name.c_str(), 2 * N, sx.data(), sy.data()));

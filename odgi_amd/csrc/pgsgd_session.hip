@@ -74,8 +74,10 @@ struct pgsgd_session {
     uint32_t region = 256, tile_steps = 224, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
-    uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed, index of the far-pull relaxation)
+    uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
+    uint64_t relax_iter = 0;              // iterations of the current layout, i.e. since the last upload (index of the far pulls' gentle start)
     uint64_t tile_seed_base = 0;          // seed + stream_offset; a sharded session: seed alone (pgsgd_session_set_shard)
+    unsigned long long* d_clock = nullptr;  // [4] TileArgs::clock_probe of the last windowed tile launch
     unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
     uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
@@ -143,6 +145,12 @@ static int pick_device(int requested, int* out) {
 static int collect_events(pgsgd_session* s) {
     for (auto& ev : s->pending_events) {
         float ms = 0;
+        if (ev.n == 1) {  // a drain on its own (pgsgd_session_flush): e[2] .. drain .. e[3]
+            HIP_TRY(hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
+            s->aux_ms[1] += ms;
+            s->free_events.push_back(ev);
+            continue;
+        }
         HIP_TRY(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
         s->kernel_ms += ms;
         s->launches++;
@@ -813,6 +821,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(uint64_t) << 14)));
                 S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
+                S_TRY(hipMalloc(&s->d_clock, 4 * sizeof(unsigned long long)));
+                S_TRY(hipMemset(s->d_clock, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
@@ -956,6 +966,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_far) (void)hipFree(s->d_far);
+    if (s->d_clock) (void)hipFree(s->d_clock);
     if (s->d_recs2) (void)hipFree(s->d_recs2);
     if (s->ob.pool) (void)hipFree(s->ob.pool);
     if (s->ob.next) (void)hipFree(s->ob.next);
@@ -1031,13 +1042,27 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     (void)hipFree(dX);
     (void)hipFree(dY);
     s->snap_stale = true;
+    // a new layout starts here: nothing of the previous one's run state may reach it — the frame-guard flag (it would
+    // double the fresh frame at the first sync), the far-pull counts behind the learning-rate cap of far terms, and the
+    // gentle start of the far pulls (tile_far_relax counts iterations of THIS layout; tile_epoch goes on as the seed)
+    HIP_TRY(hipMemset(s->d_delta_max, 0, 2 * sizeof(unsigned int)));
+    if (s->d_far) HIP_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
+    s->far_launches[0] = s->far_launches[1] = 0;
+    s->relax_iter = 0;
     return PGSGD_OK;
 }
 
-extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y) {
+// Reading coordinates.  The download entry points return the layout: they first deliver what the last tile launch left
+// in the outbox (pgsgd_session_flush; nothing to do for per-lane sessions).  The peek entry points read the words as they
+// are — what a snapshot between iterations (path_sgd_layout.cpp:379-408) sees: without the far pulls still waiting.
+static int read_coords(pgsgd_session* s, float* X, float* Y, bool flush) {
     pgsgd::clear_error();
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
+    if (flush) {
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     const uint64_t n_ends = 2 * s->n_nodes;
     float *dX = nullptr, *dY = nullptr;
     HIP_TRY(hipMalloc(&dX, n_ends * sizeof(float)));
@@ -1056,12 +1081,19 @@ extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* 
     return PGSGD_OK;
 }
 
+extern "C" int pgsgd_session_download_coords(pgsgd_session* s, float* X, float* Y) { return read_coords(s, X, Y, true); }
+extern "C" int pgsgd_session_peek_coords(pgsgd_session* s, float* X, float* Y) { return read_coords(s, X, Y, false); }
+
 extern "C" void* pgsgd_session_coords_ptr(pgsgd_session* s) { return s ? (void*)s->d_coords : nullptr; }
 
-extern "C" int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words) {
+static int read_words(pgsgd_session* s, uint64_t* words, bool flush) {
     pgsgd::clear_error();
     if (!s || !words) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
+    if (flush) {
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(words, s->d_coords, s->n_nodes * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PGSGD_OK;
@@ -1069,11 +1101,14 @@ extern "C" int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words) {
 
 // Coordinates in double precision: exactly x_off + q / quanta_per_bp for the fixed-point format (fp32 cannot hold
 // 1/16 bp at genome-scale coordinates: its spacing is 2-16 bp from 3e7 bp on), the fp32 words widened otherwise.
-extern "C" int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, double* Y) {
+extern "C" int pgsgd_session_download_words(pgsgd_session* s, uint64_t* words) { return read_words(s, words, true); }
+extern "C" int pgsgd_session_peek_words(pgsgd_session* s, uint64_t* words) { return read_words(s, words, false); }
+
+static int read_coords_f64(pgsgd_session* s, double* X, double* Y, bool flush) {
     pgsgd::clear_error();
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     std::vector<uint64_t> w(2 * s->n_nodes);
-    const int rc = pgsgd_session_download_words(s, w.data());
+    const int rc = read_words(s, w.data(), flush);
     if (rc) return rc;
     const pgsgd::Xform& xf = s->dc.xf;
     for (uint64_t i = 0; i < w.size(); ++i) {
@@ -1091,6 +1126,8 @@ extern "C" int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, do
     }
     return PGSGD_OK;
 }
+extern "C" int pgsgd_session_download_coords_f64(pgsgd_session* s, double* X, double* Y) { return read_coords_f64(s, X, Y, true); }
+extern "C" int pgsgd_session_peek_coords_f64(pgsgd_session* s, double* X, double* Y) { return read_coords_f64(s, X, Y, false); }
 
 extern "C" int pgsgd_session_coord_format(const pgsgd_session* s, int* fixed_point, double* x_off, double* y_off, double* quanta_per_bp) {
     if (!s) return PGSGD_E_INVALID;
@@ -1362,7 +1399,15 @@ extern "C" int pgsgd_session_flush(pgsgd_session* s) {
     HIP_TRY(hipSetDevice(s->device));
     // (the counter zeroed is the one the next launch — colour 0 unless it has no items — will write)
     const int next_colour = s->n_items[0] ? 0 : 1;
-    return drain_outbox(s, s->d_far + 2 * next_colour + (s->far_launches[next_colour] & 1u));
+    pgsgd_session::EvSet ev;
+    int rc = take_events(s, &ev);
+    if (rc) return rc;
+    ev.n = 1;
+    HIP_TRY(hipEventRecord(ev.e[2], s->stream));
+    rc = drain_outbox(s, s->d_far + 2 * next_colour + (s->far_launches[next_colour] & 1u));
+    HIP_TRY(hipEventRecord(ev.e[3], s->stream));
+    s->pending_events.push_back(ev);
+    return rc;
 }
 
 extern "C" int pgsgd_session_iteration(pgsgd_session* s, double eta, int cooling, uint64_t n_terms) {
@@ -1392,7 +1437,10 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         }
     }
     HIP_TRY(hipSetDevice(s->device));
-    if (part == 0) s->tile_epoch++;  // iterations started, whichever kernel runs them (tile seeds, far-pull relaxation)
+    if (part == 0) {  // iterations started, whichever kernel runs them: tile_epoch seeds the tile streams, relax_iter counts
+        s->tile_epoch++;   // the iterations of this layout (pgsgd_session_upload_coords starts it again) for the far pulls' gentle start
+        s->relax_iter++;
+    }
     if (s->pending_events.size() >= 64) {  // bound the event pool
         HIP_TRY(hipStreamSynchronize(s->stream));
         int rc = collect_events(s);
@@ -1448,13 +1496,14 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
-            ta.far_relax = pgsgd::tile_far_relax(s->tile_epoch - 1);
+            ta.far_relax = pgsgd::tile_far_relax(s->relax_iter - 1);
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
             ta.wq_threshold = s->tile_wq_threshold;
             ta.pair_uniform = s->tile_pair_uniform;
+            ta.clock_probe = s->d_clock;
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;
@@ -1498,6 +1547,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             if (windowless) {
                 pgsgd::TileArgs tw = ta;
+                tw.clock_probe = nullptr;
                 tw.items = ta.items + ta.n_items;
                 tw.n_items = windowless;
                 tw.queue = s->d_queue + 2 * pgsgd::kItemQueues;
@@ -1651,6 +1701,26 @@ extern "C" int64_t pgsgd_session_outbox_overflow(pgsgd_session* s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(&v, s->d_ob_overflow, sizeof v, hipMemcpyDeviceToHost));
     return (int64_t)v;
+}
+
+// The shader clock the last tile launch ran at, from the two counters its workgroup 0 read when it started and ended
+// (shader cycles against the constant 100 MHz reference).  Blocks until the stream is idle.  0 when no tile launch ran.
+extern "C" int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double* launch_ms) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (mhz) *mhz = 0.0;
+    if (launch_ms) *launch_ms = 0.0;
+    if (!s->d_clock) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(v, s->d_clock, sizeof v, hipMemcpyDeviceToHost));
+    if (v[3] > v[1] && v[2] > v[0]) {
+        const double us = (double)(v[3] - v[1]) / 100.0;  // 100 MHz ticks
+        if (mhz) *mhz = (double)(v[2] - v[0]) / us;
+        if (launch_ms) *launch_ms = us / 1e3;
+    }
+    return PGSGD_OK;
 }
 
 extern "C" int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launches, uint64_t* copies) {
@@ -1820,7 +1890,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         if (p->snapshot && p->snapshot_prefix) {  // :379-408: snapshot k after iteration k, k = 1..iter_max-1
             sx.resize(2 * g->n_nodes);
             sy.resize(2 * g->n_nodes);
-            rc = pgsgd_session_download_coords(s, sx.data(), sy.data());
+            rc = pgsgd_session_peek_coords(s, sx.data(), sy.data());  // (between iterations: the last launch's far pulls arrive with the next one)
             if (rc) break;
             const std::string name = std::string(p->snapshot_prefix) + std::to_string(it + 1);
             fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");

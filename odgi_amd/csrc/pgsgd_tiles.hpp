@@ -150,6 +150,7 @@ struct TileArgs {
     uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
                                        // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
+    unsigned long long* clock_probe;   // [4] {shader cycles, 100 MHz ticks} when workgroup 0 starts and ends: the launch's achieved shader clock
     uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
@@ -614,6 +615,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         L.wq_b = reinterpret_cast<uint8_t*>(L.chunk0 + L.n_buckets);
         for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + lines; i += blockDim.x) L.head[i] = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {  // (workgroups are persistent: workgroup 0 lives as long as the launch has work)
+        ta.clock_probe[0] = __builtin_readcyclecounter();   // s_memtime: shader cycles
+        ta.clock_probe[1] = wall_clock64();                 // s_memrealtime: constant 100 MHz
+    }
     // this wave's message queue; its fill count is wave-uniform and lives in a scalar register
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQueue wq;
@@ -910,6 +915,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 const uint32_t lines = used > k * kObLinesPerChunk ? (used - k * kObLinesPerChunk < kObLinesPerChunk ? used - k * kObLinesPerChunk : kObLinesPerChunk) : 0u;
                 ta.ob.fill[ta.ob.chunk0[b] + chunk + k] = lines * kObLine;
             }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {
+        ta.clock_probe[2] = __builtin_readcyclecounter();
+        ta.clock_probe[3] = wall_clock64();
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
     if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(ta.far_count, (unsigned long long)n_far);

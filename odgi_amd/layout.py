@@ -162,32 +162,29 @@ class LayoutSession:
         check(lib.pgsgd_session_flush(self._h), "flush")
 
     def download(self, flush=True):
-        """Coordinates as fp32 [2N] X, Y.  flush=False: as a snapshot between iterations sees them, without the far
-        pulls the last tile launch collected (they are delivered right before the next launch)."""
-        if flush:
-            self.flush()
+        """Coordinates as fp32 [2N] X, Y (pgsgd_session_download_coords: the far pulls of the last tile launch delivered).
+        flush=False: as a snapshot between iterations sees them (pgsgd_session_peek_coords), without those pulls."""
         n = 2 * self.graph.n_nodes
         X = np.zeros(n, dtype=np.float32)
         Y = np.zeros(n, dtype=np.float32)
-        check(lib.pgsgd_session_download_coords(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
+        f = lib.pgsgd_session_download_coords if flush else lib.pgsgd_session_peek_coords
+        check(f(self._h, X.ctypes.data_as(_F32P), Y.ctypes.data_as(_F32P)), "download")
         return X, Y
 
     def download_f64(self, flush=True):
         """Coordinates in double precision: exactly x_off + q / quanta_per_bp of the fixed-point words."""
-        if flush:
-            self.flush()
         n = 2 * self.graph.n_nodes
         X, Y = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
         f64p = C.POINTER(C.c_double)
-        check(lib.pgsgd_session_download_coords_f64(self._h, X.ctypes.data_as(f64p), Y.ctypes.data_as(f64p)), "download_f64")
+        f = lib.pgsgd_session_download_coords_f64 if flush else lib.pgsgd_session_peek_coords_f64
+        check(f(self._h, X.ctypes.data_as(f64p), Y.ctypes.data_as(f64p)), "download_f64")
         return X, Y
 
     def download_words(self, flush=True):
         """Raw device coordinate words, uint64 [2N] (see coord_format)."""
-        if flush:
-            self.flush()
         w = np.zeros(2 * self.graph.n_nodes, dtype=np.uint64)
-        check(lib.pgsgd_session_download_words(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "download_words")
+        f = lib.pgsgd_session_download_words if flush else lib.pgsgd_session_peek_words
+        check(f(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "download_words")
         return w
 
     def tile_info(self):
@@ -284,6 +281,12 @@ class LayoutSession:
         a, b = C.c_double(), C.c_double()
         check(lib.pgsgd_session_aux_time(self._h, C.byref(a), C.byref(b)), "aux_time")
         return a.value, b.value
+
+    def shader_clock(self):
+        """(MHz, ms): the shader clock the last tile-kernel launch ran at and its duration as its first workgroup saw it."""
+        mhz, ms = C.c_double(), C.c_double()
+        check(lib.pgsgd_session_shader_clock(self._h, C.byref(mhz), C.byref(ms)), "shader_clock")
+        return mhz.value, ms.value
 
     def launch_counts(self):
         """(kernel launches, memsets + copies) the session's iterations have put on the stream."""

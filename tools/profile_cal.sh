@@ -23,6 +23,8 @@ pass write WRITE_SIZE
 pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 pass wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 pass hit TCC_HIT_sum TCC_MISS_sum
+pass rdsize TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pass rddram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum
 python3 - "$OUT" <<'PY'
 import sqlite3, sys, os, json, glob
 out = sys.argv[1]
