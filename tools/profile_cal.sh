@@ -43,6 +43,10 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
             for key in ("cal_stream_read", "cal_stream_write", "cal_gather16", "cal_gather32", "cal_linewrite64", "cal_gather_halves", "sgd_tile_kernel", "far_drain_kernel", "snapshot_kernel"):
                 if key in k: short = key
             if short and "policy" in k: short = "cal_gather16_policy" + k[k.index("policy") + 6:][:8]
+            if short == "sgd_tile_kernel":   # sgd_tile_kernel<COORD_LOAD, FAR, COOLING, LOCAL, MATH, ABL>
+                import re
+                m = re.search(r"sgd_tile_kernel<\s*\d+,\s*\d+,\s*(\w+),\s*(\w+)", k)
+                if m: short += ("_cooling" if m.group(1) in ("true", "1") else "_warm") + ("" if m.group(2) in ("true", "1") else "_windowless")
             if short:
                 res.setdefault(("mb:" if tag.startswith("mb_") else "bench:") + short, {})[c] = {"dispatches": n, "mean": v, "mean_duration_ns": dur}
 known = {}
