@@ -382,8 +382,12 @@ def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, f
     band = 1.5 if flags & _lib.FLAG_HOGWILD_STORES else 1.15 if m > 1 else 1.10
     print(f"{name} flags {flags} m {m}: stress gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} "
           f"mean/median {s_gpu:.4f}/{s_cpu:.4f} band {band}; path distance {d_gpu:.3f}/{d_cpu:.3f}; streams {gpu[0][2]}")
-    assert s_gpu <= band * s_cpu
-    assert d_gpu <= band * d_cpu
+    # two-sided: not worse than the CPU restatement's median by more than the band, and not BETTER than its best run by
+    # more than 10 % either — a sampler that drew too many short pairs would look better by this metric
+    lo_s, lo_d = min(r[0] for r in cpu) / 1.10, min(r[1] for r in cpu) / 1.10
+    print(f"   ratios: stress gpu/cpu-median {s_gpu / s_cpu:.3f} gpu/cpu-best {s_gpu / min(r[0] for r in cpu):.3f}; path distance {d_gpu / d_cpu:.3f}")
+    assert lo_s <= s_gpu <= band * s_cpu
+    assert lo_d <= d_gpu <= band * d_cpu
 
 
 def test_reference_layout_quality_bar(oa, orc, graphs, ographs):
@@ -397,7 +401,9 @@ def test_reference_layout_quality_bar(oa, orc, graphs, ographs):
         oa.path_linear_sgd_layout_gpu(g, dataclasses.replace(_params(oa, g), seed=9399220 + 7919 * i), X, Y)
         vals.append(orc.path_stress_exhaustive(og, X, Y))
     print("DRB1-3123_unsorted exhaustive stress", vals, "(the reference's own layout of this graph: 0.0871; GPU runs in round 1: 0.0755 .. 0.0762)")
-    assert float(np.mean(vals)) <= 0.0871 * 1.10
+    # two-sided: with today's default cooling phase the restatement and the GPU both land 13 % BELOW the reference's file
+    # (made without it: test_reference_fixture_statistics_two_sided_on_gpu reproduces the file itself); 5 % either way
+    assert 0.0757 * 0.95 <= float(np.mean(vals)) <= 0.0757 * 1.05
 
 
 def test_reference_fixture_statistics_two_sided_on_gpu(oa, orc, graphs, ographs):
@@ -424,20 +430,26 @@ def test_reference_fixture_statistics_two_sided_on_gpu(oa, orc, graphs, ographs)
     assert 0.072 <= default["stress"] <= 0.079 and 8.75 <= default["per_node"] <= 9.15, default
 
 
-def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs):
-    """BASELINE config 3 in small: deterministic -N h initial layout, theta and -K sweep."""
+@pytest.mark.parametrize("theta", [0.5, 0.9, 0.99, 0.999])
+def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs, theta):
+    """BASELINE config 3 in small: deterministic -N h initial layout, the whole theta x -K sweep of SURVEY 8(d)
+    (theta in {0.5, 0.9, 0.99, 0.999} x -K in {0.25, 0.5, 0.75}), two-sided."""
     g, og = graphs("chr6.C4"), ographs("chr6.C4")
     # The Hilbert initial layout is deterministic (no seed): the three runs of each side differ by sampler seed
     # (GPU) and thread timing (CPU).  theta 0.5 makes the partner distribution nearly flat: from the compact
     # Hilbert start the layout barely unfolds and the CPU restatement itself lands anywhere in 60..160 from run
-    # to run (profiles/r01/pytest_gpu_*.log), so that point only gets a factor-2 band on mean vs median; the
-    # other two scatter by < 5 % on either side: 15 %.
-    for theta, K, band in [(0.5, 0.5, 2.0), (0.9, 0.25, 1.15), (0.999, 0.75, 1.15)]:
+    # to run (profiles/r01/pytest_gpu_*.log), so those points only get a factor-2 band on mean vs median (and vs the
+    # best run, downwards); at theta 0.9 the CPU restatement's three runs still differ by 10-25 % among themselves
+    # (1.57 .. 1.97 at -K 0.5) and the GPU's mean sits 0.70-1.02 of their median: 30 %; at 0.99 and 0.999 both sides
+    # scatter by < 2 % and agree within 5 %: 10 % up against the median, 10 % down against the CPU restatement's best
+    # run.  Measured ratios of all twelve points: profiles/r04/pytest_gpu_two_sided_ratios.log.
+    band = 2.0 if theta == 0.5 else 1.3 if theta == 0.9 else 1.10
+    for K in (0.25, 0.5, 0.75):
         p = _params(oa, g, theta=theta, cooling_start=K)
         gpu, cpu = _gpu_runs(oa, orc, g, og, p, init="h"), _cpu_runs(oa, orc, g, og, "chr6.C4", p, init="h")
-        s_gpu, s_cpu = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu]))
-        print(f"theta {theta} K {K}: gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]}")
-        assert s_gpu <= band * s_cpu
+        s_gpu, s_cpu, best = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu])), min(r[0] for r in cpu)
+        print(f"theta {theta} K {K}: gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} gpu/cpu-median {s_gpu / s_cpu:.3f} gpu/cpu-best {s_gpu / best:.3f}")
+        assert best / band <= s_gpu <= band * s_cpu, (theta, K, s_gpu, s_cpu, best)
 
 
 def test_delta_early_stop_and_counts(oa, graphs):
