@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stress", action="store_true", help="also report sampled path stress of the final layout")
     ap.add_argument("--no-tiles", action="store_true", help="force the per-lane kernel (PGSGD_FLAG_NO_TILES)")
+    ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="extra PGSGD_FLAG_* bits (A/B runs: 0x2000 exact math, 0x4000 no partner pairs)")
+    ap.add_argument("--seed", type=int, default=None, help="sampler seed (default: the reference's 9399220)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank exchange (prepare, all-reduce, merge) even at world size 1: under "
                          "`torchrun --nproc-per-node 1` this executes the RCCL path on a single-GPU box")
@@ -82,7 +84,9 @@ def main():
     iters = max(30, args.warmup + args.steps)
     from odgi_amd import _lib
     p = oa.LayoutParams.defaults(g, iter_max=iters, n_streams=args.streams, device=local_rank,
-                                 flags=_lib.FLAG_NO_TILES if args.no_tiles else 0)
+                                 flags=(_lib.FLAG_NO_TILES if args.no_tiles else 0) | args.flags)
+    if args.seed is not None:
+        p.seed = args.seed
     X0, Y0 = oa.initial_layout(g, "d", seed=42)
     if rank == 0:
         log(f"[bench] graph N={g.n_nodes} S={g.n_steps} P={g.n_paths} terms/iter={p.min_term_updates} "

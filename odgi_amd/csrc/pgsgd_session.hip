@@ -113,6 +113,7 @@ struct pgsgd_session {
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
+    uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
     uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
@@ -735,6 +736,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->tile_forced = force;
         s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
         s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 1u;
+        s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
+        if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
         bool short_paths = true, paths_32 = true;  // (the fast instance keeps positions as 32-bit words: every path shorter than 2^32 bp)
@@ -1502,6 +1505,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
             ta.wq_threshold = s->tile_wq_threshold;
+            ta.lane_coin = s->tile_lane_coin;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;
             ta.ob = s->ob;

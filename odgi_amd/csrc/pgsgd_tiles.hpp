@@ -152,6 +152,7 @@ struct TileArgs {
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
     unsigned long long* clock_probe;   // [4] {shader cycles, 100 MHz ticks} when workgroup 0 starts and ends: the launch's achieved shader clock
     uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
+    uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
 };
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     // first step: uniform inside the tile; the reference's coins (path_sgd_layout.cpp:206,253,262) from the same word
                     Kw.ka = below32_hi(rng, t.n, Kw.flags);
                     // the Zipf/uniform coin (:205) is the wave's for this trip (tile_coin_seed); it rides in bit 31 of the flags
-                    if (!COOLING) Kw.flags = (Kw.flags & 0x7fffffffu) | ((uint32_t)(coin_cur >> (j & 63u)) << 31);
+                    if (!COOLING && !ta.lane_coin) Kw.flags = (Kw.flags & 0x7fffffffu) | ((uint32_t)(coin_cur >> (j & 63u)) << 31);
                     uint32_t s_rank;
                     bool zipf, back;
                     const uint32_t jump = jump_of(Kw.ka, Kw.flags, s_rank, zipf, back);
