@@ -98,6 +98,10 @@ typedef struct pgsgd_graph_view {
                                            /* lanes of a wave pair up in a warm iteration's uniform trips: the odd lane takes the step that shares */
                                            /* a 64-byte unit with its even neighbour's partner (one memory request for two terms; every partner  */
                                            /* is still uniform over the path).  A/B and parity                                                  */
+#define PGSGD_FLAG_LOCK_WINDOW_ENDS 0x8000u /* tile kernel, option (measured: no effect on the layout, 3 % slower — profiles/r04/NOTES.md): conflict   */
+                                           /* resolution on shared node coordinates.  While a term's learning rate is in the projection regime     */
+                                           /* (mu >= 0.1) it takes a lock bit on each of its window ends (one LDS atomic OR per end; the lanes of a  */
+                                           /* wave that go for one end are served one after the other) and does nothing when an end is taken       */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -228,6 +232,9 @@ int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launche
  * workgroup saw it (s_memtime against the constant 100 MHz s_memrealtime); blocks until the stream is idle; 0 when the
  * session has run no tile launch. */
 int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double* launch_ms);
+/* Tile kernel: terms that went for their window ends' locks so far (conflict resolution on shared node coordinates while
+ * the learning rate is in the projection regime), and terms among them that found an end taken and did nothing. */
+int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost);
 /* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
  * direct atomic adds instead (0 in normal operation; the pool is sized from the tile table). */
 int64_t pgsgd_session_outbox_overflow(pgsgd_session* s);

@@ -58,6 +58,7 @@ FLAG_NO_PIPELINE = 0x80
 FLAG_NO_SPLIT = 0x1000
 FLAG_EXACT_MATH = 0x2000
 FLAG_NO_PARTNER_PAIRS = 0x4000
+FLAG_LOCK_WINDOW_ENDS = 0x8000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
@@ -96,6 +97,7 @@ SIGNATURES = [
     ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_launch_counts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_shader_clock", C.c_int, [C.c_void_p, P(f64), P(f64)]),
+    ("pgsgd_session_tile_conflicts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),

@@ -113,7 +113,9 @@ struct pgsgd_session {
     size_t tile_lds = 0;
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
+    float tile_lock_mu = 0.0f;        // TileArgs::lock_mu (debug knob PGSGD_TILE_LOCK_MU)
     uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
+    float tile_far_relax_override = 0.0f;  // debug knob PGSGD_TILE_FAR_RELAX: a constant under-relaxation of the far pulls instead of tile_far_relax()
     uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
@@ -697,7 +699,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
         }
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
-        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
         int bpc = 0;
         S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
         if (bpc < 1) bpc = 1;
@@ -717,18 +719,18 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (r != s->region) {
                 s->region = r;
                 s->tile_steps = r - r / 8;
-                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
                 int bpc_r = 0;
                 S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_r, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
                 if (bpc_r < bpc) {  // (cannot happen at 272 nodes per region with the default bucket count; keep the validated size if it does)
                     s->region = 256;
                     s->tile_steps = 224;
-                    s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+                    s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
                 }
             }
             if (steps_given >= 16 && steps_given <= (long)s->region) s->tile_steps = (uint32_t)steps_given;
         }
-        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets);
+        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
         // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
@@ -736,7 +738,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->tile_forced = force;
         s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
         s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 1u;
+        s->tile_lock_mu = (p->flags & PGSGD_FLAG_LOCK_WINDOW_ENDS) ? 0.1f : 0.0f;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
@@ -824,8 +829,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(uint64_t) << 14)));
                 S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
-                S_TRY(hipMalloc(&s->d_clock, 4 * sizeof(unsigned long long)));
-                S_TRY(hipMemset(s->d_clock, 0, 4 * sizeof(unsigned long long)));
+                S_TRY(hipMalloc(&s->d_clock, 6 * sizeof(unsigned long long)));
+                S_TRY(hipMemset(s->d_clock, 0, 6 * sizeof(unsigned long long)));
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
@@ -1499,13 +1504,14 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
-            ta.far_relax = pgsgd::tile_far_relax(s->relax_iter - 1);
+            ta.far_relax = s->tile_far_relax_override > 0.0f ? s->tile_far_relax_override : pgsgd::tile_far_relax(s->relax_iter - 1);
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
             ta.wq_threshold = s->tile_wq_threshold;
             ta.lane_coin = s->tile_lane_coin;
+            ta.lock_mu = s->tile_lock_mu;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;
             ta.ob = s->ob;
@@ -1724,6 +1730,22 @@ extern "C" int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double*
         if (mhz) *mhz = (double)(v[2] - v[0]) / us;
         if (launch_ms) *launch_ms = us / 1e3;
     }
+    return PGSGD_OK;
+}
+
+// Terms of the tile kernel that went for their ends' locks, and terms that found one taken and did nothing (cumulative).
+extern "C" int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (locked) *locked = 0;
+    if (lost) *lost = 0;
+    if (!s->d_clock) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(v, s->d_clock, sizeof v, hipMemcpyDeviceToHost));
+    if (locked) *locked = v[4];
+    if (lost) *lost = v[5];
     return PGSGD_OK;
 }
 

@@ -150,8 +150,10 @@ struct TileArgs {
     uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
                                        // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
-    unsigned long long* clock_probe;   // [4] {shader cycles, 100 MHz ticks} when workgroup 0 starts and ends: the launch's achieved shader clock
+    unsigned long long* clock_probe;   // [6] {shader cycles, 100 MHz ticks} when workgroup 0 starts and ends: the launch's achieved shader clock; [4], [5]: terms
+                                       // that went for their ends' locks, and that lost one (cumulative)
     uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
+    float lock_mu;                     // conflict resolution inside a window: terms whose learning rate mu reaches this take both their ends' locks or do nothing (0: off)
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
@@ -204,6 +206,7 @@ struct OutboxLds {
     uint32_t ring_b0; // bucket of hot ring 0 (the window's), wave-uniform
 };
 
+__host__ __device__ inline uint32_t tile_lock_words(uint32_t region) { return (4u * region + 31u) / 32u; }
 __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
     const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
     return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * 64 * sizeof(uint2) + (size_t)kTileWaves * kWqCap * (sizeof(uint64_t) + 1) +
@@ -616,6 +619,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         L.wq_b = reinterpret_cast<uint8_t*>(L.chunk0 + L.n_buckets);
         for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + lines; i += blockDim.x) L.head[i] = 0;
     }
+    // one lock bit per window word (tile_lock_words(region) 32-bit words behind the queues' bucket bytes)
+    uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b + kTileWaves * kWqCap);
+    for (uint32_t i = threadIdx.x; i < tile_lock_words(ta.region); i += blockDim.x) lockw[i] = 0;
+    uint32_t n_locked = 0, n_lost = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {  // (workgroups are persistent: workgroup 0 lives as long as the launch has work)
         ta.clock_probe[0] = __builtin_readcyclecounter();   // s_memtime: shader cycles
         ta.clock_probe[1] = wall_clock64();                 // s_memrealtime: constant 100 MHz
@@ -806,6 +813,30 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     // here (no dead global loads in the windowed instance: the compiler could not count what is in flight).
                     const uint32_t la = end_a - wbase, lb = end_b - wbase;
                     const bool in_a = LOCAL, in_b = LOCAL && lb < win_words;
+                    // Conflict resolution on shared node coordinates.  256 lanes work on a window of ~1 000 node ends: an eighth of
+                    // the ends a wave touches in a trip are touched by another lane at the same time, and two projections computed
+                    // from the same stale position add up to twice the move.  While a term's learning rate is large (mu >= lock_mu:
+                    // the projection regime) it therefore takes a lock bit on each of its window ends before it reads them — one LDS
+                    // atomic OR per end; the lanes of a wave that go for the same end are served one after the other by the LDS, and
+                    // exactly one of them finds the bit clear — and a term that finds an end taken does nothing at all (like a
+                    // lost update of the reference's Hogwild loop, path_sgd_layout.cpp:360-363, but of the whole term: the sums of
+                    // the coordinates stay conserved).  The owner clears its bits after its atomic adds.  A one-lane run never
+                    // loses a term: the mirror tests are unaffected.
+                    bool own_a = false, own_b = false, lost = false;
+                    if (LOCAL && ta.lock_mu > 0.0f) {
+                        const float mu0 = a.eta * __builtin_amdgcn_rcpf(d > 0.0f ? d : 1e-9f);
+                        if (mu0 >= ta.lock_mu) {
+                            ++n_locked;
+                            const uint32_t bit_a = 1u << (la & 31u);
+                            own_a = !(atomicOr(lockw + (la >> 5), bit_a) & bit_a);
+                            lost = !own_a;
+                            if (in_b && lb != la) {
+                                const uint32_t bit_b = 1u << (lb & 31u);
+                                own_b = !(atomicOr(lockw + (lb >> 5), bit_b) & bit_b);
+                                lost = lost || !own_b;
+                            }
+                        }
+                    }
                     uint64_t wa, wb;
                     if (LOCAL) {
                         wa = win[la];
@@ -834,7 +865,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     const int32_t qx = (int32_t)floorf(fx), qy = (int32_t)floorf(fy);  // (clamped to the 32-bit range above)
                     // a step that rounds to no quantum adds zero: nothing to send, in particular no message
                     // for a far partner (most far terms of the late iterations, where eta / d^2 is tiny)
-                    if ((qx | qy) != 0) {
+                    if (lost) ++n_lost;
+                    if ((qx | qy) != 0 && !lost) {
                         n_far += (in_b || one_sided) ? 0u : 1u;
                         mqx = qx;
                         mqy = qy;
@@ -844,6 +876,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         if (in_a) atomicAdd(reinterpret_cast<unsigned long long*>(win + la), (unsigned long long)(0ull - delta));
                         else msg_a = true;
                     }
+                    if (own_a) atomicAnd(lockw + (la >> 5), ~(1u << (la & 31u)));   // (LDS operations of a wave execute in order: after the adds)
+                    if (own_b) atomicAnd(lockw + (lb >> 5), ~(1u << (lb & 31u)));
                 }
                 if (ABL == 1) msg_a = msg_b = false;  // profiling instance: far updates are dropped (results invalid)
                 return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
@@ -916,6 +950,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 const uint32_t lines = used > k * kObLinesPerChunk ? (used - k * kObLinesPerChunk < kObLinesPerChunk ? used - k * kObLinesPerChunk : kObLinesPerChunk) : 0u;
                 ta.ob.fill[ta.ob.chunk0[b] + chunk + k] = lines * kObLine;
             }
+    }
+    if (ta.clock_probe && ta.lock_mu > 0.0f) {
+        for (int off = 32; off > 0; off >>= 1) { n_locked += __shfl_xor(n_locked, off); n_lost += __shfl_xor(n_lost, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(ta.clock_probe + 4, (unsigned long long)n_locked); atomicAdd(ta.clock_probe + 5, (unsigned long long)n_lost); }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {
         ta.clock_probe[2] = __builtin_readcyclecounter();

@@ -288,6 +288,12 @@ class LayoutSession:
         check(lib.pgsgd_session_shader_clock(self._h, C.byref(mhz), C.byref(ms)), "shader_clock")
         return mhz.value, ms.value
 
+    def tile_conflicts(self):
+        """(locked, lost): tile-kernel terms that went for their window ends' locks so far, and those that lost one."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib.pgsgd_session_tile_conflicts(self._h, C.byref(a), C.byref(b)), "tile_conflicts")
+        return a.value, b.value
+
     def launch_counts(self):
         """(kernel launches, memsets + copies) the session's iterations have put on the stream."""
         k, c = C.c_uint64(), C.c_uint64()
