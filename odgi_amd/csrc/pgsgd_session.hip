@@ -316,8 +316,12 @@ static tile_kernel_t tile_kernel_f(bool cooling, bool local) {
     if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH> : sgd_tile_kernel<1, FAR, false, true, MATH>;
     return cooling ? sgd_tile_kernel<1, FAR, true, false, MATH> : sgd_tile_kernel<1, FAR, false, false, MATH>;
 }
-// math: pgsgd::kMathFast (what sessions run) or kMathExact (PGSGD_FLAG_EXACT_MATH, paths of 2^32 bp and more)
-static tile_kernel_t tile_kernel(int far, int math, bool cooling = false, bool local = true) {
+// math: pgsgd::kMathFast (what sessions run) or kMathExact (PGSGD_FLAG_EXACT_MATH, paths of 2^32 bp and more); lock: the
+// instance with conflict resolution on the window ends (PGSGD_FLAG_LOCK_WINDOW_ENDS: two-sided far rule, fast math, windowed items)
+static tile_kernel_t tile_kernel(int far, int math, bool cooling = false, bool local = true, bool lock = false) {
+    using namespace pgsgd;
+    if (lock && local && far == kFarTwoSided && math == kMathFast)
+        return cooling ? sgd_tile_kernel<1, kFarTwoSided, true, true, kMathFast, true> : sgd_tile_kernel<1, kFarTwoSided, false, true, kMathFast, true>;
     if (math == pgsgd::kMathExact)
         return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathExact>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathExact>(cooling, local);
     return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathFast>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathFast>(cooling, local);
@@ -1550,7 +1554,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             HIP_TRY(hipEventRecord(ev.e[0], s->stream));
             if (ta.n_items) {
-                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, true), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, true, s->tile_lock_mu > 0.0f), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
                                    s->dc, ta, ts, a);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());

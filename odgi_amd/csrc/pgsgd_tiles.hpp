@@ -600,7 +600,8 @@ struct PendingTerm {
 #ifndef PGSGD_TILE_WAVES
 #define PGSGD_TILE_WAVES 5
 #endif
-template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, int ABL = 0>
+// LOCK: the instance with conflict resolution on the window's node ends (PGSGD_FLAG_LOCK_WINDOW_ENDS; an option, see the term loop).
+template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     // the coordinates stay conserved).  The owner clears its bits after its atomic adds.  A one-lane run never
                     // loses a term: the mirror tests are unaffected.
                     bool own_a = false, own_b = false, lost = false;
-                    if (LOCAL && ta.lock_mu > 0.0f) {
+                    if (LOCK && LOCAL && ta.lock_mu > 0.0f) {
                         const float mu0 = a.eta * __builtin_amdgcn_rcpf(d > 0.0f ? d : 1e-9f);
                         if (mu0 >= ta.lock_mu) {
                             ++n_locked;
@@ -865,8 +866,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     const int32_t qx = (int32_t)floorf(fx), qy = (int32_t)floorf(fy);  // (clamped to the 32-bit range above)
                     // a step that rounds to no quantum adds zero: nothing to send, in particular no message
                     // for a far partner (most far terms of the late iterations, where eta / d^2 is tiny)
-                    if (lost) ++n_lost;
-                    if ((qx | qy) != 0 && !lost) {
+                    if (LOCK && lost) ++n_lost;
+                    if ((qx | qy) != 0 && !(LOCK && lost)) {
                         n_far += (in_b || one_sided) ? 0u : 1u;
                         mqx = qx;
                         mqy = qy;
@@ -876,8 +877,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         if (in_a) atomicAdd(reinterpret_cast<unsigned long long*>(win + la), (unsigned long long)(0ull - delta));
                         else msg_a = true;
                     }
-                    if (own_a) atomicAnd(lockw + (la >> 5), ~(1u << (la & 31u)));   // (LDS operations of a wave execute in order: after the adds)
-                    if (own_b) atomicAnd(lockw + (lb >> 5), ~(1u << (lb & 31u)));
+                    if (LOCK && own_a) atomicAnd(lockw + (la >> 5), ~(1u << (la & 31u)));   // (LDS operations of a wave execute in order: after the adds)
+                    if (LOCK && own_b) atomicAnd(lockw + (lb >> 5), ~(1u << (lb & 31u)));
                 }
                 if (ABL == 1) msg_a = msg_b = false;  // profiling instance: far updates are dropped (results invalid)
                 return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 ta.ob.fill[ta.ob.chunk0[b] + chunk + k] = lines * kObLine;
             }
     }
-    if (ta.clock_probe && ta.lock_mu > 0.0f) {
+    if (LOCK && ta.clock_probe && ta.lock_mu > 0.0f) {
         for (int off = 32; off > 0; off >>= 1) { n_locked += __shfl_xor(n_locked, off); n_lost += __shfl_xor(n_lost, off); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(ta.clock_probe + 4, (unsigned long long)n_locked); atomicAdd(ta.clock_probe + 5, (unsigned long long)n_lost); }
     }

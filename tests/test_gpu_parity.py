@@ -1069,9 +1069,12 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
             res.setdefault(G, []).append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
     means = {G: float(np.mean(v)) for G, v in res.items()}
     print(f"virtual ranks sharded by {mode}: mean stress {means}, runs {res}")
-    band = {"tiles": {2: 1.20, 4: 1.35, 8: 1.35}, "regions": {2: 1.10, 4: 1.15, 8: 1.15}}[mode]
+    # measured (three seeds each; the means of three runs scatter by ~2 % of themselves): round 3 by tile +5.9 / +9.8 / +16.4 %, by
+    # region +3.6 / +5.4 / +5.3 %; round 4 by tile +4.8 / +9.2 / +14.5 %, by region +3.2 / +4.5 / +4.9 %.  Bands = measured + 3 sigma,
+    # two-sided: a merge that made layouts BETTER than one device's would be as suspect as one that made them worse.
+    band = {"tiles": {2: 1.11, 4: 1.16, 8: 1.22}, "regions": {2: 1.10, 4: 1.11, 8: 1.11}}[mode]
     for G in (2, 4, 8):
-        assert means[G] <= band[G] * means[1], (mode, G, means)
+        assert 0.97 * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
 
 
 @pytest.mark.parametrize("graph_name", ["synthetic-300k", "LPA"])
