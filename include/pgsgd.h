@@ -259,6 +259,13 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
  * on the device (MI355X: 256 CUs x 4): the multiple of 8 in [240, 272] whose work items (one per region of a colour) fill
  * their rounds best, 256 when a launch is a single round or more than eight.  Pure host arithmetic. */
 uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups);
+/* Two rules of the tile kernel's sampler, restated on the host for tests: the Zipf/uniform coin (path_sgd_layout.cpp:205)
+ * that the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration (a SplitMix64 stream per
+ * wave, seeded like a lane's generator with lane id 1023 - wave), and the partner (rank in its path) an odd lane takes in
+ * a uniform trip: the step sharing a 64-byte unit of the step records with its even neighbour's partner, flat step ^ 1,
+ * when that is a step of the path, its own draw otherwise. */
+int pgsgd_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip);
+uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank);
 /* How the session's per-lane launches run: 0 one pass (a lane samples a term and moves its ends), 1 two passes (a small
  * lane-bound graph whose 2N coordinate words fit one compute unit's LDS: pgsgd_session_n_streams() streams sample, one
  * workgroup of *apply_lanes lanes moves the ends in LDS). */

@@ -114,6 +114,8 @@ SIGNATURES = [
     ("pgsgd_session_tile_math", C.c_int, [C.c_void_p]),
     ("pgsgd_debug_tile_displacement", C.c_int, [C.c_int, u64, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]),
     ("pgsgd_tile_region_for", u32, [u64, u64]),
+    ("pgsgd_tile_wave_coin", C.c_int, [u64, u64, u64, u32, u64]),
+    ("pgsgd_tile_pair_partner", u32, [u32, u32, u32, u32]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_from_og", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),

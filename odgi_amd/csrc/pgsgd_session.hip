@@ -283,6 +283,17 @@ static uint32_t choose_region(uint64_t n_nodes, uint64_t slots);
 extern "C" uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups) {
     return n_nodes && resident_workgroups ? choose_region(n_nodes, resident_workgroups) : 256;
 }
+// Host-side copies of two rules of the tile kernel's sampler, for the CPU suite (the kernel, the trace kernel and the
+// oracle's mirror are compared on the GPU): the Zipf/uniform coin a wave's lanes share in a trip of a warm iteration, and
+// the partner an odd lane takes from its even neighbour's in a uniform trip.
+extern "C" int pgsgd_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip) {
+    uint64_t x = pgsgd::tile_coin_seed(seed_base, epoch, tile, wave), w = 0;
+    for (uint64_t k = 0; k <= trip / 64; ++k) w = pgsgd::Xoshiro256Plus::splitmix64(x);
+    return (int)((w >> (trip % 64)) & 1u);
+}
+extern "C" uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank) {
+    return pgsgd::tile_pair_partner(lead_flat_step, path_first_step, path_steps, own_rank);
+}
 static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
     auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
     const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;

@@ -497,3 +497,31 @@ def test_tile_region_size_fills_the_rounds_of_a_launch(oa):
         assert 240 <= r <= 272 and r % 8 == 0
         fill = lambda rr: items(n, rr) / (1024 * -(-items(n, rr) // 1024))
         assert all(fill(r) >= fill(c) - 1e-9 for c in range(240, 273, 8)), (n, r)
+
+
+def test_tile_sampler_rules_host_copies_match_the_oracle(orc):
+    """The wave coin and the partner pair of the tile kernel's sampler (pgsgd_tiles.hpp: tile_coin_seed,
+    tile_pair_partner), through the library's host copies, against the oracle's restatement: the same coins for any
+    (seed, iteration, tile, wave, trip), fair and serially independent; the odd lane's partner is its even neighbour's
+    twin in the 64-byte unit when that is a step of the path and its own draw otherwise."""
+    from odgi_amd import _lib
+    lib = _lib.lib
+    rs = np.random.RandomState(3)
+    for _ in range(200):
+        seed, epoch, tile, wave, trip = int(rs.randint(1, 1 << 40)), int(rs.randint(1, 31)), int(rs.randint(0, 1 << 22)), int(rs.randint(0, 4)), int(rs.randint(0, 5000))
+        assert lib.pgsgd_tile_wave_coin(seed, epoch, tile, wave, trip) == orc.tile_wave_coin(seed, epoch, tile, wave, trip)
+    coins = np.array([lib.pgsgd_tile_wave_coin(9399220, 7, 1234, 2, j) for j in range(20000)])
+    assert abs(coins.mean() - 0.5) < 4 * 0.5 / np.sqrt(len(coins))
+    assert abs(np.mean(coins[1:] == coins[:-1]) - 0.5) < 4 * 0.5 / np.sqrt(len(coins))
+    # different waves, tiles and iterations have different coin streams
+    other = np.array([lib.pgsgd_tile_wave_coin(9399220, 7, 1234, 3, j) for j in range(2000)])
+    assert 0.4 < np.mean(other == coins[:2000]) < 0.6
+    # partner pairs: path of 10 steps starting at flat step 7 (odd: its first step has no twin inside the path)
+    first, cnt = 7, 10
+    for lead_rank in range(cnt):
+        got = lib.pgsgd_tile_pair_partner(first + lead_rank, first, cnt, 3)
+        twin = ((first + lead_rank) ^ 1) - first
+        assert got == (twin if 0 <= twin < cnt else 3), (lead_rank, got)
+    # every step is some step's twin exactly once, but for the path's unpaired ends
+    twins = [lib.pgsgd_tile_pair_partner(first + r, first, cnt, 99) for r in range(cnt)]
+    assert sorted(t for t in twins if t != 99) == [r for r in range(cnt) if 0 <= ((first + r) ^ 1) - first < cnt]
