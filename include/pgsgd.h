@@ -245,9 +245,12 @@ uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
  *                  visited tile with its whole share of terms: no short term loops);
  *   by_region = 1: this device runs work items (node regions with all their tiles) rank, rank+world, ...
  *                  (disjoint windows across devices; needs >= ~1000 regions per device and launch).
+ *   by_region = 2: by region with the EXACT exchange (pgsgd_session_exchange_exact_begin / _end below): an iteration is two
+ *                  parts, one per region colour, each followed by an integer exchange — the devices then hold, bit for
+ *                  bit, one GPU's coordinates.
  *   by_region -1: by region when that leaves every launch at least a thousand work items per device, by tile otherwise.
- * Returns 1 (sharded by tile) or 2 (by region) when the session is tiled, 0 when it runs the per-lane kernel
- * (shard the term count instead), < 0 on error.  The tile streams of a sharded session are keyed on (seed, iteration,
+ * Returns 1 (sharded by tile), 2 (by region) or 3 (by region, exact) when the session is tiled, 0 when it runs the
+ * per-lane kernel (shard the term count instead), < 0 on error.  The tile streams of a sharded session are keyed on (seed, iteration,
  * tile, lane) — stream_offset, which the devices' per-lane streams need to differ, does not enter them. */
 int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region);
 /* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel, 2 (known
@@ -291,6 +294,17 @@ int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_buf_6N_float
  * devices' slots are written as zero, so after the SUM all-reduce of all 6N + 2*world floats every device holds every
  * device's values: the reference's stop rule (path_sgd_layout.cpp:142) and the frame widening need no second collective. */
 int pgsgd_session_exchange_begin_stats(pgsgd_session* s, void* device_buf_6N_plus_2world_floats, uint32_t rank, uint32_t world);
+/* The exact exchange of a tiled session sharded by region with pgsgd_session_set_shard(s, rank, world, 2): an iteration is then
+ * pgsgd_session_iteration_part(s, eta, cooling, n_terms, c, 2) for colour c = 0, 1, each followed by
+ *   exchange_exact_begin  (delivers the launch's far pulls; device_buf[0 .. 2N) = coords - base as 64-bit integers; tail
+ *                          [2N .. 2N + 3 world): in this rank's slots the launch's far-pull count, the bits of its max |Delta|
+ *                          (a float), its frame-guard flag — zero in the other ranks' slots),
+ *   a SUM all-reduce of the 2N + 3 world 64-bit integers over the ranks,
+ *   exchange_exact_end    (coords = base = base + sum; the far-pull count over all ranks goes to the learning-rate cap).
+ * The windows a rank runs in one colour's launch are its alone and integer adds commute, so every rank ends with, bit for
+ * bit, the coordinates one GPU computes (with its snapshot pass per iteration): no merge rule, 16 N bytes per exchange. */
+int pgsgd_session_exchange_exact_begin(pgsgd_session* s, void* device_buf_2N_plus_3world_u64, uint32_t rank, uint32_t world);
+int pgsgd_session_exchange_exact_end(pgsgd_session* s, const void* device_buf_2N_plus_3world_u64, uint32_t world);
 /* Parity hooks of the tile kernel.  Every term of a tiled iteration is a pure function of (seed +
  * stream_offset, iteration number, tile, lane of the tile, position in the lane's stream); tile_table copies up to `capacity` tiles (in work order:
  * first step, steps before the tile, steps, path) and returns their number; trace_tile_terms replays the

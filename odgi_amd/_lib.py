@@ -109,6 +109,8 @@ SIGNATURES = [
     ("pgsgd_session_tile_items", i64, [C.c_void_p, P(u32), P(u32), P(u32), P(u32), u64, P(u64)]),
     ("pgsgd_session_trace_tile_terms", i64, [C.c_void_p, u64, C.c_int, u64, u64, P(u64), u64]),
     ("pgsgd_session_set_shard", C.c_int, [C.c_void_p, u32, u32, C.c_int]),
+    ("pgsgd_session_exchange_exact_begin", C.c_int, [C.c_void_p, C.c_void_p, u32, u32]),
+    ("pgsgd_session_exchange_exact_end", C.c_int, [C.c_void_p, C.c_void_p, u32]),
     ("pgsgd_session_tile_info", C.c_int, [C.c_void_p, P(u64), P(u64), P(u64), P(u32), P(u32)]),
     ("pgsgd_session_split_info", C.c_int, [C.c_void_p, P(u32)]),
     ("pgsgd_session_tile_math", C.c_int, [C.c_void_p]),

@@ -1208,4 +1208,35 @@ __global__ void exchange_apply_kernel(uint64_t* coords, uint64_t* base, uint64_t
     }
 }
 
+// The exact exchange of a region-sharded tiled session (pgsgd_session_exchange_exact_*): after the launch of one colour the
+// windows a rank ran are its alone and its far pulls are drained, so what it changed is a 64-bit integer delta per node end
+// that nobody else's delta collides with but by plain addition: buf[e] = coords[e] - base[e] (mod 2^64), an integer SUM
+// all-reduce, coords[e] = base[e] + sum — bit for bit what one GPU computes, with no merge rule.  The tail carries, in a
+// slot per rank, the launch's far-pull count (the learning-rate cap of far terms needs the count over all ranks), the
+// bits of its max |Delta| and its frame-guard flag.
+__global__ void exchange_exact_prepare_kernel(const uint64_t* coords, const uint64_t* base, uint64_t n_ends, uint64_t* buf) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) buf[i] = coords[i] - base[i];
+}
+__global__ void exchange_exact_tail_kernel(const unsigned int* delta_max_bits, const unsigned long long* far_count, uint32_t rank, uint32_t world, uint64_t* tail) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * world) return;
+    uint64_t v = 0;
+    if (i == rank) v = far_count ? *far_count : 0ull;
+    if (i == world + rank) v = delta_max_bits[0];
+    if (i == 2 * world + rank) v = delta_max_bits[1] ? 1ull : 0ull;
+    tail[i] = v;
+}
+__global__ void exchange_exact_apply_kernel(uint64_t* coords, uint64_t* base, uint64_t n_ends, const uint64_t* buf, unsigned long long* far_count, uint32_t world) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = base[i] + buf[i];
+        coords[i] = w;
+        base[i] = w;
+    }
+    if (far_count && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (uint32_t r = 0; r < world; ++r) acc += buf[n_ends + r];
+        *far_count = acc;
+    }
+}
+
 }  // namespace pgsgd

@@ -29,7 +29,7 @@
 extern "C" {
 typedef struct ncclComm* ncclComm_t;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat32 = 7, ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclUint64 = 5, ncclFloat32 = 7, ncclFloat = 7 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
@@ -122,6 +122,7 @@ struct Shared {
     Rccl* rccl = nullptr;               // null: host-staged sum
     std::vector<ncclComm_t> comms;
     std::vector<float*> host_buf;       // [2G] pinned, host-staged sum only
+    std::vector<std::vector<uint64_t>> host_tail64;  // [G][2G] the exact exchange's tail as read back
     std::vector<int> rc;                // [G] first error of each rank
     std::vector<std::string> err;       // [G]
     // what rank 0 found when it set its session up; the ranks' sessions are built from the same graph and layout, so
@@ -166,6 +167,9 @@ void rank_main(Shared& sh, int r) {
     const pgsgd_params& p0 = *sh.p;
     const uint64_t N = sh.g->n_nodes;
     const size_t buf_floats = 6 * N + 2 * (size_t)G;  // S (4N), Q (2N), then every rank's max |Delta| and frame-guard flag
+    const size_t buf_words = 2 * N + 3 * (size_t)G;   // the exact exchange: 2N integer deltas, then every rank's far-pull count, max |Delta| bits, guard flag
+    static_assert(sizeof(uint64_t) == 2 * sizeof(float), "the two exchanges share one buffer");
+    const size_t buf_bytes = std::max(buf_floats * sizeof(float), buf_words * sizeof(uint64_t));
     pgsgd_params p = p0;
     p.device = sh.devices[r];
     // Sampler streams: the per-lane kernel's lane l draws from seed + stream_offset + l, so ranks take disjoint blocks of
@@ -184,18 +188,27 @@ void rank_main(Shared& sh, int r) {
     R_TRY(pgsgd_session_create(sh.g, &p, &s));
     if (s) R_TRY(pgsgd_session_upload_coords(s, sh.X0, sh.Y0));
     if (s) R_TRY(pgsgd_session_exchange_mark(s));
-    bool engine_sharded = false;
+    bool engine_sharded = false, exact = false;  // exact: region shard, an integer exchange after each colour's launch
     if (s && !sh.rc[r]) {
         const int info = pgsgd_session_tile_info(s, nullptr, nullptr, nullptr, nullptr, nullptr);
         // by tile, or by node region when that leaves every launch enough work items (decided by the session: -1)
-        const int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, -1);
+        int want = -1;
+        if (const char* e = pgsgd::debug_env("PGSGD_MULTI_SHARD"))  // test knob: tiles / regions / exact whatever the graph's size
+            want = !strcmp(e, "tiles") ? 0 : !strcmp(e, "regions") ? 1 : !strcmp(e, "exact") ? 2 : -1;
+        int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, want);
+        if (rcs == 2 && want < 0) {  // by region: with the exact exchange (fixed-point coordinates: the default format)
+            int fixed = 0;
+            (void)pgsgd_session_coord_format(s, &fixed, nullptr, nullptr, nullptr);
+            if (fixed) rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, 2);
+        }
         if (rcs < 0) R_TRY(rcs);
         engine_sharded = rcs > 0;
+        exact = rcs == 3;
         if (r == 0) {
             sh.tiled = info > 0;
             sh.warm_per_lane = info == 2;
         }
-        R_HIP(hipMalloc((void**)&buf, buf_floats * sizeof(float)));
+        R_HIP(hipMalloc((void**)&buf, buf_bytes));
         R_HIP(hipHostMalloc((void**)&h_tail, 4 * 2 * (size_t)G * sizeof(float)));
     }
     hipStream_t stream = s ? (hipStream_t)pgsgd_session_stream(s) : nullptr;
@@ -238,6 +251,44 @@ void rank_main(Shared& sh, int r) {
         if (!sh.rc[r]) R_HIP(hipMemcpyAsync(tail_out, buf + 6 * N, 2 * (size_t)G * sizeof(float), hipMemcpyDeviceToHost, stream));
         return true;
     };
+    // the exact exchange after one colour's launch of a region-sharded run: far pulls delivered, 64-bit integer deltas
+    // summed over the ranks, every rank ends with one GPU's coordinates (pgsgd_session_exchange_exact_*); the tail read
+    // back is {max |Delta| bits, guard flag} x G as floats, like the other exchange's
+    auto exchange_exact = [&](float* tail_out) -> bool {
+        uint64_t* wbuf = reinterpret_cast<uint64_t*>(buf);
+        if (!sh.rc[r]) R_TRY(pgsgd_session_exchange_exact_begin(s, wbuf, (uint32_t)r, (uint32_t)G));
+        if (sh.rccl) {
+            const ncclResult_t e = sh.rccl->all_reduce(wbuf, wbuf, buf_words, ncclUint64, ncclSum, sh.comms[r], stream);
+            if (e != ncclSuccess && !sh.rc[r]) {
+                sh.rc[r] = PGSGD_E_HIP;
+                sh.err[r] = std::string("ncclAllReduce: ") + (sh.rccl->error_string ? sh.rccl->error_string(e) : "error");
+            }
+        } else {  // sum through pinned host memory (tests on a single GPU)
+            if (!sh.rc[r]) R_HIP(hipMemcpyAsync(sh.host_buf[r], wbuf, buf_words * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            if (!sh.rc[r]) R_HIP(hipStreamSynchronize(stream));
+            if (sh.barrier.wait(sh.rc[r] != 0)) return false;
+            uint64_t* mine = reinterpret_cast<uint64_t*>(sh.host_buf[G + r]);
+            for (size_t i = 0; i < buf_words; ++i) {
+                uint64_t acc = 0;
+                for (int q = 0; q < G; ++q) acc += reinterpret_cast<const uint64_t*>(sh.host_buf[q])[i];
+                mine[i] = acc;
+            }
+            sh.barrier.wait();  // everybody has read the ranks' buffers
+            R_HIP(hipMemcpyAsync(wbuf, mine, buf_words * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        }
+        if (!sh.rc[r]) R_TRY(pgsgd_session_exchange_exact_end(s, wbuf, (uint32_t)G));
+        // the tail's words: the low halves of the max |Delta| slots are the floats' bits; guard slots are 0 / 1
+        if (!sh.rc[r]) R_HIP(hipMemcpyAsync(sh.host_tail64[r].data(), wbuf + 2 * N + G, 2 * (size_t)G * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        if (!sh.rc[r]) R_HIP(hipStreamSynchronize(stream));
+        for (int q = 0; q < G; ++q) {
+            const uint32_t bits = (uint32_t)sh.host_tail64[r][(size_t)q];
+            float f;
+            memcpy(&f, &bits, sizeof f);
+            tail_out[q] = f;
+            tail_out[G + q] = sh.host_tail64[r][(size_t)G + q] ? 1.0f : 0.0f;
+        }
+        return true;
+    };
     uint64_t iters = 0;
     uint32_t early = 0;
     double dmax_all = 0;
@@ -248,10 +299,11 @@ void rank_main(Shared& sh, int r) {
         const bool cooling = it >= sh.first_cooling;
         // the per-lane kernel needs four exchanges per iteration to keep the one-GPU quality, the tile kernel one
         // (measured with virtual ranks)
-        const uint32_t blocks = (!sh.tiled || (sh.warm_per_lane && !cooling)) ? 4u : 1u;
+        const bool tiles_now = sh.tiled && !(sh.warm_per_lane && !cooling);
+        const uint32_t blocks = !tiles_now ? 4u : exact ? 2u : 1u;   // exact exchange: one part per region colour
         for (uint32_t b = 0; b < blocks && !broken; ++b) {
             if (!sh.rc[r]) R_TRY(pgsgd_session_iteration_part(s, sh.etas[it], cooling ? 1 : 0, my_terms, b, blocks));
-            broken = !exchange(h_tail + (size_t)b * 2 * G);
+            broken = !((exact && tiles_now) ? exchange_exact(h_tail + (size_t)b * 2 * G) : exchange(h_tail + (size_t)b * 2 * G));
         }
         if (!broken && !sh.rc[r]) R_TRY(pgsgd_session_sync(s, nullptr));
         // the one meeting of the iteration: did anybody fail?
@@ -291,7 +343,7 @@ void rank_main(Shared& sh, int r) {
     // the far pulls of every rank's last tile launch: delivered, then merged like any other move
     bool failed = broken;  // (a rank that left the loop on a barrier's verdict left it with every other rank)
     if (!failed) failed = sh.barrier.wait(sh.rc[r] != 0);
-    if (!failed && sh.tiled) {
+    if (!failed && sh.tiled && !exact) {  // (an exact exchange delivers its launch's far pulls itself: nothing is left)
         R_TRY(pgsgd_session_flush(s));
         failed = !exchange(h_tail);
         if (!failed && !sh.rc[r]) R_TRY(pgsgd_session_sync(s, nullptr));
@@ -345,6 +397,7 @@ int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     sh.first_cooling = (uint64_t)std::floor(p->cooling_start * (double)p->iter_max);
     sh.rc.assign(G, 0);
     sh.err.assign(G, "");
+    sh.host_tail64.assign((size_t)G, std::vector<uint64_t>(2 * (size_t)G, 0));
     sh.X0 = X; sh.Y0 = Y; sh.X = X; sh.Y = Y; sh.Xd = Xd; sh.Yd = Yd;
     Rccl rccl;
     auto release = [&] {
@@ -363,7 +416,7 @@ int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     } else {
         sh.host_buf.assign(2 * (size_t)G, nullptr);
         for (size_t i = 0; i < sh.host_buf.size(); ++i)
-            if (hipHostMalloc((void**)&sh.host_buf[i], (6 * g->n_nodes + 2 * (size_t)G) * sizeof(float)) != hipSuccess) {
+            if (hipHostMalloc((void**)&sh.host_buf[i], std::max((6 * g->n_nodes + 2 * (size_t)G) * sizeof(float), (2 * g->n_nodes + 3 * (size_t)G) * sizeof(uint64_t))) != hipSuccess) {
                 set_error("pinned exchange buffers");
                 release();
                 return PGSGD_E_NOMEM;

@@ -74,6 +74,9 @@ struct pgsgd_session {
     uint32_t region = 256, tile_steps = 224, tile_block = pgsgd::kTileBlock, tile_substeps = 1;
     uint32_t shard_rank = 0, shard_world = 1;    // multi-GPU by node region: work items rank, rank+world, ...
     uint32_t tshard_rank = 0, tshard_world = 1;  // multi-GPU by tile: tiles rank, rank+world, ... of every work item
+    bool exact_colours = false;           // region shard with the exact exchange: iteration_part(c, 2) runs colour c alone, the ranks
+                                          // exchange integer deltas after it (pgsgd_session_exchange_exact_*)
+    int last_colour = -1;                 // colour of the last tile launch
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
     uint64_t relax_iter = 0;              // iterations of the current layout, i.e. since the last upload (index of the far pulls' gentle start)
     uint64_t tile_seed_base = 0;          // seed + stream_offset; a sharded session: seed alone (pgsgd_session_set_shard)
@@ -1253,21 +1256,25 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
 // (tile shard); 1: every world-th work item (node region) with all its tiles belongs to this rank — the ranks' private
 // windows are then disjoint, which keeps the one-GPU layout quality, but a launch has only (work items / world) items to
 // fill the GPU with; -1: by region when that still leaves a launch a thousand items per rank (BASELINE config 5 at
-// G = 8), by tile otherwise.  Returns 0: not a tiled session (the caller shards the term count),
-// 1: sharded by tile, 2: by region.
+// G = 8), by tile otherwise; 2: by region with the EXACT exchange — pgsgd_session_iteration_part(c, 2) then
+// runs colour c alone and the caller exchanges integer deltas after each colour (pgsgd_session_exchange_exact_begin / _end):
+// the ranks' coordinates are then, bit for bit, what one GPU computes.  Returns 0: not a tiled session (the caller shards
+// the term count), 1: sharded by tile, 2: by region, 3: by region, exact.
 // A sharded session's tile streams are keyed on (seed, iteration, tile, lane) only: every tile is run by exactly one
 // rank, and a rank-dependent stream_offset (which the per-lane streams of the ranks need to differ) would make rank r's
 // tile t draw the stream of rank 0's tile t + 1024 r.
 extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region) {
     pgsgd::clear_error();
-    if (!s || world == 0 || rank >= world) return PGSGD_E_INVALID;
+    if (!s || world == 0 || rank >= world || by_region > 2) return PGSGD_E_INVALID;
     if (by_region < 0) by_region = s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000 ? 1 : 0;
+    if (by_region == 2 && (!s->tiled || s->fmt != pgsgd::kFmtQ32)) { set_error("the exact exchange needs a tiled session with fixed-point coordinates"); return PGSGD_E_UNSUPPORTED; }
     s->shard_rank = by_region ? rank : 0;
     s->shard_world = by_region ? world : 1;
     s->tshard_rank = by_region ? 0 : rank;
     s->tshard_world = by_region ? 1 : world;
+    s->exact_colours = by_region == 2;
     s->tile_seed_base = world > 1 ? s->params.seed : s->params.seed + (uint64_t)s->params.stream_offset;
-    return s->tiled ? (by_region ? 2 : 1) : 0;
+    return s->tiled ? (by_region == 2 ? 3 : by_region ? 2 : 1) : 0;
 }
 
 extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles, uint64_t* n_work_items,
@@ -1415,13 +1422,17 @@ static int drain_outbox(pgsgd_session* s, unsigned long long* far_next) {
 // Apply what is still waiting in the outbox.  A tile launch's far pulls are delivered right before the NEXT launch, so
 // after an iteration the coordinates lack the pulls its last launch collected: a run flushes before it reads its result
 // (pgsgd_layout_run does), a snapshot between iterations does not.  A no-op for sessions that run the per-lane kernel.
+static int flush_for(pgsgd_session* s, int next_colour);
 extern "C" int pgsgd_session_flush(pgsgd_session* s) {
     pgsgd::clear_error();
     if (!s) return PGSGD_E_INVALID;
+    // (the counter zeroed is the one the next launch — colour 0 unless it has no items — will write)
+    return flush_for(s, s->n_items[0] ? 0 : 1);
+}
+// next_colour: the colour of the launch that follows (its far-pull counter starts from zero)
+static int flush_for(pgsgd_session* s, int next_colour) {
     if (!s->ob_pending) return PGSGD_OK;
     HIP_TRY(hipSetDevice(s->device));
-    // (the counter zeroed is the one the next launch — colour 0 unless it has no items — will write)
-    const int next_colour = s->n_items[0] ? 0 : 1;
     pgsgd_session::EvSet ev;
     int rc = take_events(s, &ev);
     if (rc) return rc;
@@ -1459,6 +1470,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             n_terms = base + (part < rem ? 1 : 0);
         }
     }
+    const bool exact = use_tiles && s->exact_colours;   // part = the colour to run, of n_parts = 2
+    if (exact && n_parts != 2) { set_error("a session with the exact exchange runs an iteration as two parts, one per colour"); return PGSGD_E_INVALID; }
     HIP_TRY(hipSetDevice(s->device));
     if (part == 0) {  // iterations started, whichever kernel runs them: tile_epoch seeds the tile streams, relax_iter counts
         s->tile_epoch++;   // the iterations of this layout (pgsgd_session_upload_coords starts it again) for the far pulls' gentle start
@@ -1475,7 +1488,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         a.eta = (float)eta;
         a.cooling = cooling ? 1u : 0u;
         a.epoch = s->tile_epoch;
-        int rc = ensure_outbox(s, n_terms, n_parts);
+        const uint32_t tile_parts = exact ? 1u : n_parts;   // the parts the TILES are dealt out to
+        int rc = ensure_outbox(s, n_terms, tile_parts);
         if (rc) return rc;
         if (s->term0_terms != n_terms) {  // every tile's exact share of this call's terms
             const uint64_t nt = s->n_tiles + 1;
@@ -1487,17 +1501,18 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         }
         // nothing was counted before a colour's first launch: assume three quarters of the partners of this call's
         // terms are far, half of them in each colour's launch
-        const double h0 = 0.75 * 0.5 * (double)n_terms / (double)n_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
+        const double h0 = 0.75 * 0.5 * (double)n_terms / (double)tile_parts / (double)s->tshard_world / (double)(2 * s->n_nodes);
         HIP_TRY(hipMemsetAsync(s->d_delta_max, 0, sizeof(unsigned int), s->stream));  // (the frame-guard flag next to it stays set until the frame is widened)
         // tile subsets: (part, window refresh, tile shard of this device) -> tiles with index = sub (mod n_sub)
-        const uint32_t n_sub = n_parts * s->tile_substeps * s->tshard_world;
+        const uint32_t n_sub = tile_parts * s->tile_substeps * s->tshard_world;
         s->n_copies++;
         const int snap_grid = (int)std::min<uint64_t>((s->n_steps + 255) / 256, 256 * 16);
-        bool snapshot_taken = false;
-        for (uint32_t ps = part * s->tile_substeps; ps < (part + 1) * s->tile_substeps; ++ps)
+        bool snapshot_taken = exact && part == 1;   // (exact exchange: one pass per iteration, before its first colour — as one GPU does)
+        const uint32_t tile_part = exact ? 0u : part;
+        for (uint32_t ps = tile_part * s->tile_substeps; ps < (tile_part + 1) * s->tile_substeps; ++ps)
         for (int colour = 0; colour < 2; ++colour) {
             const uint32_t sub = ps * s->tshard_world + s->tshard_rank;
-            if (!s->n_items[colour]) continue;
+            if (!s->n_items[colour] || (exact && colour != (int)part)) continue;
             pgsgd_session::EvSet ev;
             rc = take_events(s, &ev);
             if (rc) return rc;
@@ -1555,7 +1570,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // warm iteration to tame the far pulls delivered at the END of an iteration; delivered at the start of the
             // next launch they need no second refresh, and the tiles' own writes give the same curves as a pass per
             // iteration: tools/cpu_transient.py.)
-            const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || n_parts > 1 || s->tile_substeps > 1 || s->snapshot_pass;  // this launch runs a share of the tiles
+            const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || tile_parts > 1 || s->tile_substeps > 1 || s->snapshot_pass || exact;  // this launch runs a share of the tiles
             ta.recs2_out = sharded ? nullptr : s->d_recs2;
             if (!snapshot_taken && (sharded || s->snap_stale)) {
                 hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
@@ -1585,6 +1600,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             HIP_TRY(hipEventRecord(ev.e[1], s->stream));
             s->ob_pending = true;
+            s->last_colour = colour;
             s->snap_stale = sharded;
             s->pending_events.push_back(ev);
         }
@@ -1830,6 +1846,45 @@ extern "C" int pgsgd_session_exchange_end(pgsgd_session* s, const void* device_b
         hipLaunchKernelGGL(pgsgd::exchange_apply_kernel<pgsgd::kFmtQ32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (const float*)device_buf_6N_floats, inv_world);
     else
         hipLaunchKernelGGL(pgsgd::exchange_apply_kernel<pgsgd::kFmtF32>, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, s->dc.xf, (const float*)device_buf_6N_floats, inv_world);
+    HIP_TRY(hipGetLastError());
+    s->snap_stale = true;
+    return PGSGD_OK;
+}
+
+// The exact exchange of a session sharded by region with pgsgd_session_set_shard(.., 2), after pgsgd_session_iteration_part(c, 2):
+// begin delivers the launch's far pulls (so that they are part of what this rank changed), writes coords - base as 64-bit
+// integers into device_buf[0 .. 2N) and this rank's slots of the tail [2N .. 2N + 3 world): the launch's far-pull count, the
+// bits of its max |Delta|, its frame-guard flag; the caller SUMs the buffer over the ranks as 64-bit integers; end sets
+// coords = base = base + sum and hands the launch's far-pull count over ALL ranks to the learning-rate cap of the colour's
+// next launch.
+extern "C" int pgsgd_session_exchange_exact_begin(pgsgd_session* s, void* device_buf, uint32_t rank, uint32_t world) {
+    pgsgd::clear_error();
+    if (!s || !device_buf || world == 0 || rank >= world) return PGSGD_E_INVALID;
+    if (!s->exact_colours || !s->d_base) { set_error("exchange_exact_begin: set_shard(.., 2) and exchange_mark first"); return PGSGD_E_INVALID; }
+    HIP_TRY(hipSetDevice(s->device));
+    const int c = s->last_colour < 0 ? 0 : s->last_colour;
+    const int other = 1 - c;
+    int rc = flush_for(s, s->n_items[other] ? other : c);
+    if (rc) return rc;
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    hipLaunchKernelGGL(pgsgd::exchange_exact_prepare_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, (uint64_t*)device_buf);
+    const unsigned long long* far = s->far_launches[c] ? s->d_far + 2 * c + ((s->far_launches[c] - 1) & 1u) : nullptr;
+    hipLaunchKernelGGL(pgsgd::exchange_exact_tail_kernel, dim3((3 * world + 255) / 256), dim3(256), 0, s->stream, s->d_delta_max, far, rank, world,
+                       (uint64_t*)device_buf + n_ends);
+    HIP_TRY(hipGetLastError());
+    return PGSGD_OK;
+}
+
+extern "C" int pgsgd_session_exchange_exact_end(pgsgd_session* s, const void* device_buf, uint32_t world) {
+    pgsgd::clear_error();
+    if (!s || !device_buf || world == 0 || !s->d_base || !s->exact_colours) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    const int c = s->last_colour < 0 ? 0 : s->last_colour;
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const int grid = (int)std::min<uint64_t>((n_ends + 255) / 256, 2048);
+    unsigned long long* far = s->far_launches[c] ? s->d_far + 2 * c + ((s->far_launches[c] - 1) & 1u) : nullptr;
+    hipLaunchKernelGGL(pgsgd::exchange_exact_apply_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_coords, s->d_base, n_ends, (const uint64_t*)device_buf, far, world);
     HIP_TRY(hipGetLastError());
     s->snap_stale = true;
     return PGSGD_OK;

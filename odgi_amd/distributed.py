@@ -74,15 +74,33 @@ class HipEngine:
         return bool(self.session.tile_info()["warm_per_lane"])
 
     def set_shard(self, rank, world, by_region=None):
-        """by_region None: by node region when that leaves a launch a thousand work items per rank, by tile
-        otherwise (pgsgd_session_set_shard).  True when the engine shards by tile or by region itself (tile
-        kernel): iteration() then takes the full term count of a block; False when the caller must shard the
-        term count (per-lane kernel)."""
-        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), -1 if by_region is None else 1 if by_region else 0)
+        """by_region None: by node region with the exact exchange when that leaves a launch a thousand work items per
+        rank, by tile otherwise; True / False force region (merge rule) / tile; "exact" forces region with the exact
+        exchange (pgsgd_session_set_shard).  True when the engine shards by tile or by region itself (tile kernel):
+        iteration() then takes the full term count of a block; False when the caller must shard the term count
+        (per-lane kernel)."""
+        if by_region is None:
+            ti = self.session.tile_info()
+            items = self.session.tile_items() if ti["tiled"] else None
+            per_colour = min(int(items["n_first"]), len(items["local"]) - int(items["n_first"])) if items is not None else 0
+            fixed = bool(self.session.coord_format()[0])
+            mode = 2 if ti["tiled"] and fixed and per_colour // int(world) >= 1000 else 0
+        else:
+            mode = 2 if by_region == "exact" else 1 if by_region else 0
+        rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), mode)
         if rc < 0:
             check(rc, "set_shard")
-        self.shard_mode = {0: "terms", 1: "tiles", 2: "regions"}[rc]
+        self.shard_mode = {0: "terms", 1: "tiles", 2: "regions", 3: "regions-exact"}[rc]
         return rc > 0
+
+    def new_exact_exchange_buffer(self, world=1):
+        return torch.zeros(2 * self.n_nodes + 3 * world, dtype=torch.int64, device=self.device)
+
+    def exchange_exact_begin(self, buf, rank=0, world=1):
+        check(lib.pgsgd_session_exchange_exact_begin(self.session._h, C.c_void_p(buf.data_ptr()), int(rank), int(world)), "exchange_exact_begin")
+
+    def exchange_exact_end(self, buf, world):
+        check(lib.pgsgd_session_exchange_exact_end(self.session._h, C.c_void_p(buf.data_ptr()), int(world)), "exchange_exact_end")
 
     def exchange_mark(self):
         check(lib.pgsgd_session_exchange_mark(self.session._h), "exchange_mark")
@@ -135,6 +153,7 @@ class DistributedLayout:
         self.iterations_done = 0
         self.stopped_early = False
         self._buf = None
+        self._ebuf = None
         # Every rank applies 1/G of each iteration's terms.  Per-lane kernel: 1/G of the term count, in B
         # slices.  Tile kernel: part b of an iteration runs the tiles with index = b*G + rank (mod B*G), each
         # with its whole share of the iteration's terms, so a visited tile always has a full term loop and
@@ -161,6 +180,20 @@ class DistributedLayout:
             return self.params.min_term_updates // self.world
         return shard_terms(self.params.min_term_updates, self.world, self.rank)
 
+    def _exchange_exact(self):
+        """The exchange of a region-sharded engine after one colour's launch: 64-bit integer deltas, one SUM all-reduce;
+        returns (max|Delta| over the ranks, any frame-guard flag) from its tail."""
+        import struct
+        eng, G = self.engine, self.world
+        if self._ebuf is None:
+            self._ebuf = eng.new_exact_exchange_buffer(G)
+        eng.exchange_exact_begin(self._ebuf, self.rank, G)
+        dist.all_reduce(self._ebuf, op=dist.ReduceOp.SUM, group=self.group)
+        eng.exchange_exact_end(self._ebuf, G)
+        tail = self._ebuf[-2 * G:].tolist()   # (waits for the stream: the exchange's one synchronisation)
+        dmax = max(struct.unpack("<f", struct.pack("<I", int(v) & 0xffffffff))[0] for v in tail[:G])
+        return dmax, any(v != 0 for v in tail[G:])
+
     def _exchange(self):
         """One fused all-reduce; returns (max|Delta| over the ranks, any frame-guard flag) from its tail."""
         eng, G = self.engine, self.world
@@ -180,6 +213,15 @@ class DistributedLayout:
         blocks = self.blocks
         if self.world > 1 and not cooling and getattr(eng, "warm_per_lane", lambda: False)():
             blocks = max(blocks, 4)
+        exact = self.exchanging and getattr(eng, "shard_mode", "") == "regions-exact" and not (not cooling and getattr(eng, "warm_per_lane", lambda: False)())
+        if exact:
+            # region shard with the exact exchange: one colour, its far pulls delivered, integer deltas summed over the ranks —
+            # twice per iteration; every rank then holds what one GPU would (no merge rule)
+            for colour in range(2):
+                eng.iteration_part(self.etas[it], cooling, self._iteration_terms(), colour, 2)
+                d, g = self._exchange_exact()
+                dmax, guard = max(dmax, d), guard or g
+            blocks = 0
         for b in range(blocks):
             eng.iteration_part(self.etas[it], cooling, self._iteration_terms(), b, blocks)
             if self.exchanging:
@@ -200,8 +242,8 @@ class DistributedLayout:
         """The far pulls of every rank's last tile launch: delivered, then merged like any other move."""
         eng = self.engine
         if hasattr(eng, "flush"):
-            eng.flush()
-            if self.exchanging:
+            eng.flush()   # (nothing left to deliver after an exact exchange: it drained the launch's far pulls itself)
+            if self.exchanging and getattr(eng, "shard_mode", "") != "regions-exact":
                 self._exchange()
                 eng.sync()
 

@@ -1020,7 +1020,7 @@ def test_tile_sharded_virtual_ranks(oa, init):
     assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))
 
 
-@pytest.mark.parametrize("mode", ["tiles", "regions"])
+@pytest.mark.parametrize("mode", ["tiles", "regions", "regions-exact"])
 def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     """The multi-GPU split at G = 1, 2, 4, 8 with G sessions on the one GPU of the test box (the exchange kernels as in
     production, the all-reduce replaced by a sum on the device), three seeds each, both ways of sharding the tile
@@ -1040,27 +1040,29 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
             engines = [HipEngine(g, _params(oa, g, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep, **kw), X0, Y0) for r in range(G)]
             for r, e in enumerate(engines):
                 e.exchange_mark()
-                assert e.tiled and e.set_shard(r, G, by_region=(mode == "regions")) and not e.warm_per_lane()
-            bufs = [e.new_exchange_buffer() for e in engines]
+                assert e.tiled and e.set_shard(r, G, by_region="exact" if mode == "regions-exact" else mode == "regions") and not e.warm_per_lane()
+            exact = mode == "regions-exact"
+            bufs = [e.new_exact_exchange_buffer(G) if exact else e.new_exchange_buffer() for e in engines]
 
             def exchange():
-                for e, b in zip(engines, bufs):
-                    e.exchange_begin(b)
+                for r, (e, b) in enumerate(zip(engines, bufs)):
+                    e.exchange_exact_begin(b, r, G) if exact else e.exchange_begin(b)
                 torch.cuda.synchronize()
                 total = torch.stack(bufs).sum(0)
                 for e in engines:
-                    e.exchange_end(total, G)
+                    e.exchange_exact_end(total, G) if exact else e.exchange_end(total, G)
 
             for it in range(p.iter_max):
-                for e in engines:
-                    e.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, 0, 1)
-                if G > 1:
-                    exchange()
+                for part in range(2 if exact else 1):   # the exact exchange: one colour, then what it changed, twice per iteration
+                    for e in engines:
+                        e.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, part, 2 if exact else 1)
+                    if G > 1 or exact:
+                        exchange()
                 for e in engines:
                     e.sync()
             for e in engines:
                 e.flush()
-            if G > 1:
+            if G > 1 and not exact:
                 exchange()
             X, Y = engines[0].result()
             for e in engines:
@@ -1072,9 +1074,75 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     # measured (three seeds each; the means of three runs scatter by ~2 % of themselves): round 3 by tile +5.9 / +9.8 / +16.4 %, by
     # region +3.6 / +5.4 / +5.3 %; round 4 by tile +4.8 / +9.2 / +14.5 %, by region +3.2 / +4.5 / +4.9 %.  Bands = measured + 3 sigma,
     # two-sided: a merge that made layouts BETTER than one device's would be as suspect as one that made them worse.
-    band = {"tiles": {2: 1.11, 4: 1.16, 8: 1.22}, "regions": {2: 1.10, 4: 1.11, 8: 1.11}}[mode]
+    # With the exact exchange the ranks compute what one GPU computes (bit for bit when the launches are sequential programs:
+    # test_region_shard_with_the_exact_exchange_is_one_gpu_bit_for_bit): only the run-to-run scatter of a Hogwild launch is left.
+    band = {"tiles": {2: 1.11, 4: 1.16, 8: 1.22}, "regions": {2: 1.10, 4: 1.11, 8: 1.11}, "regions-exact": {2: 1.04, 4: 1.04, 8: 1.04}}[mode]
     for G in (2, 4, 8):
-        assert 0.97 * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
+        assert (0.96 if mode == "regions-exact" else 0.97) * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_region_shard_with_the_exact_exchange_is_one_gpu_bit_for_bit(oa, G, monkeypatch):
+    """The multi-GPU split that is correct by construction: ranks own every G-th node region of a colour, an iteration is one
+    launch per colour, and after each the ranks deliver their far pulls and SUM what they changed as 64-bit integers
+    (pgsgd_session_set_shard(.., 2), exchange_exact_begin / _end).  Windows of one colour are disjoint, integer adds commute,
+    the tile streams do not depend on who runs a tile and the far-pull count behind the learning-rate cap is summed with the
+    coordinates — so G ranks must end with EXACTLY the words one GPU computes (run with its snapshot pass per iteration,
+    which is what a sharded session does).  G virtual ranks on the one GPU of the test box, the all-reduce replaced by a
+    sum on the device; G = 3 does not divide the work items."""
+    import torch
+    from odgi_amd.distributed import HipEngine
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
+    # one lane per tile: the lanes of a workgroup race on their window's words (the kernel is Hogwild inside a window, like the
+    # reference's threads), so only a launch whose workgroups are sequential programs is reproducible at all — across
+    # workgroups nothing races (exclusive windows, far pulls deferred), however many run at once
+    monkeypatch.setenv("PGSGD_TILE_LANES", "1")
+    monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")
+    g = oa.Graph.synthetic(120_000, 10, seed=11)
+    kw = dict(min_term_updates=3 * g.n_steps, iter_max=20)
+    p = _params(oa, g, **kw)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    X0, Y0 = oa.initial_layout(g, "d", seed=4)
+    # one GPU, snapshot records refreshed by a pass per iteration
+    monkeypatch.setenv("PGSGD_TILE_SNAPSHOT_PASS", "1")
+    with oa.LayoutSession(g, p) as s:
+        assert s.tile_info()["tiled"]
+        s.upload(X0, Y0)
+        dmax_one = []
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            dmax_one.append(s.sync())
+        want = s.download_words()
+    monkeypatch.delenv("PGSGD_TILE_SNAPSHOT_PASS")
+    engines = [HipEngine(g, _params(oa, g, stream_offset=r * (1 << 20), **kw), X0, Y0) for r in range(G)]
+    for r, e in enumerate(engines):
+        e.exchange_mark()
+        assert e.tiled and e.set_shard(r, G, by_region="exact") and e.shard_mode == "regions-exact"
+    bufs = [e.new_exact_exchange_buffer(G) for e in engines]
+    dmax_g = []
+    for it in range(p.iter_max):
+        d_it = 0.0
+        for colour in range(2):
+            for e in engines:
+                e.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, colour, 2)
+            for r, (e, b) in enumerate(zip(engines, bufs)):
+                e.exchange_exact_begin(b, r, G)
+            torch.cuda.synchronize()
+            total = torch.stack(bufs).sum(0)
+            for e in engines:
+                e.exchange_exact_end(total, G)
+            tail = total[-2 * G:].cpu().numpy()
+            d_it = max(d_it, float(tail[:G].astype(np.uint32).view(np.float32).max()))
+            assert not tail[G:].any()
+        for e in engines:
+            e.sync()
+        dmax_g.append(d_it)
+    words = [e.session.download_words() for e in engines]
+    for e in engines:
+        e.close()
+    for r in range(G):
+        assert np.array_equal(words[r], want), (G, r, int((words[r] != want).sum()))
+    assert dmax_g == dmax_one
 
 
 @pytest.mark.parametrize("graph_name", ["synthetic-300k", "LPA"])
@@ -1101,6 +1169,43 @@ def test_cpp_multi_gpu_run_with_two_virtual_devices(oa, graphs, graph_name, monk
             res[G].append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
     print(f"C++ multi-GPU driver, {graph_name}: stress one device {res[1]}, two virtual devices {res[2]}")
     assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))   # measured +4.6 % (synthetic), -6 % (LPA)
+
+
+def test_cpp_multi_gpu_run_with_the_exact_exchange(oa, monkeypatch):
+    """The C++ multi-GPU driver sharding by region with the exact exchange (what it chooses when a launch keeps a thousand
+    work items per device; forced here by PGSGD_MULTI_SHARD on a smaller graph): two virtual devices through
+    pgsgd_layout_run(n_devices = 2) against one device.  (a) launches as sequential programs (one lane per tile) and one
+    device refreshing its snapshot records by a pass per iteration, as sharded sessions do: the SAME coordinates, bit for
+    bit; (b) full-width launches: the same layout quality (one device's own run-to-run scatter, 4 %)."""
+    import dataclasses
+    monkeypatch.setenv("PGSGD_MULTI_HOST_REDUCE", "1")
+    monkeypatch.setenv("PGSGD_MULTI_SHARD", "exact")
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
+    g = oa.Graph.synthetic(100_000, 10, seed=11)
+    X0, Y0 = oa.initial_layout(g, "d", seed=4)
+    kw = dict(min_term_updates=3 * g.n_steps, iter_max=16)
+    monkeypatch.setenv("PGSGD_TILE_LANES", "1")
+    monkeypatch.setenv("PGSGD_TILE_BLOCK", "64")
+    monkeypatch.setenv("PGSGD_TILE_SNAPSHOT_PASS", "1")
+    out = {}
+    for G in (1, 2):
+        X, Y = X0.copy(), Y0.copy()
+        st = oa.path_linear_sgd_layout_gpu(g, _params(oa, g, n_devices=G, **kw), X, Y)
+        assert st["iterations"] == 16 and st["term_updates"] == 16 * 3 * g.n_steps
+        out[G] = (X, Y)
+    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
+    for k in ("PGSGD_TILE_LANES", "PGSGD_TILE_BLOCK", "PGSGD_TILE_SNAPSHOT_PASS"):
+        monkeypatch.delenv(k)
+    g = oa.Graph.synthetic(300_000, 24, seed=7)
+    res = {1: [], 2: []}
+    for rep in range(3):
+        X0, Y0 = oa.initial_layout(g, "d", seed=7 + rep)
+        for G in (1, 2):
+            X, Y = X0.copy(), Y0.copy()
+            oa.path_linear_sgd_layout_gpu(g, _params(oa, g, n_devices=G, seed=9399220 + 7919 * rep, min_term_updates=3 * g.n_steps), X, Y)
+            res[G].append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
+    print(f"C++ multi-GPU driver, exact exchange: stress one device {res[1]}, two virtual devices {res[2]}")
+    assert 0.96 * float(np.mean(res[1])) <= float(np.mean(res[2])) <= 1.04 * float(np.mean(res[1]))
 
 
 def test_cpp_multi_gpu_run_writes_snapshots(oa, graphs, tmp_path, monkeypatch):
