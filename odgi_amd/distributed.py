@@ -12,7 +12,17 @@ After each part the ranks exchange what they changed since the previous exchange
     all-reduce(SUM) of the one fused buffer of 6N + 2G floats over the G ranks            (RCCL)
     end   : coords = base + S * clamp(Q/|S|^2, 1/G, 1) per node end ; base = coords      (HIP kernel)
 
-The merge is not a plain sum: with the early learning rates every term is a full projection
+A tiled engine sharded by node region exchanges EXACTLY instead (HipEngine.set_shard: chosen when a launch keeps a
+thousand work items per rank): an iteration is one launch per region colour, each followed by
+
+    begin : deliver the launch's far pulls; buf[0..2N) = coords - base as 64-bit integers; tail: far-pull count, max|Delta|
+            bits and frame-guard flag in this rank's slots                                                      (HIP kernels)
+    all-reduce(SUM) of the 2N + 3G 64-bit integers                                                              (RCCL)
+    end   : coords = base = base + sum; the far-pull count over all ranks goes to the learning-rate cap         (HIP kernel)
+
+Windows of one colour are disjoint and integer adds commute: every rank ends with, bit for bit, one GPU's coordinates.
+
+The merge of the other modes (tile shard, per-lane kernel) is not a plain sum: with the early learning rates every term is a full projection
 (mu = 1), each rank alone already moves a node end all the way, and summing G such deltas
 overshoots G-fold (measured: divergence at G = 2 on DRB1-3123).  The factor f = Q/|S|^2 is 1/G when
 the ranks' deltas agree (-> their mean) and 1 when they are uncorrelated small steps (-> their sum);
