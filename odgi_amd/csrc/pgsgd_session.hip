@@ -1407,7 +1407,8 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
 // start from zero.
 static int drain_outbox(pgsgd_session* s, unsigned long long* far_next) {
     if (!s->ob_pending) return PGSGD_OK;
-    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(s->ob.n_buckets << (s->ob.shift - s->ob_part_shift)), dim3(1024),
+    // (a bucket's parts run on one XCD: the grid is the buckets rounded up to a multiple of the 8 XCDs, times the parts)
+    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3((((s->ob.n_buckets + pgsgd::kItemQueues - 1) / pgsgd::kItemQueues) * pgsgd::kItemQueues) << (s->ob.shift - s->ob_part_shift)), dim3(1024),
                        sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift, s->dc.frame_flag);
     s->n_kernels++;
     HIP_TRY(hipGetLastError());

@@ -1003,7 +1003,14 @@ __global__ __launch_bounds__(256) void snapshot_kernel(const uint4* recs, const 
 __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift, unsigned int* frame_flag) {
     extern __shared__ uint64_t acc[];
     const uint32_t parts = 1u << (ob.shift - part_shift);
-    const uint32_t b = blockIdx.x / parts, part = blockIdx.x % parts, span = 1u << part_shift;
+    // The parts of one bucket stream the SAME messages, each keeping its share.  Workgroups are dealt to the 8 XCDs round-robin
+    // by index, so workgroup 8 m + x is XCD x's m-th: XCD x takes buckets x, x + 8, ... and runs a bucket's parts back to back
+    // — at the same time, on CUs that share an L2: one of them fetches a line from memory, the others find it there (1e7
+    // nodes, 8 parts: the drain's memory reads fall from 8x the messages towards 1x; with a bucket's parts on 8 different
+    // XCDs every part fetched everything itself).  One part per bucket: the identity.
+    const uint32_t xcd = blockIdx.x % kItemQueues, m = blockIdx.x / kItemQueues;
+    const uint32_t b = (m / parts) * kItemQueues + xcd, part = m % parts, span = 1u << part_shift;
+    if (b >= ob.n_buckets) return;
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) acc[i] = 0;
     __syncthreads();
     const uint32_t handed = ob.next[b], cap = ob.cap[b];
