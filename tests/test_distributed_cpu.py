@@ -160,3 +160,129 @@ def test_single_process_driver_without_process_group():
     drv = DistributedLayout(p, eng)
     assert drv.world == 1 and drv.my_terms() == p.min_term_updates
     assert drv.run() == 8
+
+
+class ExactStubEngine:
+    """The interface of a tiled HipEngine sharded by region with the exact exchange (shard_mode "regions-exact"), in numpy:
+    `words` are 2N 64-bit coordinate words; the launch of colour c moves the words of the blocks (of 64 words) this rank
+    owns in that colour by a deterministic function of (iteration, colour, word index, current value) — wrapping 64-bit
+    arithmetic, like the device's packed adds — and sends a "far pull" to a word that another rank owns.  What the driver
+    must get right: one launch per colour, each followed by one integer all-reduce; tails decoded; no exchange left over."""
+    tiled = True
+
+    def __init__(self, n_words, rank, world):
+        self.n, self.rank, self.world = n_words, rank, world
+        self.words = (np.arange(n_words, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(7)
+        self.pending = np.zeros(n_words, dtype=np.uint64)   # far pulls not yet delivered (the outbox)
+        self.shard_mode = "terms"
+        self.launches = []
+        self.far_seen = []
+
+    def set_shard(self, rank, world, by_region=None):
+        self.shard_mode = "regions-exact"
+        return True
+
+    def warm_per_lane(self):
+        return False
+
+    def new_exact_exchange_buffer(self, world=1):
+        return torch.zeros(self.n + 3 * world, dtype=torch.int64)
+
+    def new_exchange_buffer(self, world=1):
+        return torch.zeros(8, dtype=torch.float32)
+
+    def exchange_mark(self):
+        self.base = self.words.copy()
+
+    def iteration_part(self, eta, cooling, n_terms, part, n_parts):
+        assert n_parts == 2 and part in (0, 1)
+        colour = part
+        self.launches.append((float(eta), bool(cooling), colour))
+        idx = np.arange(self.n, dtype=np.uint64)
+        block = idx // np.uint64(64)
+        mine = ((block % np.uint64(2)) == np.uint64(colour)) & (((block // np.uint64(2)) % np.uint64(self.world)) == np.uint64(self.rank))
+        k = np.uint64(len(self.launches))
+        with np.errstate(over="ignore"):
+            step = (self.words * np.uint64(6364136223846793005) + idx * k + np.uint64(colour)) >> np.uint64(40)
+            self.words = np.where(mine, self.words + step - np.uint64(1 << 23), self.words)
+            # far pulls: every owned word pushes on the word half the array away (someone else's, or the other colour's)
+            tgt = (idx + np.uint64(self.n // 2 + 64)) % np.uint64(self.n)
+            np.add.at(self.pending, tgt[mine].astype(np.int64), (step[mine] >> np.uint64(3)))
+        self._far = int(mine.sum())
+        self._dmax = float(eta) * (1.0 + 0.125 * self.rank)
+
+    def exchange_exact_begin(self, buf, rank=0, world=1):
+        with np.errstate(over="ignore"):
+            self.words = self.words + self.pending       # deliver the launch's far pulls
+            self.pending[:] = 0
+            delta = self.words - self.base
+        out = np.zeros(self.n + 3 * world, dtype=np.uint64)
+        out[: self.n] = delta
+        out[self.n + rank] = self._far
+        out[self.n + world + rank] = np.float32(self._dmax).view(np.uint32)
+        buf.copy_(torch.from_numpy(out.view(np.int64)))
+
+    def exchange_exact_end(self, buf, world):
+        tot = buf.numpy().view(np.uint64)
+        with np.errstate(over="ignore"):
+            self.words = self.base + tot[: self.n]
+        self.base = self.words.copy()
+        self.far_seen.append(int(tot[self.n: self.n + world].sum()))
+
+    def sync(self):
+        return self._dmax
+
+    def flush(self):
+        assert not self.pending.any()    # an exact exchange delivers its launch's far pulls itself
+
+
+def _exact_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import odgi_amd as oa
+        from odgi_amd.distributed import DistributedLayout
+        g = oa.Graph.from_gfa(os.path.join(GOLDEN, "DRB1-3123.gfa"))
+        p = oa.LayoutParams.defaults(g, iter_max=5, min_term_updates=1000)
+        eng = ExactStubEngine(4096, rank, world)
+        drv = DistributedLayout(p, eng)
+        assert drv.engine_sharded and eng.shard_mode == "regions-exact"
+        dmaxes = [drv.step(it) for it in range(p.iter_max)]
+        drv.finish()
+        np.save(os.path.join(outdir, f"words_{rank}.npy"), eng.words)
+        np.save(os.path.join(outdir, f"dmax_{rank}.npy"), np.array(dmaxes))
+        np.save(os.path.join(outdir, f"far_{rank}.npy"), np.array(eng.far_seen))
+        assert [c for _, _, c in eng.launches] == [0, 1] * p.iter_max
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exact_exchange_equals_one_rank(tmp_path):
+    """DistributedLayout with an engine sharded by region and the exact exchange, world 2 over gloo: one launch per region
+    colour, one 64-bit integer all-reduce after each, tails decoded (max |Delta| as float bits), nothing exchanged at the
+    end — and both ranks end with exactly the words ONE rank owning everything computes."""
+    world, port = 2, 29617
+    mp.spawn(_exact_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    w0, w1 = np.load(tmp_path / "words_0.npy"), np.load(tmp_path / "words_1.npy")
+    assert np.array_equal(w0, w1)
+    sys.path.insert(0, ROOT)
+    import odgi_amd as oa
+    from odgi_amd.distributed import DistributedLayout
+    g = oa.Graph.from_gfa(os.path.join(GOLDEN, "DRB1-3123.gfa"))
+    p = oa.LayoutParams.defaults(g, iter_max=5, min_term_updates=1000)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    one = ExactStubEngine(4096, 0, 1)
+    one.exchange_mark()
+    one.shard_mode = "regions-exact"
+    buf = one.new_exact_exchange_buffer(1)
+    for it in range(p.iter_max):
+        for colour in range(2):
+            one.iteration_part(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates, colour, 2)
+            one.exchange_exact_begin(buf, 0, 1)
+            one.exchange_exact_end(buf, 1)
+    assert np.array_equal(w0, one.words)
+    # every rank saw every rank's max |Delta| (rank 1's is the larger by construction) and the far-pull counts of all ranks
+    d0, d1 = np.load(tmp_path / "dmax_0.npy"), np.load(tmp_path / "dmax_1.npy")
+    assert np.array_equal(d0, d1) and np.allclose(d0, np.float32(1.125) * etas[: p.iter_max].astype(np.float32), rtol=1e-6)
+    assert np.array_equal(np.load(tmp_path / "far_0.npy"), np.array(one.far_seen))
