@@ -102,6 +102,10 @@ typedef struct pgsgd_graph_view {
                                            /* resolution on shared node coordinates.  While a term's learning rate is in the projection regime     */
                                            /* (mu >= 0.1) it takes a lock bit on each of its window ends (one LDS atomic OR per end; the lanes of a  */
                                            /* wave that go for one end are served one after the other) and does nothing when an end is taken       */
+#define PGSGD_FLAG_NO_RELABEL    0x10000u /* pgsgd_layout_run: keep the caller's node ranks.  By default a graph whose node ranks do not follow its paths   */
+                                           /* (more than 2 % of a sample of steps jump over 128 ranks) and would therefore miss the tile kernel is laid out */
+                                           /* under ranks ordered by (component, mean path position) when that order at least halves the jumps              */
+                                           /* (pgsgd_graph_path_order); the coordinates come back under the caller's ranks.  Not with snapshots (-u)        */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -147,11 +151,17 @@ typedef struct pgsgd_stats {
     uint32_t early_stop;      /* 1 if Delta_max <= delta ended the run (path_sgd_layout.cpp:142)    */
     uint32_t frame_doublings; /* times the fixed-point coordinate frame was widened during the run  */
     uint32_t apply_lanes;     /* iterations in two passes (a small lane-bound graph): the lanes that moved node ends; else 0 */
+    uint32_t relabeled;       /* 1: the run renamed the nodes by path position (PGSGD_FLAG_NO_RELABEL turns that off)   */
+    uint32_t tiled;           /* 1: the tile kernel ran (2: after per-lane warm iterations); 0: the per-lane kernel     */
 } pgsgd_stats;
 
 /* Fill every field of *p with the reference defaults derived from the path index
  * (src/subcommand/layout_main.cpp:153-155,198-204,251-266). */
 int pgsgd_params_defaults(const pgsgd_graph_view* g, pgsgd_params* p);
+/* Node ranks ordered by (path-connected component, mean bp position of the node's steps): new_rank_of_old[N].  disorder_* :
+ * the share of a sample of consecutive path steps whose node ranks differ by more than 128, before and after (may be NULL).
+ * What pgsgd_layout_run renames the nodes by when the caller's ranks do not follow the paths.  Host only. */
+int pgsgd_graph_path_order(const pgsgd_graph_view* g, uint32_t* new_rank_of_old, double* disorder_before, double* disorder_after);
 
 /* Learning-rate schedule, iter_max+1 doubles (path_sgd_layout.cpp:433-468).  Returns count. */
 int64_t pgsgd_schedule(const pgsgd_params* p, double* etas, size_t capacity);

@@ -44,7 +44,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("iterations", u64), ("term_updates", u64), ("last_delta_max", f64),
                 ("kernel_ms", f64), ("wall_ms", f64), ("n_streams", u32), ("early_stop", u32),
-                ("frame_doublings", u32), ("apply_lanes", u32)]
+                ("frame_doublings", u32), ("apply_lanes", u32), ("relabeled", u32), ("tiled", u32)]
 
 
 FLAG_COORD_LOAD_PLAIN = 0x1
@@ -59,6 +59,7 @@ FLAG_NO_SPLIT = 0x1000
 FLAG_EXACT_MATH = 0x2000
 FLAG_NO_PARTNER_PAIRS = 0x4000
 FLAG_LOCK_WINDOW_ENDS = 0x8000
+FLAG_NO_RELABEL = 0x10000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
@@ -115,6 +116,7 @@ SIGNATURES = [
     ("pgsgd_session_split_info", C.c_int, [C.c_void_p, P(u32)]),
     ("pgsgd_session_tile_math", C.c_int, [C.c_void_p]),
     ("pgsgd_debug_tile_displacement", C.c_int, [C.c_int, u64, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]),
+    ("pgsgd_graph_path_order", C.c_int, [P(GraphView), P(u32), P(f64), P(f64)]),
     ("pgsgd_tile_region_for", u32, [u64, u64]),
     ("pgsgd_tile_wave_coin", C.c_int, [u64, u64, u64, u32, u64]),
     ("pgsgd_tile_pair_partner", u32, [u32, u32, u32, u32]),

@@ -214,3 +214,67 @@ extern "C" int pgsgd_init_layout(const pgsgd_graph_view* g, char mode, uint64_t 
     }
     return PGSGD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Node order by path position.  The tile kernel (what runs at 6e10 terms/s) needs node ranks that follow the paths: a run
+// of path steps must visit a run of node ranks.  `odgi layout` is normally fed a sorted graph (odgi sort), but nothing
+// in the reference requires it, and a graph whose ids are in another order would fall back to the per-lane kernel
+// (1e10 terms/s).  The ranks are only names: pgsgd_layout_run renames them for the duration of a run when that helps —
+// nodes ordered by (path-connected component, mean bp position of the node's steps) — and hands the coordinates back
+// under the caller's names.  Whether it helps is measured on a sample of consecutive steps: the share of steps whose
+// successor lies more than `reach` ranks away.
+namespace pgsgd {
+double step_rank_disorder(const pgsgd_graph_view* g, const uint32_t* new_rank_of_old, uint32_t reach) {
+    const uint64_t S = g->n_steps;
+    if (S < 2) return 0.0;
+    const uint64_t K = std::min<uint64_t>(S - 1, 200000);
+    uint64_t seen = 0, far = 0;
+    for (uint64_t i = 0; i < K; ++i) {
+        const uint64_t k = (uint64_t)(((unsigned __int128)i * (S - 1)) / K);
+        if (g->step_path[k] != g->step_path[k + 1]) continue;
+        uint32_t a = g->step_handle[k] >> 1, b = g->step_handle[k + 1] >> 1;
+        if (new_rank_of_old) { a = new_rank_of_old[a]; b = new_rank_of_old[b]; }
+        ++seen;
+        far += (a > b ? a - b : b - a) > reach;
+    }
+    return seen ? (double)far / (double)seen : 0.0;
+}
+}  // namespace pgsgd
+
+extern "C" int pgsgd_graph_path_order(const pgsgd_graph_view* g, uint32_t* new_rank_of_old, double* disorder_before, double* disorder_after) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!new_rank_of_old) return PGSGD_E_INVALID;
+    const uint64_t N = g->n_nodes, S = g->n_steps;
+    for (uint64_t k = 0; k < S; ++k)
+        if ((g->step_handle[k] >> 1) >= N) { pgsgd::set_error("a step names a node rank outside the graph"); return PGSGD_E_INVALID; }
+    // components of "visited by a common path, transitively": union-find over consecutive steps
+    std::vector<uint32_t> parent(N);
+    for (uint64_t i = 0; i < N; ++i) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+        return x;
+    };
+    std::vector<double> sum(N, 0.0);
+    std::vector<uint32_t> cnt(N, 0);
+    for (uint64_t k = 0; k < S; ++k) {
+        const uint32_t n = g->step_handle[k] >> 1;
+        sum[n] += (double)g->step_pos[k];
+        cnt[n]++;
+        if (k + 1 < S && g->step_path[k] == g->step_path[k + 1]) {
+            const uint32_t a = find(n), b = find(g->step_handle[k + 1] >> 1);
+            if (a != b) parent[a < b ? b : a] = a < b ? a : b;   // the smaller rank is the component's name
+        }
+    }
+    struct Key { uint32_t comp; double pos; uint32_t old; };
+    std::vector<Key> keys(N);
+    for (uint64_t i = 0; i < N; ++i) keys[i] = Key{find((uint32_t)i), cnt[i] ? sum[i] / (double)cnt[i] : 0.0, (uint32_t)i};
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+        return a.comp != b.comp ? a.comp < b.comp : a.pos != b.pos ? a.pos < b.pos : a.old < b.old;
+    });
+    for (uint64_t r = 0; r < N; ++r) new_rank_of_old[keys[r].old] = (uint32_t)r;
+    if (disorder_before) *disorder_before = pgsgd::step_rank_disorder(g, nullptr, 128);
+    if (disorder_after) *disorder_after = pgsgd::step_rank_disorder(g, new_rank_of_old, 128);
+    return PGSGD_OK;
+}

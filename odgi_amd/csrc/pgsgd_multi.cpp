@@ -357,6 +357,7 @@ void rank_main(Shared& sh, int r) {
         sh.stats.last_delta_max = dmax_all;
         sh.stats.n_streams = pgsgd_session_n_streams(s);
         sh.stats.early_stop = early;
+        sh.stats.tiled = sh.tiled ? (sh.warm_per_lane ? 2u : 1u) : 0u;
         uint32_t doublings = 0;
         (void)pgsgd_session_frame_status(s, nullptr, &doublings);
         sh.stats.frame_doublings = doublings;

@@ -1933,12 +1933,69 @@ extern "C" int pgsgd_layout_run_f64(const pgsgd_graph_view* g, const pgsgd_param
     return layout_run_impl(g, p, xf.data(), yf.data(), X, Y, stats);
 }
 
+namespace pgsgd { double step_rank_disorder(const pgsgd_graph_view* g, const uint32_t* new_rank_of_old, uint32_t reach); }  // pgsgd_host.cpp
+static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
+
+// The run under node ranks that follow the paths, when the caller's do not (pgsgd_graph_path_order; include/pgsgd.h:
+// PGSGD_FLAG_NO_RELABEL): node lengths, step handles and the initial layout are renamed, the run is the usual one, the
+// coordinates come back under the caller's names.  Ranks are only names — the sampler draws path STEPS, which keep their
+// numbers — but names that follow the paths are what lets the tile kernel keep a run of steps' nodes in one LDS window.
 static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
     pgsgd::clear_error();
     if (stats) memset(stats, 0, sizeof *stats);
     if (!g || !p || !X || !Y) return PGSGD_E_INVALID;
     int rc = pgsgd_validate_view(g);
     if (rc) return rc;
+    const bool may_rename = !(p->flags & (PGSGD_FLAG_NO_RELABEL | PGSGD_FLAG_NO_TILES)) && !(p->snapshot && p->snapshot_prefix) && g->n_nodes >= 4096 &&
+                            g->n_steps >= 2 && g->n_steps < 0xffffffffull;
+    if (!may_rename || pgsgd::step_rank_disorder(g, nullptr, 128) <= 0.02) return layout_run_named(g, p, X, Y, Xd, Yd, stats);
+    pgsgd::PhaseTimer timer;
+    const uint64_t N = g->n_nodes, S = g->n_steps;
+    std::vector<uint32_t> new_of_old(N);
+    double d0 = 0, d1 = 0;
+    rc = pgsgd_graph_path_order(g, new_of_old.data(), &d0, &d1);
+    if (rc) return rc;
+    if (!(d1 <= 0.5 * d0)) {  // the paths themselves do not agree on an order: nothing to gain
+        if (p->progress) fprintf(stderr, "[odgi::path_linear_sgd_layout] node ranks do not follow the paths (%.1f %% of steps jump) and no order does (%.1f %%): per-lane kernel\n", 100 * d0, 100 * d1);
+        return layout_run_named(g, p, X, Y, Xd, Yd, stats);
+    }
+    if (p->progress) fprintf(stderr, "[odgi::path_linear_sgd_layout] node ranks do not follow the paths (%.1f %% of steps jump): laying the graph out under ranks by path position (%.1f %%)\n", 100 * d0, 100 * d1);
+    std::vector<uint32_t> len2(N), handle2(S);
+    std::vector<float> X2(2 * N), Y2(2 * N);
+    for (uint64_t i = 0; i < N; ++i) {
+        const uint64_t n = new_of_old[i];
+        len2[n] = g->node_len[i];
+        X2[2 * n] = X[2 * i]; X2[2 * n + 1] = X[2 * i + 1];
+        Y2[2 * n] = Y[2 * i]; Y2[2 * n + 1] = Y[2 * i + 1];
+    }
+    const unsigned nt = (unsigned)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (!pgsgd::run_threads(nt, [&](unsigned t) {
+            for (uint64_t k = S * t / nt; k < S * (t + 1) / nt; ++k) handle2[k] = (new_of_old[g->step_handle[k] >> 1] << 1) | (g->step_handle[k] & 1u);
+        })) { set_error("out of memory while renaming the nodes"); return PGSGD_E_NOMEM; }
+    pgsgd_graph_view g2 = *g;
+    g2.node_len = len2.data();
+    g2.step_handle = handle2.data();
+    timer.lap("node ranks by path position");
+    std::vector<double> Xd2, Yd2;
+    if (Xd) { Xd2.resize(2 * N); Yd2.resize(2 * N); }
+    rc = layout_run_named(&g2, p, X2.data(), Y2.data(), Xd ? Xd2.data() : nullptr, Xd ? Yd2.data() : nullptr, stats);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < N; ++i) {
+        const uint64_t n = new_of_old[i];
+        if (Xd) {
+            Xd[2 * i] = Xd2[2 * n]; Xd[2 * i + 1] = Xd2[2 * n + 1];
+            Yd[2 * i] = Yd2[2 * n]; Yd[2 * i + 1] = Yd2[2 * n + 1];
+        } else {
+            X[2 * i] = X2[2 * n]; X[2 * i + 1] = X2[2 * n + 1];
+            Y[2 * i] = Y2[2 * n]; Y[2 * i + 1] = Y2[2 * n + 1];
+        }
+    }
+    if (stats) stats->relabeled = 1;
+    return PGSGD_OK;
+}
+
+static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
+    int rc = PGSGD_OK;
     // path_sgd_layout.cpp:64-74: nothing to do unless some path has more than one step
     bool multi = false;
     for (uint64_t i = 0; i < g->n_paths && !multi; ++i) multi = g->path_first[i + 1] - g->path_first[i] > 1;
@@ -2007,6 +2064,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
         stats->early_stop = early;
         stats->frame_doublings = s->frame_doublings;
         stats->apply_lanes = s->split && !s->tiled ? s->apply_lanes : 0;
+        stats->tiled = s->tiled ? (s->warm_per_lane ? 2u : 1u) : 0u;
         pgsgd_session_kernel_time(s, &stats->kernel_ms, nullptr, 0);
         stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

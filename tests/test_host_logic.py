@@ -203,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol(oa):
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 56 and C.sizeof(_lib.Params) == 136
+    assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 64 and C.sizeof(_lib.Params) == 136
 
 
 def test_no_cpu_fallback_without_a_device(oa, graphs):
@@ -525,3 +525,47 @@ def test_tile_sampler_rules_host_copies_match_the_oracle(orc):
     # every step is some step's twin exactly once, but for the path's unpaired ends
     twins = [lib.pgsgd_tile_pair_partner(first + r, first, cnt, 99) for r in range(cnt)]
     assert sorted(t for t in twins if t != 99) == [r for r in range(cnt) if 0 <= ((first + r) ^ 1) - first < cnt]
+
+
+def test_path_order_renames_nodes_along_the_paths(oa):
+    """pgsgd_graph_path_order: ranks by (path-connected component, mean bp position).  A sorted pangenome whose nodes are
+    renumbered at random comes back in an order that follows the paths again (hardly a step jumps over 128 ranks, where
+    nearly all did), components stay apart, and a sorted graph is left (almost) as it is.  Host only."""
+    from odgi_amd import _lib
+    import ctypes as C
+    g = oa.Graph.synthetic(50_000, 8, seed=5)
+    u32p, f64 = C.POINTER(C.c_uint32), C.c_double
+
+    def order(graph):
+        new = np.zeros(graph.n_nodes, dtype=np.uint32)
+        d0, d1 = f64(), f64()
+        rc = _lib.lib.pgsgd_graph_path_order(C.byref(graph.view), new.ctypes.data_as(u32p), C.byref(d0), C.byref(d1))
+        assert rc == 0
+        return new, d0.value, d1.value
+
+    new, d0, d1 = order(g)
+    assert sorted(new.tolist()) == list(range(g.n_nodes)) and d0 < 0.01 and d1 < 0.01
+    # mean path position follows the synthetic graph's own order up to local swaps (nodes no path visits are components of
+    # their own and go behind the component they sat in)
+    visited = np.zeros(g.n_nodes, dtype=bool)
+    visited[g.step_handle >> 1] = True
+    assert np.abs(new[visited].astype(np.int64) - np.arange(int(visited.sum()))).max() < 256
+    perm = np.random.RandomState(3).permutation(g.n_nodes)
+    new_len = np.empty_like(g.node_len)
+    new_len[perm] = g.node_len
+    h = g.step_handle
+    gr = oa.Graph.from_arrays(new_len, g.path_first, (perm[h >> 1].astype(np.uint32) << 1) | (h & 1))
+    new_r, d0, d1 = order(gr)
+    assert d0 > 0.9 and d1 < 0.01
+    # the recovered order is the sorted graph's (up to ties of the mean position, which go by the names): new_r[perm[i]] ~ new[i]
+    assert np.abs(new_r[perm][visited].astype(np.int64) - new[visited].astype(np.int64)).max() <= 8
+    # two components (two copies of the graph side by side, node ranks interleaved): each keeps to itself
+    n = g.n_nodes
+    len2 = np.repeat(g.node_len, 2)
+    first2 = np.concatenate([g.path_first, g.path_first[1:] + g.n_steps])
+    h2 = np.concatenate([((h >> 1) * 2 << 1) | (h & 1), (((h >> 1) * 2 + 1) << 1) | (h & 1)]).astype(np.uint32)
+    g2 = oa.Graph.from_arrays(len2, first2, h2)
+    new2, d0, d1 = order(g2)
+    comp_a, comp_b = new2[0::2][visited], new2[1::2][visited]   # (the nodes no path visits are components of their own, at the end)
+    assert comp_a.max() < comp_b.min() or comp_b.max() < comp_a.min()
+    assert d1 < 0.01
