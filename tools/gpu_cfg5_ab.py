@@ -16,7 +16,7 @@ N = int(float(sys.argv[1]))
 variants = sys.argv[2:] or ["tile", "per_lane"]
 g = oa.Graph.synthetic(N, 50, seed=42)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
-KNOBS = ("PGSGD_TILE_FAR_RELAX", "PGSGD_TILE_SNAPSHOT_PASS", "PGSGD_TILE_LANES", "PGSGD_FRAME_SPAN", "PGSGD_TILE_LOCK_MU")
+KNOBS = ("PGSGD_TILE_FAR_RELAX", "PGSGD_TILE_SNAPSHOT_PASS", "PGSGD_TILE_LANES", "PGSGD_FRAME_SPAN", "PGSGD_TILE_LOCK_MU", "PGSGD_TILE_SUBSTEPS")
 for v_in in variants:
     v = v_in
     for k in KNOBS:
@@ -40,7 +40,12 @@ for v_in in variants:
         if v0.startswith("lanes"): os.environ["PGSGD_TILE_LANES"] = v0[5:]
     elif v.startswith("lanes"): os.environ["PGSGD_TILE_LANES"] = v[5:]
     if v.startswith("lock"): os.environ["PGSGD_TILE_LOCK_MU"] = v[4:].split("@")[0]
-    p = oa.LayoutParams.defaults(g, device=0, flags=flags)
+    if v.startswith("sub"): os.environ["PGSGD_TILE_SUBSTEPS"] = v[3:].split("@")[0]
+    n_streams = 0
+    if v.startswith("pl"):   # per-lane kernel with this many streams (lanes), e.g. pl45875@11
+        flags = _lib.FLAG_NO_TILES
+        n_streams = int(v[2:].split("@")[0])
+    p = oa.LayoutParams.defaults(g, device=0, flags=flags, n_streams=n_streams)
     p.seed = seed
     etas = oa.path_linear_sgd_layout_schedule(p)
     t0 = time.time()
