@@ -57,6 +57,10 @@ const Opt kOpts[] = {
     {0, "device", true, "N", "HIP device ordinal (default: current)."},
     {0, "gpu-no-tiles", false, "", "Always use the per-lane kernel (one reference worker stream per GPU lane), never the tiled one."},
     {0, "gpu-terms-per-anchor", true, "N", "Partners drawn per sampled first step (default: 1 = the reference's term stream)."},
+    {0, "gpu-exact-math", false, "", "Tile kernel: IEEE divisions and square root in a term's geometry instead of the hardware's reciprocal / reciprocal square root (1 ulp)."},
+    {0, "gpu-no-partner-pairs", false, "", "Tile kernel: every lane keeps its own uniform partner (default: the lanes of a wavefront share them in pairs of neighbouring steps)."},
+    {0, "gpu-no-relabel", false, "", "Keep the graph's node ranks even if they do not follow the paths (default: such a graph is laid out under ranks by path position, which lets the tile kernel run)."},
+    {0, "gpu-lock-window-ends", false, "", "Tile kernel: conflict resolution on shared node ends (measured: no effect on the layout)."},
     {0, "stress", false, "", "Print sampled path stress and the odgi-stats 2D path distance of the result to stderr."},
     {'P', "progress", false, "", "Write the current progress to stderr."},
     {'h', "help", false, "", "Print a help summary for odgi layout."},
@@ -266,6 +270,10 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     if (a.has("gpu-terms-per-anchor") && !to_u64(a.get("gpu-terms-per-anchor"), &tpa)) return finish(bad("gpu-terms-per-anchor"));
     p.terms_per_anchor = (uint32_t)std::max<uint64_t>(1, tpa);
     if (a.has("gpu-no-tiles")) p.flags |= PGSGD_FLAG_NO_TILES;
+    if (a.has("gpu-exact-math")) p.flags |= PGSGD_FLAG_EXACT_MATH;
+    if (a.has("gpu-no-partner-pairs")) p.flags |= PGSGD_FLAG_NO_PARTNER_PAIRS;
+    if (a.has("gpu-no-relabel")) p.flags |= PGSGD_FLAG_NO_RELABEL;
+    if (a.has("gpu-lock-window-ends")) p.flags |= PGSGD_FLAG_LOCK_WINDOW_ENDS;
     p.device = -1;
     if (a.has("device")) {
         if (!to_u64(a.get("device"), &device)) return finish(bad("device"));

@@ -84,6 +84,23 @@ struct default_init_allocator : std::allocator<T> {
     }
 };
 template <class T> using raw_vector = std::vector<T, default_init_allocator<T>>;
+// The `-P` progress line in the form of the reference's ProgressMeter (src/algorithms/progress.hpp:52-68 with the banner of
+// path_sgd_layout.cpp:45-46): "\r<banner> <percent>% @ <rate> bp/s elapsed: DD:HH:MM:SS remain: DD:HH:MM:SS" — the rate is
+// term updates per second; the reference's meter labels it bp/s, and a drop-in keeps the label.  One line per iteration.
+inline void progress_line(const char* banner, uint64_t completed, uint64_t total, double elapsed_s) {
+    const double rate = elapsed_s > 0 ? (double)completed / elapsed_s : 0.0;
+    const double remain_s = completed > 0 && rate > 0 ? (double)(total - completed) / rate : 0.0;
+    auto dhms = [](double sec, int out[4]) {
+        const long t = (long)sec;
+        out[0] = (int)(t / 86400); out[1] = (int)(t % 86400 / 3600); out[2] = (int)(t % 3600 / 60); out[3] = (int)(t % 60);
+    };
+    int e[4], r[4];
+    dhms(elapsed_s, e);
+    dhms(remain_s, r);
+    fprintf(stderr, "\r%s %5.2f%% @ %.2e bp/s elapsed: %02d:%02d:%02d:%02d remain: %02d:%02d:%02d:%02d", banner,
+            total ? 100.0 * (double)completed / (double)total : 100.0, rate, e[0], e[1], e[2], e[3], r[0], r[1], r[2], r[3]);
+}
+
 }  // namespace pgsgd
 
 struct pgsgd_graph {

@@ -323,8 +323,8 @@ void rank_main(Shared& sh, int r) {
         if (any_guard) R_TRY(pgsgd_session_reframe(s));
         ++iters;
         if (r == 0 && p0.progress)
-            fprintf(stderr, "\r[odgi::path_linear_sgd_layout] 2D path-guided SGD on %d GPUs: iteration %llu/%llu  eta %.4g  delta_max %.4g   ", G,
-                    (unsigned long long)(it + 1), (unsigned long long)p0.iter_max, sh.etas[it], dmax_all);
+            pgsgd::progress_line("[odgi::path_linear_sgd_layout] 2D path-guided SGD:", iters * M, p0.iter_max * M,
+                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         if (it + 1 >= p0.iter_max) break;
         if (dmax_all <= p0.delta) {  // path_sgd_layout.cpp:142 — the same decision on every rank
             early = 1;

@@ -2032,8 +2032,8 @@ static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, fl
         ++iters;
         terms += p->min_term_updates;
         if (p->progress)
-            fprintf(stderr, "\r[odgi::path_linear_sgd_layout] 2D path-guided SGD: iteration %llu/%llu  eta %.4g  delta_max %.4g   ",
-                    (unsigned long long)(it + 1), (unsigned long long)p->iter_max, etas[it], dmax);
+            pgsgd::progress_line("[odgi::path_linear_sgd_layout] 2D path-guided SGD:", terms, p->iter_max * p->min_term_updates,
+                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         if (it + 1 >= p->iter_max) break;
         if (dmax <= p->delta) {  // :142 (also stops at 0, as upstream notes)
             if (p->progress)

@@ -522,6 +522,15 @@ def test_cli_end_to_end(oa, orc, graphs, ographs, tmp_path):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "odgi_amd", "lib", "odgi")
     r = subprocess.run([exe, "layout", "-i", os.path.join(GOLDEN, "t.gfa"), "-T", "-", "-N", "h"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("idx\tX\tY\tcomponent") and len(r.stdout.splitlines()) == 31
+    # -P prints the reference's progress line (ProgressMeter, src/algorithms/progress.hpp:52-68; banner path_sgd_layout.cpp:45-46)
+    import re
+    r = subprocess.run([exe, "layout", "-i", os.path.join(GOLDEN, "DRB1-3123.gfa"), "-o", str(tmp_path / "p.lay"), "-P", "--gpu-exact-math",
+                        "--gpu-no-partner-pairs", "--gpu-no-relabel"], capture_output=True, text=True)
+    assert r.returncode == 0
+    lines = [l for l in r.stderr.replace("\r", "\n").splitlines() if "2D path-guided SGD:" in l]
+    pat = re.compile(r"^\[odgi::path_linear_sgd_layout\] 2D path-guided SGD: +\d+\.\d\d% @ \d\.\d\de[+-]\d\d bp/s elapsed: \d\d:\d\d:\d\d:\d\d remain: \d\d:\d\d:\d\d:\d\d$")
+    assert len(lines) == 30 and all(pat.match(l) for l in lines), lines[:2]
+    assert lines[-1].split("%")[0].endswith("100.00")
 
 
 def test_synthetic_million_node_properties(oa, orc):
