@@ -117,6 +117,7 @@ struct pgsgd_session {
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
     float tile_lock_mu = 0.0f;        // TileArgs::lock_mu (debug knob PGSGD_TILE_LOCK_MU)
+    uint32_t tile_snap_every = 1;     // debug knob PGSGD_TILE_SNAP_EVERY
     uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
     float tile_far_relax_override = 0.0f;  // debug knob PGSGD_TILE_FAR_RELAX: a constant under-relaxation of the far pulls instead of tile_far_relax()
     uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
@@ -758,6 +759,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 1u;
         s->tile_lock_mu = (p->flags & PGSGD_FLAG_LOCK_WINDOW_ENDS) ? 0.1f : 0.0f;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_SNAP_EVERY")) s->tile_snap_every = (uint32_t)std::min(8, std::max(1, atoi(e)));
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
@@ -1542,6 +1544,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.seed_base = s->tile_seed_base;
             ta.wq_threshold = s->tile_wq_threshold;
             ta.lane_coin = s->tile_lane_coin;
+            ta.snap_every = s->tile_snap_every;
             ta.lock_mu = s->tile_lock_mu;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;

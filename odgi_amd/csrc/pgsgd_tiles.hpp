@@ -154,6 +154,7 @@ struct TileArgs {
                                        // that went for their ends' locks, and that lost one (cumulative)
     uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
     float lock_mu;                     // conflict resolution inside a window: terms whose learning rate mu reaches this take both their ends' locks or do nothing (0: off)
+    uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
     Outbox ob;
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // bytes: whole 64-byte units per store instruction.  Readers in other workgroups may see a record's old or new
             // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
             // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
-            if (ta.recs2_out) {
+            if (ta.recs2_out && (ta.snap_every <= 1u || ((uint32_t)a.epoch + ti) % ta.snap_every == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
                 __syncthreads();
                 uint4* dst = ta.recs2_out + 2 * (uint64_t)t.t0;
                 for (uint32_t piece = threadIdx.x; piece < 2 * t.n; piece += blockDim.x) {
