@@ -159,7 +159,9 @@ def main():
                    "kernel_launches_per_step": n_kernels / args.steps, "memset_and_copy_ops_per_step": n_copies / args.steps,
                    "update_kernel_launches_per_step": launches / args.steps,
                    "parallelism": f"{getattr(eng, 'shard_mode', 'terms') if drv.engine_sharded else 'terms'}-sharded x{world}, graph replicated, "
-                                  f"{drv.blocks} fused delta all-reduce(s) per eta step",
+                                  + ("2 integer delta all-reduces per eta step (one per region colour; the ranks hold one GPU's coordinates bit for bit)"
+                                     if drv.engine_sharded and getattr(eng, "shard_mode", "") == "regions-exact" and world > 1
+                                     else f"{drv.blocks} fused delta all-reduce(s) per eta step"),
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
                    "collective_backend": dist.get_backend() if dist.is_initialized() else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
