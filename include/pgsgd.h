@@ -270,7 +270,7 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
 /* Region size (nodes) a tiled session takes for a graph of n_nodes nodes when a launch has resident_workgroups workgroups
  * on the device (MI355X: 256 CUs x 4): the multiple of 8 in [240, 272] whose work items (one per region of a colour) fill
- * their rounds best, 256 when a launch is a single round or more than eight.  Pure host arithmetic. */
+ * their rounds best, 256 when a launch is a single round or more than three.  Pure host arithmetic. */
 uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups);
 /* Two rules of the tile kernel's sampler, restated on the host for tests: the Zipf/uniform coin (path_sgd_layout.cpp:205)
  * that the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration (a SplitMix64 stream per

@@ -282,7 +282,10 @@ static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t
 
 // Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within
 // 7 %) for which the work items of a launch (one per region of a colour: ceil(regions / 2)) fill their rounds over
-// `slots` resident workgroups best; 256 when one round or more than eight are needed either way (see the caller).
+// `slots` resident workgroups best; 256 when one round or more than three are needed either way.  (Measured with and without
+// the rule, tile kernel's roofline fraction: 1e6 nodes, two rounds: 0.493 against 0.488; 1.5e6, three: 0.543 / 0.535; 6e5, barely two:
+// 0.395 / 0.397; 2e6, four: 0.529 / 0.530; 3e6, six: 0.527 / 0.534 — a launch of many rounds balances itself, items being handed
+// out by decreasing size: profiles/r04/NOTES.md.)
 static uint32_t choose_region(uint64_t n_nodes, uint64_t slots);
 extern "C" uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups) {
     return n_nodes && resident_workgroups ? choose_region(n_nodes, resident_workgroups) : 256;
@@ -301,7 +304,7 @@ extern "C" uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t pa
 static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
     auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
     const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;
-    if (rounds256 < 2 || rounds256 > 8) return 256;
+    if (rounds256 < 2 || rounds256 > 3) return 256;
     uint32_t best = 256;
     double best_fill = (double)items_of(256) / (double)(rounds256 * slots);
     for (uint32_t r = 240; r <= 272; r += 8) {
@@ -732,7 +735,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             // — two rounds, the second 91 % full — R = 248 makes 2 017, R = 240 makes 2 084: a third round for 36
             // items (measured, tile kernel's roofline fraction: 0.488 / 0.493 / 0.420;
             // profiles/r03/bench_variants_call25_region.txt).  So R is the multiple of 8 in [240, 272] that fills the
-            // rounds best; graphs of a single round or of more than eight keep 256.
+            // rounds best; graphs of a single round or of more than three keep 256.
             const uint64_t slots = (uint64_t)prop.multiProcessorCount * std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
             const uint32_t r = choose_region(g->n_nodes, slots);
             if (r != s->region) {
