@@ -160,7 +160,7 @@ def main():
                    "update_kernel_launches_per_step": launches / args.steps,
                    "parallelism": f"{getattr(eng, 'shard_mode', 'terms') if drv.engine_sharded else 'terms'}-sharded x{world}, graph replicated, "
                                   + ("2 integer delta all-reduces per eta step (one per region colour; the ranks hold one GPU's coordinates bit for bit)"
-                                     if drv.engine_sharded and getattr(eng, "shard_mode", "") == "regions-exact" and world > 1
+                                     if drv.engine_sharded and getattr(eng, "shard_mode", "") == "regions-exact" and drv.exchanging
                                      else f"{drv.blocks} fused delta all-reduce(s) per eta step"),
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
                    "collective_backend": dist.get_backend() if dist.is_initialized() else None},

@@ -175,7 +175,9 @@ class DistributedLayout:
         if self.exchanging:
             self._buf = engine.new_exchange_buffer(self.world)
             engine.exchange_mark()
-            if self.world > 1 and hasattr(engine, "set_shard") and (region_shard or (tile_shard and getattr(engine, "tiled", False))):
+            # (a one-rank group under force_exchange shards too — trivially — so that a single-GPU box executes the very
+            # collectives of a multi-rank run, the integer all-reduce of the exact exchange included)
+            if hasattr(engine, "set_shard") and (region_shard or (tile_shard and getattr(engine, "tiled", False))):
                 self.engine_sharded = bool(engine.set_shard(self.rank, self.world, by_region=region_shard))
 
     def _iteration_terms(self):

@@ -1254,6 +1254,19 @@ def test_cpp_multi_gpu_driver_executes_rccl_with_one_rank(oa, graphs, monkeypatc
         s1, s2 = oa.path_stress(g, X1, Y1, 500_000, seed=1), oa.path_stress(g, X2, Y2, 500_000, seed=1)
         print(f"one-rank RCCL run: stress {s2:.4f} vs plain run {s1:.4f}")
         assert np.isfinite(X2).all() and 0.8 * s1 <= s2 <= 1.25 * s1
+    # the exact exchange through the same binding: ncclAllReduce of 64-bit integers after each colour's launch (one rank)
+    g = oa.Graph.synthetic(100_000, 12, seed=3)
+    X0, Y0 = oa.initial_layout(g, "d", seed=4)
+    p = _params(oa, g)
+    X1, Y1 = X0.copy(), Y0.copy()
+    oa.path_linear_sgd_layout_gpu(g, p, X1, Y1)
+    monkeypatch.setenv("PGSGD_MULTI_FORCE", "1")
+    monkeypatch.setenv("PGSGD_MULTI_SHARD", "exact")
+    X2, Y2 = X0.copy(), Y0.copy()
+    st2 = oa.path_linear_sgd_layout_gpu(g, p, X2, Y2)
+    s1, s2 = oa.path_stress(g, X1, Y1, 500_000, seed=1), oa.path_stress(g, X2, Y2, 500_000, seed=1)
+    print(f"one-rank RCCL run, exact exchange: stress {s2:.4f} vs plain run {s1:.4f}")
+    assert st2["iterations"] == p.iter_max and np.isfinite(X2).all() and 0.9 * s1 <= s2 <= 1.1 * s1
 
 
 def test_bench_runs_the_rccl_exchange_under_torchrun_with_one_rank(tmp_path):
@@ -1272,6 +1285,15 @@ def test_bench_runs_the_rccl_exchange_under_torchrun_with_one_rank(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["rccl_ranks"] == 1 and out["config"]["collective_backend"] == "nccl"
     assert out["value"] > 0 and out["stress_sampled"] < out["stress_initial"]
+    # a graph large enough for the region shard: the EXACT exchange — RCCL's 64-bit integer all-reduce after each colour's launch
+    cmd[cmd.index("--nodes") + 1] = "1100000"
+    cmd[cmd.index("--paths") + 1] = "30"
+    cmd[cmd.index("--master-port") + 1] = "29714"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["parallelism"].startswith("regions-exact-sharded x1")
+    assert out["value"] > 0 and out["stress_sampled"] < 1e-3 * out["stress_initial"]
 
 
 def test_cli_reads_odgi_native_graph_file(oa, orc, tmp_path):
