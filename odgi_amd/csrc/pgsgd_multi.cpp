@@ -195,6 +195,7 @@ void rank_main(Shared& sh, int r) {
         int want = -1;
         if (const char* e = pgsgd::debug_env("PGSGD_MULTI_SHARD"))  // test knob: tiles / regions / exact whatever the graph's size
             want = !strcmp(e, "tiles") ? 0 : !strcmp(e, "regions") ? 1 : !strcmp(e, "exact") ? 2 : -1;
+        if (want > 0 && info <= 0) want = -1;   // (the knob asks for a way of sharding TILES: a per-lane session shards its term count)
         int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, want);
         if (rcs == 2 && want < 0) {  // by region: with the exact exchange (fixed-point coordinates: the default format)
             int fixed = 0;

@@ -1259,11 +1259,14 @@ def test_cpp_multi_gpu_driver_executes_rccl_with_one_rank(oa, graphs, monkeypatc
     X0, Y0 = oa.initial_layout(g, "d", seed=4)
     p = _params(oa, g)
     X1, Y1 = X0.copy(), Y0.copy()
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")
     oa.path_linear_sgd_layout_gpu(g, p, X1, Y1)
     monkeypatch.setenv("PGSGD_MULTI_FORCE", "1")
     monkeypatch.setenv("PGSGD_MULTI_SHARD", "exact")
+    monkeypatch.setenv("PGSGD_TILE_FORCE", "1")    # (a graph this small would run the per-lane kernel)
     X2, Y2 = X0.copy(), Y0.copy()
     st2 = oa.path_linear_sgd_layout_gpu(g, p, X2, Y2)
+    assert st2["tiled"] == 1
     s1, s2 = oa.path_stress(g, X1, Y1, 500_000, seed=1), oa.path_stress(g, X2, Y2, 500_000, seed=1)
     print(f"one-rank RCCL run, exact exchange: stress {s2:.4f} vs plain run {s1:.4f}")
     assert st2["iterations"] == p.iter_max and np.isfinite(X2).all() and 0.9 * s1 <= s2 <= 1.1 * s1
