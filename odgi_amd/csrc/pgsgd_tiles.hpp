@@ -160,6 +160,26 @@ struct TileArgs {
     Outbox ob;
 };
 
+// The head of the tile kernel's argument segment as the ABI lays it out (arguments in order, each at its natural
+// alignment; the sampler's tables and the iteration's numbers follow), and a read of one argument from it AT THE PLACE OF USE.  The kernel has ~45 pointer-sized arguments; the compiler loads them
+// all on entry and keeps them in scalar registers across the term loop, where two thirds are never used — 70-90 scalar
+// registers spilled into vector lanes (profiles/r03: .sgpr_spill_count) and read back with v_readlane inside the loop.
+// Arguments that only cold code needs (work-item pick-up, the staging of a window, the outbox's line replacement and
+// flush, the epilogue) are read through TILE_COLD where they are used: one s_load there, no register held in between.
+// (The empty asm hides the segment's address from the optimiser, which would otherwise merge the load with the entry
+// loads.)  sgd_tile_kernel checks the layout assumption once per launch and traps if it does not hold.
+struct TileKernelArgs {
+    DevConst c;
+    TileArgs ta;
+};
+template <class T>
+__device__ __forceinline__ T tile_kernarg(uint32_t offset) {
+    uint64_t base = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<const T __attribute__((address_space(4)))*>(base + offset);
+}
+#define TILE_COLD(field) tile_kernarg<std::remove_reference_t<decltype(TileKernelArgs::field)>>((uint32_t)__builtin_offsetof(TileKernelArgs, field))
+
 // Every (tile, lane) pair owns a generator per iteration: lane l of the `lanes` lanes that work on a tile draws the
 // tile's terms l, l + lanes, l + 2 lanes, ... from one stream.  Which workgroup runs a tile, and when, changes nothing
 // about the terms that are drawn, and the oracle reproduces them (tests/test_gpu_parity.py: tile terms bit-exact).
@@ -194,17 +214,44 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 // lanes have a message per trip (a step that rounds to no quantum sends nothing).
 constexpr uint32_t kObStateShift = 4;                 // (kObLine = 8 slots < 1 << 4)
 constexpr uint32_t kWqCap = 128;                      // fewer than 64 waiting + at most 64 appended per call
+// The arrays follow one another behind the tile records; the struct keeps their common base as a byte offset into the
+// workgroup's LDS and works the others out where they are used (a few scalar operations in the rings' protocol, which
+// runs once per 64 messages of a wave) instead of holding eight pointers in scalar registers across the term loop.
+extern __shared__ uint64_t tile_lds[];
 struct OutboxLds {
-    uint64_t* stage;  // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
-    uint32_t* head;   // [B + kObRings] slots claimed
-    uint32_t* state;  // [B + kObRings * kObRingLines] per line: (rounds completed << kObStateShift) | slots written
-    uint32_t* line;   // [B] (first chunk of the open group << 10) | lines claimed in the group
-    uint32_t* chunk0; // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
-    uint2* list;      // [waves][64] lines completed in one round of one wave: {staged line, global line index}
-    uint64_t* wq_msg; // [waves][kWqCap] the waves' private queues: packed messages ...
-    uint8_t* wq_b;    // [waves][kWqCap] ... and their buckets
+    uint32_t base;      // byte offset of `stage` in the workgroup's LDS
     uint32_t n_buckets;
-    uint32_t ring_b0; // bucket of hot ring 0 (the window's), wave-uniform
+    uint32_t ring_b0;   // bucket of hot ring 0 (the window's), wave-uniform
+    __device__ __forceinline__ uint32_t lines() const { return n_buckets + kObRings * kObRingLines; }
+    __device__ __forceinline__ uint32_t at(uint32_t bytes) const {  // (the empty asm keeps the sum at its use: not hoisted out of the term loop into a register of its own)
+        uint32_t off = base + bytes;
+        asm volatile("" : "+s"(off));
+        return off;
+    }
+    template <class T> __device__ __forceinline__ T* ptr(uint32_t off) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(tile_lds) + off); }
+    // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
+    __device__ __forceinline__ uint64_t* stage() const { return ptr<uint64_t>(at(0)); }
+    // [waves][kWqCap] the waves' private queues: packed messages ...
+    __device__ __forceinline__ uint32_t wq_msg_off() const { return lines() * kObLine * 8u; }
+    __device__ __forceinline__ uint64_t* wq_msg() const { return ptr<uint64_t>(at(wq_msg_off())); }
+    // [waves][64] lines completed in one round of one wave: {staged line, global line index}
+    __device__ __forceinline__ uint32_t list_off() const { return wq_msg_off() + kTileWaves * kWqCap * 8u; }
+    __device__ __forceinline__ uint2* list() const { return ptr<uint2>(at(list_off())); }
+    // [B + kObRings] slots claimed
+    __device__ __forceinline__ uint32_t head_off() const { return list_off() + kTileWaves * 64u * 8u; }
+    __device__ __forceinline__ uint32_t* head() const { return ptr<uint32_t>(at(head_off())); }
+    // [B + kObRings * kObRingLines] per line: (rounds completed << kObStateShift) | slots written
+    __device__ __forceinline__ uint32_t state_off() const { return head_off() + (n_buckets + kObRings) * 4u; }
+    __device__ __forceinline__ uint32_t* state() const { return ptr<uint32_t>(at(state_off())); }
+    // [B] (first chunk of the open group << 10) | lines claimed in the group
+    __device__ __forceinline__ uint32_t line_off() const { return state_off() + lines() * 4u; }
+    __device__ __forceinline__ uint32_t* line() const { return ptr<uint32_t>(at(line_off())); }
+    // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
+    __device__ __forceinline__ uint32_t chunk0_off() const { return line_off() + n_buckets * 4u; }
+    __device__ __forceinline__ uint32_t* chunk0() const { return ptr<uint32_t>(at(chunk0_off())); }
+    // [waves][kWqCap] ... and the queued messages' buckets
+    __device__ __forceinline__ uint32_t wq_b_off() const { return chunk0_off() + n_buckets * 4u; }
+    __device__ __forceinline__ uint8_t* wq_b() const { return ptr<uint8_t>(at(wq_b_off())); }
 };
 
 __host__ __device__ inline uint32_t tile_lock_words(uint32_t region) { return (4u * region + 31u) / 32u; }
@@ -225,27 +272,27 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
     // reaches the loop's end before any starts the next pass, and the replacing lane finishes within its pass.)
     bool strayed = false;
     for (;;) {
-        if (strayed && (__hip_atomic_load(L.line + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
+        if (strayed && (__hip_atomic_load(L.line() + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
             __builtin_amdgcn_s_sleep(1);  // still being replaced (by a lane of another wave)
             continue;
         }
-        const uint32_t lp = atomicAdd(L.line + b, 1u);
+        const uint32_t lp = atomicAdd(L.line() + b, 1u);
         const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // first chunk of the group, lines claimed in the group
-        if (used < kObLinesPerGroup && chunk < kObOverflow) return (L.chunk0[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
+        if (used < kObLinesPerGroup && chunk < kObOverflow) return (L.chunk0()[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
         if (chunk == kObOverflow) {  // the bucket's share of the pool is used up (sticky; the count field is put back so that it cannot run over)
-            atomicExch(L.line + b, kObOverflow << kObUsedBits);
+            atomicExch(L.line() + b, kObOverflow << kObUsedBits);
             return kObNoLine;
         }
         if (used == kObLinesPerGroup) {  // this lane replaces the full group and takes the new one's first line
             if (chunk != kObNone)
-                for (uint32_t k = 0; k < kObGroup; ++k) ob.fill[L.chunk0[b] + chunk + k] = kObChunk;
-            const uint32_t nc = atomicAdd(ob.next + b, kObGroup);
-            if (nc + kObGroup > ob.cap[b]) {
-                atomicExch(L.line + b, kObOverflow << kObUsedBits);
+                for (uint32_t k = 0; k < kObGroup; ++k) TILE_COLD(ta.ob.fill)[L.chunk0()[b] + chunk + k] = kObChunk;
+            const uint32_t nc = atomicAdd(TILE_COLD(ta.ob.next) + b, kObGroup);
+            if (nc + kObGroup > TILE_COLD(ta.ob.cap)[b]) {
+                atomicExch(L.line() + b, kObOverflow << kObUsedBits);
                 return kObNoLine;
             }
-            atomicExch(L.line + b, (nc << kObUsedBits) | 1u);
-            return (L.chunk0[b] + nc) * kObLinesPerChunk;
+            atomicExch(L.line() + b, (nc << kObUsedBits) | 1u);
+            return (L.chunk0()[b] + nc) * kObLinesPerChunk;
         }
         strayed = true;  // the group is being replaced: every lane adds to the word at most once per replacement, so the 10-bit field holds
     }
@@ -267,25 +314,25 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
     if (m0 | m1) {  // wave-uniform
         const uint32_t want = lane == 0 ? (uint32_t)__popcll(m0) : (uint32_t)__popcll(m1);
         uint32_t base = 0;
-        if (lane < kObRings && want) base = atomicAdd(L.head + L.n_buckets + lane, want);
+        if (lane < kObRings && want) base = atomicAdd(L.head() + L.n_buckets + lane, want);
         const uint32_t base0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), base1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
         const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));  // lanes below this one in the mask
         const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
         slot = r == 0 ? base0 + rank0 : base1 + rank1;
     }
-    if (has && !hot) slot = atomicAdd(L.head + b, 1u);
+    if (has && !hot) slot = atomicAdd(L.head() + b, 1u);
     const uint32_t lines_log2 = hot ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
     const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + ((slot >> kObLineLog2) & ((1u << lines_log2) - 1u));  // staged line of the slot
     const uint32_t round = slot >> (kObLineLog2 + lines_log2);
-    uint2* list = L.list + (threadIdx.x >> 6) * 64;
+    uint2* list = L.list() + (threadIdx.x >> 6) * 64;
     bool pending = has;
     do {
         bool completes = false;
         // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out)
-        if (pending && (__hip_atomic_load(L.state + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kObStateShift) == (round & (0xffffffffu >> kObStateShift))) {
-            L.stage[src * kObLine + slot % kObLine] = packed;
+        if (pending && (__hip_atomic_load(L.state() + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kObStateShift) == (round & (0xffffffffu >> kObStateShift))) {
+            L.stage()[src * kObLine + slot % kObLine] = packed;
             pending = false;
-            completes = ((atomicAdd(L.state + src, 1u) + 1u) & ((1u << kObStateShift) - 1u)) == kObLine;  // the last of the line's writers writes it out
+            completes = ((atomicAdd(L.state() + src, 1u) + 1u) & ((1u << kObStateShift) - 1u)) == kObLine;  // the last of the line's writers writes it out
         } else if (pending) {
             __builtin_amdgcn_s_sleep(2);  // waiting for another wave to write a line out: leave it the issue slots
         }
@@ -302,15 +349,15 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
                 const uint32_t e = base + lane / kObLine, piece = lane % kObLine;
                 if (e < n) {
                     const uint2 it = list[e];
-                    const uint64_t m = L.stage[it.x * kObLine + piece];
+                    const uint64_t m = L.stage()[it.x * kObLine + piece];
                     if (it.y != kObNoLine) {
-                        ob.pool[(uint64_t)it.y * kObLine + piece] = m;
+                        TILE_COLD(ta.ob.pool)[(uint64_t)it.y * kObLine + piece] = m;
                     } else {  // no room left in the pool: the spill words, added to the coordinates by the drain
                         const uint32_t mb = it.x < L.n_buckets ? it.x : L.ring_b0 + (it.x - L.n_buckets) / kObRingLines;  // the staged line's bucket
                         uint32_t off;
                         const uint64_t d = outbox_unpack(ob, m, off);
-                        atomicAdd(ob.spill + (((uint64_t)mb << ob.shift) | off), (unsigned long long)d);
-                        atomicAdd(ob.overflow, 1ull);
+                        atomicAdd(TILE_COLD(ta.ob.spill) + (((uint64_t)mb << ob.shift) | off), (unsigned long long)d);
+                        atomicAdd(TILE_COLD(ta.ob.overflow), 1ull);
                     }
                 }
             }
@@ -318,7 +365,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
             if (completes)  // reopen the line for its next round
-                __hip_atomic_store(L.state + src, (round + 1u) << kObStateShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(L.state() + src, (round + 1u) << kObStateShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } while (__ballot(pending));
 }
@@ -335,7 +382,7 @@ __device__ __forceinline__ void wq_append(const Outbox& ob, const WaveQueue& q, 
     if (!__ballot(has)) return;
     uint64_t packed = 0;
     const bool fits = outbox_pack(ob, end, qx, qy, packed);
-    if (has && !fits) atomicAdd(ob.spill + end, (unsigned long long)outbox_delta(qx, qy));
+    if (has && !fits) atomicAdd(TILE_COLD(ta.ob.spill) + end, (unsigned long long)outbox_delta(qx, qy));
     has = has && fits;
     const uint64_t m = __ballot(has);  // (taken by the whole wave, outside the branch: the fill count must stay wave-uniform)
     const uint32_t idx = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -371,7 +418,7 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
         const uint32_t i = base + threadIdx.x / kObLine;
         uint32_t n = 0, b = 0, src = 0;
         if (i < count) {
-            const uint32_t ring = first + i, head = L.head[ring];
+            const uint32_t ring = first + i, head = L.head()[ring];
             const bool hot = ring >= L.n_buckets;
             b = hot ? L.ring_b0 + (ring - L.n_buckets) : ring;
             n = head % kObLine;  // every full line went out when its last writer finished
@@ -381,25 +428,25 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
         if (n && piece == 0) dst = outbox_next_line(ob, L, b);
         dst = __shfl(dst, (int)((threadIdx.x & 63u) & ~(kObLine - 1u)));
         if (n) {
-            const uint64_t m = piece < n ? L.stage[src * kObLine + piece] : 0ull;  // (0 = add nothing to the bucket's first end)
+            const uint64_t m = piece < n ? L.stage()[src * kObLine + piece] : 0ull;  // (0 = add nothing to the bucket's first end)
             if (dst != kObNoLine) {
-                ob.pool[(uint64_t)dst * kObLine + piece] = m;
+                TILE_COLD(ta.ob.pool)[(uint64_t)dst * kObLine + piece] = m;
             } else if (piece < n) {
                 uint32_t off;
                 const uint64_t d = outbox_unpack(ob, m, off);
-                atomicAdd(ob.spill + (((uint64_t)b << ob.shift) | off), (unsigned long long)d);
-                atomicAdd(ob.overflow, 1ull);
+                atomicAdd(TILE_COLD(ta.ob.spill) + (((uint64_t)b << ob.shift) | off), (unsigned long long)d);
+                atomicAdd(TILE_COLD(ta.ob.overflow), 1ull);
             }
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
         const uint32_t ring = first + i;
-        L.head[ring] = 0;
+        L.head()[ring] = 0;
         if (ring < L.n_buckets) {
-            L.state[ring] = 0;
+            L.state()[ring] = 0;
         } else {
-            for (uint32_t l = 0; l < kObRingLines; ++l) L.state[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
+            for (uint32_t l = 0; l < kObRingLines; ++l) L.state()[L.n_buckets + (ring - L.n_buckets) * kObRingLines + l] = 0;
         }
     }
 }
@@ -610,36 +657,30 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     OutboxLds L;
     L.n_buckets = ta.ob.n_buckets;
     {
-        const size_t lines = (size_t)L.n_buckets + kObRings * kObRingLines;
-        L.stage = reinterpret_cast<uint64_t*>(trec + ta.tile_steps);
-        L.wq_msg = L.stage + lines * kObLine;
-        L.list = reinterpret_cast<uint2*>(L.wq_msg + kTileWaves * kWqCap);
-        L.head = reinterpret_cast<uint32_t*>(L.list + kTileWaves * 64);
-        L.state = L.head + L.n_buckets + kObRings;
-        L.line = L.state + lines;
-        L.chunk0 = L.line + L.n_buckets;
-        L.wq_b = reinterpret_cast<uint8_t*>(L.chunk0 + L.n_buckets);
-        for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + lines; i += blockDim.x) L.head[i] = 0;
+        L.base = (uint32_t)(4 * (size_t)ta.region * sizeof(uint64_t) + (size_t)ta.tile_steps * sizeof(uint4));  // behind the window and the tile records
+        for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + L.lines(); i += blockDim.x) L.head()[i] = 0;  // heads and line states
     }
     // one lock bit per window word (tile_lock_words(region) 32-bit words behind the queues' bucket bytes)
-    uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b + kTileWaves * kWqCap);
+    uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b() + kTileWaves * kWqCap);
     for (uint32_t i = threadIdx.x; i < tile_lock_words(ta.region); i += blockDim.x) lockw[i] = 0;
     uint32_t n_locked = 0, n_lost = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {  // (workgroups are persistent: workgroup 0 lives as long as the launch has work)
-        ta.clock_probe[0] = __builtin_readcyclecounter();   // s_memtime: shader cycles
-        ta.clock_probe[1] = wall_clock64();                 // s_memrealtime: constant 100 MHz
+    if (TILE_COLD(ta.ob.n_buckets) != ta.ob.n_buckets || TILE_COLD(c.n_nodes) != c.n_nodes) __builtin_trap();  // the argument segment is not laid out as TileKernelArgs says
+    if (blockIdx.x == 0 && threadIdx.x == 0 && TILE_COLD(ta.clock_probe)) {  // (workgroups are persistent: workgroup 0 lives as long as the launch has work)
+        unsigned long long* probe = TILE_COLD(ta.clock_probe);
+        probe[0] = __builtin_readcyclecounter();   // s_memtime: shader cycles
+        probe[1] = wall_clock64();                 // s_memrealtime: constant 100 MHz
     }
     // this wave's message queue; its fill count is wave-uniform and lives in a scalar register
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQueue wq;
-    wq.msg = L.wq_msg + wave * kWqCap;
-    wq.b = L.wq_b + wave * kWqCap;
+    wq.msg = L.wq_msg() + wave * kWqCap;
+    wq.b = L.wq_b() + wave * kWqCap;
     uint32_t wq_n = 0;
     L.ring_b0 = 0x7fffffffu;
     __shared__ uint32_t s_item;
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
-        L.line[b] = (kObNone << kObUsedBits) | kObLinesPerGroup;
-        L.chunk0[b] = ta.ob.chunk0[b];
+        L.line()[b] = (kObNone << kObUsedBits) | kObLinesPerGroup;
+        L.chunk0()[b] = TILE_COLD(ta.ob.chunk0)[b];
     }
     float dmax = 0.0f;
     uint32_t n_far = 0;
@@ -653,14 +694,14 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     // h = far pulls per node end in the previous launch of this colour: together they amount to half a projection,
     // the usual under-relaxation of a Jacobi step (measured against 1 and 1/4: profiles/r02/curves_far_policy.jsonl),
     // less in the first iterations (tile_far_relax).  Inactive once eta/d < far_relax / h.
-    float far_mu_cap = ta.far_mu_cap_first;
-    if (ta.far_from_prev) {
-        const double h = (double)*ta.far_prev / (double)n_ends;
+    float far_mu_cap = TILE_COLD(ta.far_mu_cap_first);
+    if (TILE_COLD(ta.far_from_prev)) {
+        const double h = (double)*TILE_COLD(ta.far_prev) / (double)n_ends;
         far_mu_cap = h > 1.0 ? (float)(1.0 / h) : 1.0f;
     }
-    far_mu_cap *= ta.far_relax;
+    far_mu_cap *= TILE_COLD(ta.far_relax);
     uint32_t my_queue = 0, queues_done = 0;  // (lane 0's copies are the ones used)
-    if (gridDim.x >= kItemQueues && ta.chunk[1] != ta.chunk[kItemQueues]) {  // more than one run, and enough workgroups to have one per XCD
+    if (gridDim.x >= kItemQueues && tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u) != tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * kItemQueues)) {  // more than one run, and enough workgroups to have one per XCD
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         my_queue = xcc & (kItemQueues - 1u);
@@ -670,8 +711,9 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             uint32_t it = kNoItem;
             for (; queues_done < kItemQueues; ++queues_done) {  // a run that is used up stays used up: never asked again
                 const uint32_t q = (my_queue + queues_done) & (kItemQueues - 1u);
-                const uint32_t cand = ta.chunk[q] + atomicAdd(ta.queue + q, 1u) * ta.shard_world + ta.shard_rank;
-                if (cand < ta.chunk[q + 1]) {
+                const uint32_t lo = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * q), hi = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * (q + 1u));
+                const uint32_t cand = lo + atomicAdd(TILE_COLD(ta.queue) + q, 1u) * TILE_COLD(ta.shard_world) + TILE_COLD(ta.shard_rank);
+                if (cand < hi) {
                     it = cand;
                     break;
                 }
@@ -681,28 +723,30 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         __syncthreads();
         const uint32_t item = s_item;
         if (item == kNoItem) break;
-        const WorkItem wi = ta.items[item];
+        const WorkItem wi = TILE_COLD(ta.items)[item];
         const uint32_t wbase = 2 * wi.win0;  // first coordinate word of the window
         if (LOCAL) {
             L.ring_b0 = wbase >> ta.ob.shift;  // the hot rings serve the window's bucket and the next one
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
-                win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(c.coords, wbase + i) : 0;
+                win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(LOCAL ? TILE_COLD(c.coords) : c.coords, wbase + i) : 0;
         }
         for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
-            if (ti % ta.n_sub != ta.sub) continue;  // block-uniform
-            const Tile t = ta.tiles[ti];
+            if (ti % TILE_COLD(ta.n_sub) != TILE_COLD(ta.sub)) continue;  // block-uniform
+            const Tile t = TILE_COLD(ta.tiles)[ti];
             __syncthreads();  // previous tile's terms are done with trec; window staging is complete
-            for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = c.recs[t.t0 + i];
+            for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = TILE_COLD(c.recs)[t.t0 + i];
             __syncthreads();
-            const uint64_t term_begin = ta.term0[ti], term_end = ta.term0[ti + 1];
+            const uint64_t term_begin = TILE_COLD(ta.term0)[ti], term_end = TILE_COLD(ta.term0)[ti + 1];
             const uint32_t t0 = (uint32_t)t.t0;
-            const uint32_t pstart = (uint32_t)c.path_first[t.path];
-            const uint32_t cnt = (uint32_t)(c.path_first[t.path + 1] - c.path_first[t.path]);
+            const uint64_t* path_first = TILE_COLD(c.path_first);
+            const uint32_t pstart = (uint32_t)path_first[t.path];
+            const uint32_t cnt = (uint32_t)(path_first[t.path + 1] - path_first[t.path]);
             const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
-            if (worker) rng.seed(tile_stream_seed(ta.seed_base, a.epoch, ti, threadIdx.x));
-            uint64_t coin_x = tile_coin_seed(ta.seed_base, a.epoch, ti, wave);   // (scalar registers: the wave's coin stream)
+            const uint64_t seed_base = TILE_COLD(ta.seed_base);
+            if (worker) rng.seed(tile_stream_seed(seed_base, a.epoch, ti, threadIdx.x));
+            uint64_t coin_x = tile_coin_seed(seed_base, a.epoch, ti, wave);   // (scalar registers: the wave's coin stream)
             uint64_t coin_cur = COOLING ? 0ull : Xoshiro256Plus::splitmix64(coin_x);
             // The same trip count for every lane of the workgroup (the outbox is wave-cooperative), and two trips more
             // than the longest lane needs.  Every trip finishes term j - 2, draws the partner of term j - 1 (and requests
@@ -914,9 +958,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // bytes: whole 64-byte units per store instruction.  Readers in other workgroups may see a record's old or new
             // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
             // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
-            if (ta.recs2_out && (ta.snap_every <= 1u || ((uint32_t)a.epoch + ti) % ta.snap_every == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
+            uint4* const recs2_out = TILE_COLD(ta.recs2_out);
+            if (recs2_out && (TILE_COLD(ta.snap_every) <= 1u || ((uint32_t)a.epoch + ti) % TILE_COLD(ta.snap_every) == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
                 __syncthreads();
-                uint4* dst = ta.recs2_out + 2 * (uint64_t)t.t0;
+                uint4* dst = recs2_out + 2 * (uint64_t)t.t0;
                 for (uint32_t piece = threadIdx.x; piece < 2 * t.n; piece += blockDim.x) {
                     uint4 v = trec[piece >> 1];
                     if (piece & 1u) {  // the two ends of the step's node, the one the step enters first in front
@@ -935,7 +980,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
                 if ((uint64_t)wbase + i < n_ends) {
-                    c.coords[wbase + i] = win[i];
+                    TILE_COLD(c.coords)[wbase + i] = win[i];
                     guard |= in_frame_guard(win[i]);
                 }
             // the hot rings move on with the window: write out what they hold and unbind them
@@ -946,26 +991,27 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     // write out the partly filled lines and close the chunks this workgroup still has open
     outbox_flush_rings(ta.ob, L, 0, L.n_buckets);
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
-        const uint32_t lp = L.line[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // lines written into the open group
+        const uint32_t lp = L.line()[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // lines written into the open group
         if (chunk < kObOverflow)
             for (uint32_t k = 0; k < kObGroup; ++k) {
                 const uint32_t lines = used > k * kObLinesPerChunk ? (used - k * kObLinesPerChunk < kObLinesPerChunk ? used - k * kObLinesPerChunk : kObLinesPerChunk) : 0u;
-                ta.ob.fill[ta.ob.chunk0[b] + chunk + k] = lines * kObLine;
+                TILE_COLD(ta.ob.fill)[L.chunk0()[b] + chunk + k] = lines * kObLine;
             }
     }
-    if (LOCK && ta.clock_probe && ta.lock_mu > 0.0f) {
+    unsigned long long* const probe = TILE_COLD(ta.clock_probe);
+    if (LOCK && probe && ta.lock_mu > 0.0f) {
         for (int off = 32; off > 0; off >>= 1) { n_locked += __shfl_xor(n_locked, off); n_lost += __shfl_xor(n_lost, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(ta.clock_probe + 4, (unsigned long long)n_locked); atomicAdd(ta.clock_probe + 5, (unsigned long long)n_lost); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(probe + 4, (unsigned long long)n_locked); atomicAdd(probe + 5, (unsigned long long)n_lost); }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && ta.clock_probe) {
-        ta.clock_probe[2] = __builtin_readcyclecounter();
-        ta.clock_probe[3] = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && probe) {
+        probe[2] = __builtin_readcyclecounter();
+        probe[3] = wall_clock64();
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
-    if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(ta.far_count, (unsigned long long)n_far);
+    if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(TILE_COLD(ta.far_count), (unsigned long long)n_far);
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(c.delta_max_bits, __float_as_uint(dmax));
-    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(c.frame_flag, 1u);
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(TILE_COLD(c.delta_max_bits), __float_as_uint(dmax));
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(TILE_COLD(c.frame_flag), 1u);
 }
 
 // Every 32-byte step record rewritten in one pass — the static half from the 16-byte records, the second half with the
