@@ -242,6 +242,9 @@ int pgsgd_session_launch_counts(const pgsgd_session* s, uint64_t* kernel_launche
  * workgroup saw it (s_memtime against the constant 100 MHz s_memrealtime); blocks until the stream is idle; 0 when the
  * session has run no tile launch. */
 int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double* launch_ms);
+/* Debug (PGSGD_DEBUG=1 PGSGD_TILE_TAIL=1): the share of (workgroups x duration) of the last windowed tile launch that its
+ * persistent workgroups were alive for; the rest is the launch's tail.  Zeros when the knob is off. */
+int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction, double* launch_ms, uint32_t* workgroups);
 /* Tile kernel: terms that went for their window ends' locks so far (conflict resolution on shared node coordinates while
  * the learning rate is in the projection regime), and terms among them that found an end taken and did nothing. */
 int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost);
@@ -268,6 +271,11 @@ int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int
  * 0.1 — and the iterations before cooling therefore run the per-lane kernel, the cooling ones the tile kernel */
 int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t* n_nonlocal_tiles,
                             uint64_t* n_work_items, uint32_t* region_nodes, uint32_t* tile_steps);
+/* A tiled session whose launches would have fewer than 24 rounds of work items cuts every window's tiles into k consecutive
+ * parts, each a work item that waits for the part before it (a launch's tail — slots idle while the last items finish —
+ * shrinks with the items).  Returns k (1: whole windows; 0: per-lane kernel); *n_launch_items: items of the two launches.
+ * pgsgd_session_tile_items lists them in launch order for an unsharded session. */
+int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_launch_items);
 /* Region size (nodes) a tiled session takes for a graph of n_nodes nodes when a launch has resident_workgroups workgroups
  * on the device (MI355X: 256 CUs x 4): the multiple of 8 in [240, 272] whose work items (one per region of a colour) fill
  * their rounds best, 256 when a launch is a single round or more than three.  Pure host arithmetic. */

@@ -80,7 +80,8 @@ struct pgsgd_session {
     uint64_t tile_epoch = 0;              // iterations started (tile kernel: part of every term's seed)
     uint64_t relax_iter = 0;              // iterations of the current layout, i.e. since the last upload (index of the far pulls' gentle start)
     uint64_t tile_seed_base = 0;          // seed + stream_offset; a sharded session: seed alone (pgsgd_session_set_shard)
-    unsigned long long* d_clock = nullptr;  // [4] TileArgs::clock_probe of the last windowed tile launch
+    unsigned long long* d_clock = nullptr;  // [6] TileArgs::clock_probe of the last windowed tile launch, [4] its tail_probe
+    bool tile_tail = false;                 // debug knob PGSGD_TILE_TAIL: the launches record their workgroups' lifetimes
     unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
     uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
@@ -108,6 +109,16 @@ struct pgsgd_session {
     pgsgd::Tile* d_tiles = nullptr;
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
+    // the session's own windows with their tiles cut into tile_split consecutive parts (WorkItem::local: kItemHasNext,
+    // kItemDepShift): what it launches when tile_split > 1 (build_launch_items)
+    uint32_t tile_split = 1;
+    uint32_t tile_split_knob = 0;         // debug knob PGSGD_TILE_SPLIT (0: the rule)
+    bool items_one_run = true;            // the work items of a colour are one run by decreasing size (not PGSGD_TILE_ORDER=region)
+    std::vector<pgsgd::WorkItem> h_items_split;
+    pgsgd::WorkItem* d_items_split = nullptr;
+    uint32_t n_items_split[2] = {0, 0};
+    uint32_t* d_item_done = nullptr;      // [max items of a launch] TileArgs::item_done
+    uint32_t launch_stamp = 0;            // TileArgs::stamp of the last tile launch
     uint32_t item_chunk[2][pgsgd::kItemQueues + 1] = {};  // per colour: runs of the windowed items, one per XCD
     uint32_t n_windowless = 0;            // the last n_windowless items of colour 0 have no window (their own launch)
     uint32_t* d_queue = nullptr;          // [3][kItemQueues] work-item counters: colour 0, colour 1, colour 0's window-less items
@@ -481,6 +492,85 @@ static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, 
     return ht;
 }
 
+// One colour's work items with every window's tiles cut into k consecutive parts (see WorkItem): part 0 of every window in the
+// given order, then part 1 of every window, ...; a part waits for the part before it of the same window.  A window with
+// fewer than k tiles has fewer parts.  The window-less items (the last n_windowless) follow unchanged.
+static std::vector<pgsgd::WorkItem> split_items(const std::vector<pgsgd::WorkItem>& items, uint32_t n_windowless, uint32_t k) {
+    const uint32_t n_local = (uint32_t)items.size() - n_windowless;
+    std::vector<pgsgd::WorkItem> out;
+    std::vector<uint32_t> prev(n_local, 0xffffffffu);  // index in `out` of the window's last part so far
+    for (uint32_t j = 0; j < k; ++j)
+        for (uint32_t w = 0; w < n_local; ++w) {
+            const pgsgd::WorkItem& wi = items[w];
+            const uint32_t len = wi.tile_end - wi.tile_begin, parts = std::min(k, std::max<uint32_t>(1, len));
+            if (j >= parts) continue;
+            pgsgd::WorkItem part = wi;
+            part.tile_begin = wi.tile_begin + (uint32_t)((uint64_t)len * j / parts);
+            part.tile_end = wi.tile_begin + (uint32_t)((uint64_t)len * (j + 1) / parts);
+            part.local = pgsgd::kItemLocal;
+            if (prev[w] != 0xffffffffu) {
+                part.local |= (prev[w] + 1u) << pgsgd::kItemDepShift;
+                out[prev[w]].local |= pgsgd::kItemHasNext;
+            }
+            prev[w] = (uint32_t)out.size();
+            out.push_back(part);
+        }
+    out.insert(out.end(), items.begin() + n_local, items.end());
+    return out;
+}
+
+// The item lists a session launches.  A launch of few rounds of work items loses 7-10 % of its workgroup-time to its tail
+// (WorkItem in pgsgd_tiles.hpp), so when the session's windows fill the device at least once but fewer than 24 times, every
+// window's tiles are cut into k parts: k = what brings a launch to 24 rounds, parts no shorter than four tiles, at most 16
+// (measured at config 4, 2 017 windows of 53 tiles on 1 024 workgroups: k = 1 / 2 / 4 / 8 / 12 / 16 / 24 / 32 / 64 ->
+// 0.557 / 0.563 / 0.567 / 0.588 / 0.596 / 0.593 / 0.581 / 0.564 / 0.487 of the roofline, workgroups alive 0.91 -> 0.98 of
+// the launch at k = 16; profiles/r04/NOTES.md).  A session that owns every shard_world-th window (region shard) cuts its
+// own windows; one that runs every tshard_world-th tile of every window counts its share of a part's tiles.  Called when
+// the session is created and when its shard changes.
+static int build_launch_items(pgsgd_session* s) {
+    if (s->d_items_split) { (void)hipFree(s->d_items_split); s->d_items_split = nullptr; }
+    if (s->d_item_done) { (void)hipFree(s->d_item_done); s->d_item_done = nullptr; }
+    s->h_items_split.clear();
+    s->tile_split = 1;
+    s->n_items_split[0] = s->n_items_split[1] = 0;
+    if (!s->items_one_run || s->h_items.empty()) return PGSGD_OK;
+    std::vector<pgsgd::WorkItem> own[2];
+    uint64_t n_local_min = ~0ull, tiles = 0, windows = 0;
+    for (int colour = 0; colour < 2; ++colour) {
+        const uint32_t base = colour ? s->n_items[0] : 0, windowless = colour == 0 ? s->n_windowless : 0, n_local = s->n_items[colour] - windowless;
+        for (uint32_t w = s->shard_rank; w < n_local; w += s->shard_world) {  // (the items a kernel with these shard arguments would take)
+            own[colour].push_back(s->h_items[base + w]);
+            tiles += s->h_items[base + w].tile_end - s->h_items[base + w].tile_begin;
+        }
+        if (!own[colour].empty()) n_local_min = std::min<uint64_t>(n_local_min, own[colour].size());
+        windows += own[colour].size();
+        own[colour].insert(own[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);  // every window-less item
+    }
+    uint32_t k = 1;
+    if (s->tile_split_knob) {
+        k = s->tile_split_knob;
+    } else if (windows && n_local_min != ~0ull && n_local_min >= s->tile_grid && s->tile_grid) {
+        const uint64_t for_rounds = (24ull * s->tile_grid + n_local_min - 1) / n_local_min;
+        const uint64_t by_length = tiles / windows / std::max<uint32_t>(1, s->tshard_world) / 4;
+        k = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, std::min(for_rounds, by_length)));
+    }
+    if (k <= 1) return PGSGD_OK;
+    std::vector<pgsgd::WorkItem> cut[2] = {split_items(own[0], s->n_windowless, k), split_items(own[1], 0, k)};
+    s->tile_split = k;
+    s->n_items_split[0] = (uint32_t)cut[0].size();
+    s->n_items_split[1] = (uint32_t)cut[1].size();
+    s->h_items_split = cut[0];
+    s->h_items_split.insert(s->h_items_split.end(), cut[1].begin(), cut[1].end());
+    const size_t n_flags = std::max<size_t>(1, std::max(cut[0].size(), cut[1].size()));
+    hipError_t e = hipSetDevice(s->device);
+    if (e == hipSuccess) e = hipMalloc(&s->d_items_split, s->h_items_split.size() * sizeof(pgsgd::WorkItem));
+    if (e == hipSuccess) e = hipMalloc(&s->d_item_done, n_flags * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(s->d_items_split, s->h_items_split.data(), s->h_items_split.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->d_item_done, 0, n_flags * sizeof(uint32_t));
+    if (e != hipSuccess) { set_error("work-item lists: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
+    return PGSGD_OK;
+}
+
 // Long-range step pairs for the initial-layout check of a tiled session: first step uniform over all steps,
 // partner uniform over the same path (the pairs the non-cooling phase draws half of the time), kept when they
 // are more than eight windows apart.  The tile kernel
@@ -764,6 +854,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_SNAP_EVERY")) s->tile_snap_every = (uint32_t)std::min(8, std::max(1, atoi(e)));
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
+        s->tile_tail = pgsgd::debug_env("PGSGD_TILE_TAIL") != nullptr;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
@@ -843,6 +934,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 std::vector<pgsgd::WorkItem> all(ht.items[0]);
                 all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
                 s->h_items = all;
+                if (const char* e = pgsgd::debug_env("PGSGD_TILE_SPLIT")) s->tile_split_knob = (uint32_t)std::min(256, std::max(1, atoi(e)));
+                s->items_one_run = !(order && !strcmp(order, "region"));
+                rc = build_launch_items(s);
+                if (rc) return fail(rc);
                 S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
                 S_TRY(hipMalloc(&s->d_items, std::max<size_t>(1, all.size()) * sizeof(pgsgd::WorkItem)));
                 S_TRY(hipMalloc(&s->d_queue, 3 * pgsgd::kItemQueues * sizeof(uint32_t)));
@@ -852,8 +947,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(uint64_t) << 14)));
                 S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
-                S_TRY(hipMalloc(&s->d_clock, 6 * sizeof(unsigned long long)));
-                S_TRY(hipMemset(s->d_clock, 0, 6 * sizeof(unsigned long long)));
+                S_TRY(hipMalloc(&s->d_clock, 10 * sizeof(unsigned long long)));  // [6..9]: TileArgs::tail_probe
+                S_TRY(hipMemset(s->d_clock, 0, 10 * sizeof(unsigned long long)));
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
@@ -995,6 +1090,8 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_delta_max) (void)hipFree(s->d_delta_max);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
     if (s->d_items) (void)hipFree(s->d_items);
+    if (s->d_items_split) (void)hipFree(s->d_items_split);
+    if (s->d_item_done) (void)hipFree(s->d_item_done);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_far) (void)hipFree(s->d_far);
     if (s->d_clock) (void)hipFree(s->d_clock);
@@ -1216,13 +1313,15 @@ extern "C" int64_t pgsgd_session_tile_lanes(const pgsgd_session* s, uint32_t* la
 extern "C" int64_t pgsgd_session_tile_items(const pgsgd_session* s, uint32_t* tile_begin, uint32_t* tile_end, uint32_t* win0, uint32_t* local,
                                             uint64_t capacity, uint64_t* n_first) {
     if (!s) return PGSGD_E_INVALID;
-    if (n_first) *n_first = s->n_items[0];
-    const uint64_t cnt = s->h_items.size();
+    const bool split = s->tile_split > 1 && s->shard_world == 1;  // the list the session launches
+    const std::vector<pgsgd::WorkItem>& items = split ? s->h_items_split : s->h_items;
+    if (n_first) *n_first = split ? s->n_items_split[0] : s->n_items[0];
+    const uint64_t cnt = items.size();
     for (uint64_t i = 0; i < cnt && i < capacity; ++i) {
-        if (tile_begin) tile_begin[i] = s->h_items[i].tile_begin;
-        if (tile_end) tile_end[i] = s->h_items[i].tile_end;
-        if (win0) win0[i] = s->h_items[i].win0;
-        if (local) local[i] = s->h_items[i].local;
+        if (tile_begin) tile_begin[i] = items[i].tile_begin;
+        if (tile_end) tile_end[i] = items[i].tile_end;
+        if (win0) win0[i] = items[i].win0;
+        if (local) local[i] = items[i].local & pgsgd::kItemLocal;
     }
     return (int64_t)cnt;
 }
@@ -1279,6 +1378,11 @@ extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t
     s->tshard_world = by_region ? 1 : world;
     s->exact_colours = by_region == 2;
     s->tile_seed_base = world > 1 ? s->params.seed : s->params.seed + (uint64_t)s->params.stream_offset;
+    if (s->tiled) {
+        HIP_TRY(hipStreamSynchronize(s->stream));  // (no launch still reads the lists that are replaced)
+        const int rc = build_launch_items(s);
+        if (rc) return rc;
+    }
     return s->tiled ? (by_region == 2 ? 3 : by_region ? 2 : 1) : 0;
 }
 
@@ -1287,10 +1391,17 @@ extern "C" int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles
     if (!s) return PGSGD_E_INVALID;
     if (n_tiles) *n_tiles = s->tiled ? s->n_tiles : 0;
     if (n_nonlocal_tiles) *n_nonlocal_tiles = s->n_nonlocal_tiles;
-    if (n_work_items) *n_work_items = (uint64_t)s->n_items[0] + s->n_items[1];
+    if (n_work_items) *n_work_items = (uint64_t)s->n_items[0] + s->n_items[1];  // (windows and window-less tiles; pgsgd_session_tile_parts: the items launched)
     if (region_nodes) *region_nodes = s->region;
     if (tile_steps) *tile_steps = s->tile_steps;
     return s->tiled ? (s->warm_per_lane ? 2 : 1) : 0;
+}
+
+// Parts a window's tiles are cut into (1: whole windows) and the work items the session's two launches take together.
+extern "C" int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_launch_items) {
+    if (!s) return PGSGD_E_INVALID;
+    if (n_launch_items) *n_launch_items = s->tile_split > 1 ? (uint64_t)s->n_items_split[0] + s->n_items_split[1] : (uint64_t)s->n_items[0] + s->n_items[1];
+    return s->tiled ? (int)s->tile_split : 0;
 }
 
 extern "C" int pgsgd_session_tile_math(const pgsgd_session* s) {
@@ -1526,16 +1637,20 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const uint32_t launches = s->far_launches[colour]++;
             pgsgd::TileArgs ta;
             ta.tiles = s->d_tiles;
-            ta.items = s->d_items + (colour ? s->n_items[0] : 0);
+            const bool split = s->tile_split > 1;  // the session's own windows, in parts (build_launch_items)
+            const uint32_t* n_items_now = split ? s->n_items_split : s->n_items;
+            ta.items = (split ? s->d_items_split : s->d_items) + (colour ? n_items_now[0] : 0);
             ta.queue = s->d_queue + colour * pgsgd::kItemQueues;
             memcpy(ta.chunk, s->item_chunk[colour], sizeof ta.chunk);
+            ta.item_done = s->d_item_done;
+            ta.stamp = ++s->launch_stamp;
             ta.region = s->region;
             ta.tile_steps = s->tile_steps;
             ta.term0 = s->d_term0;
             ta.sub = sub;
             ta.n_sub = n_sub;
-            ta.shard_rank = s->shard_rank;
-            ta.shard_world = s->shard_world;
+            ta.shard_rank = split ? 0 : s->shard_rank;   // (a split list holds this session's windows only)
+            ta.shard_world = split ? 1 : s->shard_world;
             // the far-pull count of this colour's previous launch stays on the device: no host round trip
             const bool no_cap = (s->params.flags & PGSGD_FLAG_NO_FAR_CAP) != 0;
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
@@ -1551,6 +1666,12 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.lock_mu = s->tile_lock_mu;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;
+            ta.tail_probe = nullptr;
+            if (s->tile_tail && s->d_clock) {  // (debug only: two more memsets per launch)
+                ta.tail_probe = s->d_clock + 6;
+                HIP_TRY(hipMemsetAsync(s->d_clock + 6, 0, 4 * sizeof(unsigned long long), s->stream));
+                HIP_TRY(hipMemsetAsync(s->d_clock + 8, 0xff, sizeof(unsigned long long), s->stream));
+            }
             ta.ob = s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;
@@ -1560,7 +1681,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ts.one_plus_half_pow = s->dc.zc.one_plus_half_pow;
             // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own
             const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
-            ta.n_items = s->n_items[colour] - windowless;
+            ta.n_items = n_items_now[colour] - windowless;
+            if (split)
+                for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) ta.chunk[q] = ta.n_items;  // one run
             // The far pulls the launch before this one collected are delivered now, right before the windows are staged:
             // an iteration ends with a launch's window-local terms, not with the arrival of a launch's worth of far
             // pulls (each an average of a dozen long-range pulls — noise at the scale of neighbouring nodes until the
@@ -1594,6 +1717,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             if (windowless) {
                 pgsgd::TileArgs tw = ta;
+                tw.shard_rank = s->shard_rank;
+                tw.shard_world = s->shard_world;
                 tw.clock_probe = nullptr;
                 tw.items = ta.items + ta.n_items;
                 tw.n_items = windowless;
@@ -1784,6 +1909,29 @@ extern "C" int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, 
     HIP_TRY(hipMemcpy(v, s->d_clock, sizeof v, hipMemcpyDeviceToHost));
     if (locked) *locked = v[4];
     if (lost) *lost = v[5];
+    return PGSGD_OK;
+}
+
+// Debug knob PGSGD_TILE_TAIL: of the last windowed tile launch, the share of (workgroups x launch duration) that the
+// workgroups were alive for — a persistent workgroup lives until the launch has no work item left for it, so what is
+// missing is the launch's tail: slots idle while the last items finish.  0 when the knob is off.
+extern "C" int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction, double* launch_ms, uint32_t* workgroups) {
+    pgsgd::clear_error();
+    if (!s) return PGSGD_E_INVALID;
+    if (alive_fraction) *alive_fraction = 0.0;
+    if (launch_ms) *launch_ms = 0.0;
+    if (workgroups) *workgroups = 0;
+    if (!s->d_clock || !s->tile_tail) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(v, s->d_clock + 6, sizeof v, hipMemcpyDeviceToHost));
+    if (v[3] && v[1] > v[2]) {
+        const double span = (double)(v[1] - v[2]);  // 100 MHz ticks from the first start to the last finish
+        if (alive_fraction) *alive_fraction = (double)v[0] / (span * (double)v[3]);
+        if (launch_ms) *launch_ms = span / 1e5;
+        if (workgroups) *workgroups = (uint32_t)v[3];
+    }
     return PGSGD_OK;
 }
 

@@ -46,8 +46,19 @@ struct Tile {
 struct WorkItem {
     uint32_t tile_begin, tile_end;
     uint32_t win0;   // first node rank of the window
-    uint32_t local;  // 1 = window staged in LDS, 0 = every end in global memory
+    uint32_t local;  // bit 0: 1 = window staged in LDS, 0 = every end in global memory; the other bits: a window's tiles cut into
+                     // several items of one launch (kItemHasNext, kItemDepShift)
 };
+// A launch of a few rounds of work items ends with a tail: slots idle while the last items finish (7-10 % of the
+// workgroup-time at config 4, two rounds of ~1.9-ms items: tools/gpu_tile_tail.py).  A session whose launches have few
+// rounds therefore cuts every window's tiles into k consecutive parts, each an item of its own: part j of every window
+// sits in the queue behind part j - 1 of every window and starts when its predecessor has written the window back — the
+// same tiles in the same order on the same window, in items a k-th as long.  The predecessor was taken from the queue
+// earlier, so it is running or done when its successor is taken: the wait cannot deadlock (and gives up with a trap
+// after ~1 s instead of hanging the device, should that reasoning ever fail).
+constexpr uint32_t kItemLocal = 1u;
+constexpr uint32_t kItemHasNext = 2u;   // another item of this launch waits for this one: write the window through and raise its flag
+constexpr uint32_t kItemDepShift = 2;   // bits 31..2: 1 + index (in the launch's item list) of the item this one waits for; 0: none
 
 // The far-update outbox.  Messages are grouped by bucket = end >> shift and packed into 8 bytes: the end's offset
 // inside its bucket (shift bits) and the two coordinate steps as signed qbits-bit quanta (25 bits each with the
@@ -152,6 +163,9 @@ struct TileArgs {
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
     unsigned long long* clock_probe;   // [6] {shader cycles, 100 MHz ticks} when workgroup 0 starts and ends: the launch's achieved shader clock; [4], [5]: terms
                                        // that went for their ends' locks, and that lost one (cumulative)
+    uint32_t* item_done;               // [items of the launch] launch stamp of the last launch that finished the item (items cut into parts, WorkItem::local)
+    uint32_t stamp;                    // this launch's
+    unsigned long long* tail_probe;    // debug knob PGSGD_TILE_TAIL: [4] {sum of the workgroups' lifetimes, last finish, first start, workgroups} in 100 MHz ticks; null: off
     uint32_t pair_uniform;             // 1: the lanes of a wave share uniform partners in pairs (tile_pair_partner); 0: PGSGD_FLAG_NO_PARTNER_PAIRS
     float lock_mu;                     // conflict resolution inside a window: terms whose learning rate mu reaches this take both their ends' locks or do nothing (0: off)
     uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
@@ -670,6 +684,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         probe[0] = __builtin_readcyclecounter();   // s_memtime: shader cycles
         probe[1] = wall_clock64();                 // s_memrealtime: constant 100 MHz
     }
+    const uint64_t wg_start = TILE_COLD(ta.tail_probe) ? wall_clock64() : 0;  // (debug: how much of a launch its workgroups are alive, pgsgd_session_tile_tail)
     // this wave's message queue; its fill count is wave-uniform and lives in a scalar register
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQueue wq;
@@ -716,6 +731,19 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 if (cand < hi) {
                     it = cand;
                     break;
+                }
+            }
+            if (LOCAL && it != kNoItem) {  // a later part of a window waits until the part before it has written the window back
+                const uint32_t dep = TILE_COLD(ta.items)[it].local >> kItemDepShift;
+                if (dep) {
+                    const uint32_t* flag = TILE_COLD(ta.item_done) + (dep - 1u);
+                    const uint32_t stamp = TILE_COLD(ta.stamp);
+                    const uint64_t t_wait = wall_clock64();
+                    // (relaxed: an acquire at agent scope invalidates the XCD's L2 on every poll, and the words that follow are read with agent-scope loads anyway)
+                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (wall_clock64() - t_wait > 100000000ull) __builtin_trap();  // 1 s of 100 MHz ticks: never seen; a dead launch, not a hung device
+                    }
                 }
             }
             s_item = it;
@@ -978,13 +1006,22 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         while (wq_n) wq_push(ta.ob, L, wq, wq_n);
         __syncthreads();
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
+            const bool has_next = (wi.local & kItemHasNext) != 0;  // ... unless the window's next part may be staged by another workgroup in this launch
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
                 if ((uint64_t)wbase + i < n_ends) {
-                    TILE_COLD(c.coords)[wbase + i] = win[i];
+                    if (has_next) __hip_atomic_store(TILE_COLD(c.coords) + wbase + i, win[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (staging reads with agent-scope loads: load_word)
+                    else TILE_COLD(c.coords)[wbase + i] = win[i];
                     guard |= in_frame_guard(win[i]);
                 }
+            // every thread's words are out before the flag goes up: the write-through stores have completed when the counter is
+            // back at zero (a release fence at agent scope would also write back the XCD's whole L2: measured, 200 us per item)
+            if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the hot rings move on with the window: write out what they hold and unbind them
             outbox_flush_rings(ta.ob, L, L.n_buckets, kObRings);
+            if (has_next) {
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(TILE_COLD(ta.item_done) + item, TILE_COLD(ta.stamp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();  // s_item and the window are reused
     }
@@ -1006,6 +1043,14 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     if (blockIdx.x == 0 && threadIdx.x == 0 && probe) {
         probe[2] = __builtin_readcyclecounter();
         probe[3] = wall_clock64();
+    }
+    if (threadIdx.x == 0 && TILE_COLD(ta.tail_probe)) {
+        unsigned long long* tail = TILE_COLD(ta.tail_probe);
+        const uint64_t now = wall_clock64();
+        atomicAdd(tail, (unsigned long long)(now - wg_start));
+        atomicMax(tail + 1, (unsigned long long)now);
+        atomicMin(tail + 2, (unsigned long long)wg_start);
+        atomicAdd(tail + 3, 1ull);
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
     if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(TILE_COLD(ta.far_count), (unsigned long long)n_far);

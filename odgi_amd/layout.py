@@ -188,13 +188,16 @@ class LayoutSession:
         return w
 
     def tile_info(self):
-        """dict(tiled, warm_per_lane, n_tiles, n_nonlocal_tiles, n_work_items, region_nodes, tile_steps) of the session
+        """dict(tiled, warm_per_lane, n_tiles, n_nonlocal_tiles, n_work_items, region_nodes, tile_steps, fast_math, parts,
+        n_launch_items) of the session (parts: consecutive work items a window's tiles are cut into, pgsgd_session_tile_parts)
         (tiled=False: per-lane kernel; warm_per_lane, known after upload(): the initial layout had no global
         structure, so the iterations before cooling run the per-lane kernel)."""
         a, b, c_, r, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
         on = lib.pgsgd_session_tile_info(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(r), C.byref(t))
+        n_launch = C.c_uint64()
+        parts = lib.pgsgd_session_tile_parts(self._h, C.byref(n_launch))
         return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value,
-                    fast_math=lib.pgsgd_session_tile_math(self._h) == 1)
+                    fast_math=lib.pgsgd_session_tile_math(self._h) == 1, parts=max(0, parts), n_launch_items=n_launch.value)
 
     def split_info(self):
         """dict(split, apply_lanes): whether per-lane iterations run in two passes (a small lane-bound graph: n_streams
@@ -287,6 +290,13 @@ class LayoutSession:
         mhz, ms = C.c_double(), C.c_double()
         check(lib.pgsgd_session_shader_clock(self._h, C.byref(mhz), C.byref(ms)), "shader_clock")
         return mhz.value, ms.value
+
+    def tile_tail(self):
+        """(alive, ms, workgroups): with PGSGD_DEBUG=1 PGSGD_TILE_TAIL=1, the share of workgroups x duration of the last
+        windowed tile launch that its workgroups were alive for (the rest is the launch's tail), its duration, its grid."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        check(lib.pgsgd_session_tile_tail(self._h, C.byref(a), C.byref(b), C.byref(n)), "tile_tail")
+        return a.value, b.value, n.value
 
     def tile_conflicts(self):
         """(locked, lost): tile-kernel terms that went for their window ends' locks so far, and those that lost one."""

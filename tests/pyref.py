@@ -150,13 +150,14 @@ def decode_og(path):
     return dict(header=header, node_len=[len(n[1]) for n in nodes], node_seq=[n[1] for n in nodes], edges=edges, paths=paths)
 
 
-def build_tiles_py(path_first, step_handle, R, T, order="size"):
+def build_tiles_py(path_first, step_handle, R, T, order="size", split=1):
     """Independent restatement of the tile table of the region-exclusive tile kernel: paths cut
     into tiles of T steps (single-step paths have none); a tile whose node ranks fit the window
     [r0*R, (r0+2)*R), r0 = rmin // R, joins work item r0; the launch of the even regions takes its items in
     order of decreasing step count, ties: smaller region first (order="region": in node order, the product's
     experiment PGSGD_TILE_ORDER=region), then every
-    window-less tile as an item of its own; the launch of the odd regions follows.  Returns (tiles dict, items dict) shaped like
+    window-less tile as an item of its own; the launch of the odd regions follows.  split=k: the product's PGSGD_TILE_SPLIT
+    (every window's tiles as k consecutive items).  Returns (tiles dict, items dict) shaped like
     LayoutSession.tile_table() / tile_items()."""
     import numpy as np
     pf = np.asarray(path_first, dtype=np.int64)
@@ -203,6 +204,25 @@ def build_tiles_py(path_first, step_handle, R, T, order="size"):
             n_first = len(items["local"])
     tiles = {k: np.array(v, dtype=np.uint64 if k in ("t0", "cum") else np.uint32) for k, v in tiles.items()}
     tiles["steps_total"] = total
+    if split > 1:   # every window's tiles in `split` consecutive parts: part 0 of every window of a colour, then part 1, ... (split_items)
+        cut = dict(tile_begin=[], tile_end=[], win0=[], local=[])
+        bounds = ((0, n_first), (n_first, len(items["local"])))
+        for lo, hi in bounds:
+            idx = [i for i in range(lo, hi) if items["local"][i]]
+            for j in range(split):
+                for i in idx:
+                    tb, te = items["tile_begin"][i], items["tile_end"][i]
+                    parts = min(split, max(1, te - tb))
+                    if j < parts:
+                        cut["tile_begin"].append(tb + (te - tb) * j // parts); cut["tile_end"].append(tb + (te - tb) * (j + 1) // parts)
+                        cut["win0"].append(items["win0"][i]); cut["local"].append(1)
+            for i in range(lo, hi):
+                if not items["local"][i]:
+                    for k in cut:
+                        cut[k].append(items[k][i])
+            if lo == 0:
+                n_first = len(cut["local"])
+        items = cut
     items = {k: np.array(v, dtype=np.uint32) for k, v in items.items()}
     items["n_first"] = n_first
     return tiles, items

@@ -1337,7 +1337,7 @@ def _ragged_graph(oa):
     return oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
 
 
-@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages"])
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages", "synthetic-split", "DRB1-3123-split"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
@@ -1345,7 +1345,13 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     no quantum, the flush.  `synthetic` is a sorted graph (every tile has a window), DRB1-3123 has stretches
     whose tiles do not fit a window (every end in global memory).  `synthetic-narrow-messages` packs the steps of an
     outbox message into 6 bits each: most far updates are then too wide for a message and take the spill words, which
-    the drain adds with the messages — the same sums."""
+    the drain adds with the messages — the same sums.  `-split`: every window's tiles as three consecutive work items, a later one
+    waiting for the one before it (what sessions with launches of few rounds do, WorkItem in pgsgd_tiles.hpp); the mirror follows
+    the same item list."""
+    split = 1
+    if graph_name.endswith("-split"):
+        monkeypatch.setenv("PGSGD_TILE_SPLIT", "3")
+        graph_name, split = graph_name[:-6], 3
     if graph_name == "synthetic-narrow-messages":
         monkeypatch.setenv("PGSGD_OUTBOX_QBITS", "6")
         graph_name = "synthetic"
@@ -1366,10 +1372,11 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
         assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64 and not info["fast_math"]
         assert (info["n_nonlocal_tiles"] == 0) == (graph_name != "DRB1-3123")
-        assert len(items["local"]) == info["n_work_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
+        assert len(items["local"]) == info["n_launch_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
+        assert info["parts"] == split and (len(items["local"]) > info["n_work_items"]) == (split > 1)
         # the product's tile table and work items are exactly the independent restatement's (tests/pyref.py)
         import pyref
-        tiles_py, items_py = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56)
+        tiles_py, items_py = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56, split=split)
         for k in ("t0", "cum", "n", "path"):
             assert np.array_equal(tiles[k], tiles_py[k]), k
         assert np.all(tiles["lanes"] == 1)                       # PGSGD_TILE_LANES=1: one term stream per tile

@@ -296,6 +296,37 @@ static double time_ms(F launch, int reps = 3) {
     return best;
 }
 
+// MICROBENCH_LOCAL=1: does the random-request ceiling (~50 G/s) depend on where a wave's 64 requests go?  Every wave-iteration
+// picks one aligned block of `block_bytes` at random (wave-uniform) and every lane one 64-byte sector in it (DISTINCT sectors
+// when the block has exactly 64: a 4-KiB block is then read whole).
+__global__ void cal_gather_wave_local(const uint4* buf, uint64_t bytes, uint64_t block_bytes, uint64_t iters, uint32_t* sink) {
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t sw = 0xD1342543DE82EF95ull * (wave + 1);                                              // the wave's stream (same in all its lanes)
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);   // the lane's
+    const uint64_t n_blocks = bytes / block_bytes, sectors = block_bytes / 64;
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t rw = xs(sw), b = __umul64hi(rw, n_blocks);
+        const uint64_t sec = sectors == 64 ? ((threadIdx.x ^ rw) & 63u) : __umul64hi(xs(s), sectors);
+        acc += buf[(b * block_bytes + sec * 64) / 16].x;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+// groups of G lanes share one random aligned run of G 32-byte records (G = 2: a 64-byte sector, the tile kernel's partner pairs; G = 4: a
+// 128-byte line); every lane reads 16 + 8 bytes of its own record
+template <int G>
+__global__ void cal_gather_group(const uint4* buf, uint64_t n32, uint64_t iters, uint32_t* sink) {
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t s = 0x9E3779B97F4A7C15ull * (lane / G + 1);   // the group's stream
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s), k = __umul64hi(r, n32 / G) * G + lane % G;
+        const uint4 a = buf[2 * k];
+        const unsigned long long w = reinterpret_cast<const unsigned long long*>(buf)[4 * k + 2 + (r & 1)];
+        acc += a.x ^ (uint32_t)w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
 int main() {
     const int grid = 256 * 8, block = 256;
     const uint64_t lanes = (uint64_t)grid * block;
@@ -303,6 +334,45 @@ int main() {
     const size_t big = 1ull << 30;  // 1 GiB
     uint4* g; CK(hipMalloc(&g, big)); CK(hipMemset(g, 1, big));
     printf("{\"lanes\": %llu}\n", (unsigned long long)lanes);
+    if (getenv("MICROBENCH_LOCAL")) {
+        (void)hipFree(g);
+        const size_t big2 = 1536ull << 20;
+        CK(hipMalloc(&g, big2)); CK(hipMemset(g, 1, big2));
+        const uint64_t iters = 128;
+        const double req = (double)lanes * iters;
+        hipLaunchKernelGGL(cal_stream_read, dim3(4096), dim3(256), 0, 0, g, big2 / 16, sink);   // first touch
+        for (int rep = 0; rep < 2; ++rep)
+            for (unsigned long long bb : {4096ull, 16384ull, 65536ull, 1ull << 20, 16ull << 20, (unsigned long long)big2}) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+                hipDeviceSynchronize();
+                hipEventRecord(a);
+                hipLaunchKernelGGL(cal_gather_wave_local, dim3(grid), dim3(block), 0, 0, g, (uint64_t)big2, bb, iters, sink);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                printf("{\"local\": \"wave's 64 gathers inside one random block\", \"block_bytes\": %llu, \"lane_gathers\": %.0f, \"ms\": %.4f, \"G_lane_gathers_per_s\": %.2f}\n",
+                       (unsigned long long)bb, req, ms, req / ms / 1e6);
+                hipEventDestroy(a); hipEventDestroy(b);
+            }
+        auto group = [&](int G, auto kernel) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, 0, g, (uint64_t)big2 / 32, iters, sink);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("{\"local\": \"groups of G lanes share G consecutive 32-byte records\", \"G\": %d, \"lane_gathers\": %.0f, \"ms\": %.4f, \"G_lane_gathers_per_s\": %.2f, \"G_groups_per_s\": %.2f}\n",
+                   G, req, ms, req / ms / 1e6, req / G / ms / 1e6);
+            hipEventDestroy(a); hipEventDestroy(b);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            group(1, cal_gather_group<1>);
+            group(2, cal_gather_group<2>);
+            group(4, cal_gather_group<4>);
+            group(8, cal_gather_group<8>);
+            group(16, cal_gather_group<16>);
+        }
+        return 0;
+    }
     if (getenv("MICROBENCH_CAL")) {
         (void)hipFree(g);
         const size_t big2 = 3ull << 30;
