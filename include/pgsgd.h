@@ -276,10 +276,9 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
  * shrinks with the items).  Returns k (1: whole windows; 0: per-lane kernel); *n_launch_items: items of the two launches.
  * pgsgd_session_tile_items lists them in launch order for an unsharded session. */
 int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_launch_items);
-/* Region size (nodes) a tiled session takes for a graph of n_nodes nodes when a launch has resident_workgroups workgroups
- * on the device (MI355X: 256 CUs x 4): the multiple of 8 in [240, 272] whose work items (one per region of a colour) fill
- * their rounds best, 256 when a launch is a single round or more than three.  Pure host arithmetic. */
-uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups);
+/* The rule behind it, pure host arithmetic: 1 when the `windows` of a launch do not fill the resident workgroups once;
+ * otherwise what brings the launch to 24 rounds of work items, parts of at least four tiles, at most 16 per window. */
+uint32_t pgsgd_tile_parts_for(uint64_t windows, uint64_t tiles_per_window, uint64_t resident_workgroups);
 /* Two rules of the tile kernel's sampler, restated on the host for tests: the Zipf/uniform coin (path_sgd_layout.cpp:205)
  * that the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration (a SplitMix64 stream per
  * wave, seeded like a lane's generator with lane id 1023 - wave), and the partner (rank in its path) an odd lane takes in

@@ -100,6 +100,7 @@ SIGNATURES = [
     ("pgsgd_session_shader_clock", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_tile_tail", C.c_int, [C.c_void_p, P(f64), P(f64), P(C.c_uint32)]),
     ("pgsgd_session_tile_parts", C.c_int, [C.c_void_p, P(C.c_uint64)]),
+    ("pgsgd_tile_parts_for", u32, [u64, u64, u64]),
     ("pgsgd_session_tile_conflicts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
@@ -119,7 +120,6 @@ SIGNATURES = [
     ("pgsgd_session_tile_math", C.c_int, [C.c_void_p]),
     ("pgsgd_debug_tile_displacement", C.c_int, [C.c_int, u64, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]),
     ("pgsgd_graph_path_order", C.c_int, [P(GraphView), P(u32), P(f64), P(f64)]),
-    ("pgsgd_tile_region_for", u32, [u64, u64]),
     ("pgsgd_tile_wave_coin", C.c_int, [u64, u64, u64, u32, u64]),
     ("pgsgd_tile_pair_partner", u32, [u32, u32, u32, u32]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),

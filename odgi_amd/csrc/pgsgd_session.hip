@@ -291,16 +291,6 @@ static iter_kernel_t session_kernel(const pgsgd_session* s, bool plain, uint32_t
     return select_kernel(s->pf_lds, plain, s->fmt, s->upd, grouped, abl);
 }
 
-// Region size of a tiled session: the multiple of 8 in [240, 272] (near the validated 256: lanes per window end within
-// 7 %) for which the work items of a launch (one per region of a colour: ceil(regions / 2)) fill their rounds over
-// `slots` resident workgroups best; 256 when one round or more than three are needed either way.  (Measured with and without
-// the rule, tile kernel's roofline fraction: 1e6 nodes, two rounds: 0.493 against 0.488; 1.5e6, three: 0.543 / 0.535; 6e5, barely two:
-// 0.395 / 0.397; 2e6, four: 0.529 / 0.530; 3e6, six: 0.527 / 0.534 — a launch of many rounds balances itself, items being handed
-// out by decreasing size: profiles/r04/NOTES.md.)
-static uint32_t choose_region(uint64_t n_nodes, uint64_t slots);
-extern "C" uint32_t pgsgd_tile_region_for(uint64_t n_nodes, uint64_t resident_workgroups) {
-    return n_nodes && resident_workgroups ? choose_region(n_nodes, resident_workgroups) : 256;
-}
 // Host-side copies of two rules of the tile kernel's sampler, for the CPU suite (the kernel, the trace kernel and the
 // oracle's mirror are compared on the GPU): the Zipf/uniform coin a wave's lanes share in a trip of a warm iteration, and
 // the partner an odd lane takes from its even neighbour's in a uniform trip.
@@ -312,24 +302,6 @@ extern "C" int pgsgd_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t
 extern "C" uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank) {
     return pgsgd::tile_pair_partner(lead_flat_step, path_first_step, path_steps, own_rank);
 }
-static uint32_t choose_region(uint64_t n_nodes, uint64_t slots) {
-    auto items_of = [&](uint64_t r) { return ((n_nodes + r - 1) / r + 1) / 2; };
-    const uint64_t rounds256 = (items_of(256) + slots - 1) / slots;
-    if (rounds256 < 2 || rounds256 > 3) return 256;
-    uint32_t best = 256;
-    double best_fill = (double)items_of(256) / (double)(rounds256 * slots);
-    for (uint32_t r = 240; r <= 272; r += 8) {
-        const uint64_t items = items_of(r), rounds = (items + slots - 1) / slots;
-        const double fill = (double)items / (double)(rounds * slots);
-        const bool nearer = (r > 256 ? r - 256 : 256 - r) < (best > 256 ? best - 256 : 256 - best);
-        if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && nearer)) {
-            best = r;
-            best_fill = fill;
-        }
-    }
-    return best;
-}
-
 // Host side of the tiled kernel: cut paths into tiles, bind tiles to region windows, order the work.
 struct HostTiles {
     std::vector<pgsgd::Tile> tiles;
@@ -492,6 +464,15 @@ static HostTiles group_tiles(const std::vector<RawTile>& raw, uint64_t n_nodes, 
     return ht;
 }
 
+// The rule of build_launch_items as host arithmetic (tests): parts a window's tiles are cut into when a launch has
+// `windows` windows (the fewer of the two colours') of `tiles_per_window` tiles on average for `resident_workgroups` slots.
+extern "C" uint32_t pgsgd_tile_parts_for(uint64_t windows, uint64_t tiles_per_window, uint64_t resident_workgroups) {
+    if (!windows || !resident_workgroups || windows < resident_workgroups) return 1;  // the device is not filled once: nothing to balance
+    const uint64_t for_rounds = (24 * resident_workgroups + windows - 1) / windows;   // 24 rounds of work items per launch ...
+    const uint64_t by_length = tiles_per_window / 4;                                  // ... of no fewer than four tiles each ...
+    return (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, std::min(for_rounds, by_length)));  // ... and at most 16 per window
+}
+
 // One colour's work items with every window's tiles cut into k consecutive parts (see WorkItem): part 0 of every window in the
 // given order, then part 1 of every window, ...; a part waits for the part before it of the same window.  A window with
 // fewer than k tiles has fewer parts.  The window-less items (the last n_windowless) follow unchanged.
@@ -547,13 +528,8 @@ static int build_launch_items(pgsgd_session* s) {
         own[colour].insert(own[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);  // every window-less item
     }
     uint32_t k = 1;
-    if (s->tile_split_knob) {
-        k = s->tile_split_knob;
-    } else if (windows && n_local_min != ~0ull && n_local_min >= s->tile_grid && s->tile_grid) {
-        const uint64_t for_rounds = (24ull * s->tile_grid + n_local_min - 1) / n_local_min;
-        const uint64_t by_length = tiles / windows / std::max<uint32_t>(1, s->tshard_world) / 4;
-        k = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, std::min(for_rounds, by_length)));
-    }
+    if (s->tile_split_knob) k = s->tile_split_knob;
+    else if (windows && n_local_min != ~0ull) k = pgsgd_tile_parts_for(n_local_min, tiles / windows / std::max<uint32_t>(1, s->tshard_world), s->tile_grid);
     if (k <= 1) return PGSGD_OK;
     std::vector<pgsgd::WorkItem> cut[2] = {split_items(own[0], s->n_windowless, k), split_items(own[1], 0, k)};
     s->tile_split = k;
@@ -703,14 +679,22 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // (Round 3 measured coarser buckets at config 4 — 123 or 62 instead of 245, 26 / 21 KB of LDS per tile workgroup
         // instead of 36, five workgroups per CU instead of four: the warm iterations get 9 % SLOWER with the fifth
         // workgroup, the cooling ones 3 % faster, the drain 30-100 % slower; profiles/r03/bench_variants_call1.txt.)
+        // Round 4, with the launch's tail gone (a window's tiles as several work items): at most 128 buckets — 30 KB of LDS per
+        // tile workgroup, FIVE per CU — wherever the drain then reads a bucket at most twice (graphs up to 2.1e6 nodes; two
+        // drain workgroups per bucket, since 123 would leave half the CUs idle).  Config 4, 245 buckets and four per CU against
+        // 123 and five: tile kernel 0.596 -> 0.636 of the roofline, drain 0.49 -> 0.58 ms per iteration, everything 0.554 ->
+        // 0.581; six per CU (62 buckets): 0.630 and a drain of 0.89 ms (profiles/r04/bench_probes_late.txt).
         uint32_t ob_shift = 13;
-        if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_SHIFT")) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(e)));  // experiment knob
-        while (((2 * g->n_nodes - 1) >> ob_shift) + 1 > 256) ++ob_shift;
+        const char* shift_knob = pgsgd::debug_env("PGSGD_OUTBOX_SHIFT");
+        if (shift_knob) ob_shift = (uint32_t)std::min(20, std::max(10, atoi(shift_knob)));  // experiment knob
+        auto buckets_at = [&](uint32_t sh) { return ((2 * g->n_nodes - 1) >> sh) + 1; };
+        while (buckets_at(ob_shift) > 256) ++ob_shift;
+        if (!shift_knob && buckets_at(ob_shift) > 128 && ob_shift < 15) ++ob_shift;
         s->ob.shift = ob_shift;
         s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
         if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_QBITS"))  // test knob: narrow packed steps, so that most messages take the path of a step too wide for the packed form
             s->ob.qbits = (uint32_t)std::min<int>((int)s->ob.qbits, std::max(2, atoi(e)));
-        s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
+        s->ob_part_shift = std::min<uint32_t>(buckets_at(ob_shift) <= 128 && ob_shift > 10 ? ob_shift - 1 : ob_shift, 14);
         if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_PART_SHIFT")) s->ob_part_shift = (uint32_t)std::min<int>((int)ob_shift, std::max(10, atoi(e)));  // experiment knob
         s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
         s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
@@ -819,29 +803,11 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // was validated at); between that and full residency the grid is cut to the hot-node cap
         const uint64_t cu_lanes = (uint64_t)prop.multiProcessorCount * s->tile_block;
         if (steps_given >= 16 && steps_given <= (long)s->region && region_given) s->tile_steps = (uint32_t)steps_given;
-        if (!region_given) {
-            // A launch's work items are handed to the resident workgroups in rounds, and a launch of a few rounds lasts
-            // a whole number of them: at config 4 (1e6 nodes, 1024 workgroups) R = 256 makes 1 953 items per colour
-            // — two rounds, the second 91 % full — R = 248 makes 2 017, R = 240 makes 2 084: a third round for 36
-            // items (measured, tile kernel's roofline fraction: 0.488 / 0.493 / 0.420;
-            // profiles/r03/bench_variants_call25_region.txt).  So R is the multiple of 8 in [240, 272] that fills the
-            // rounds best; graphs of a single round or of more than three keep 256.
-            const uint64_t slots = (uint64_t)prop.multiProcessorCount * std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)bpc, std::max<uint64_t>(1, cap / cu_lanes)));
-            const uint32_t r = choose_region(g->n_nodes, slots);
-            if (r != s->region) {
-                s->region = r;
-                s->tile_steps = r - r / 8;
-                s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
-                int bpc_r = 0;
-                S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc_r, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
-                if (bpc_r < bpc) {  // (cannot happen at 272 nodes per region with the default bucket count; keep the validated size if it does)
-                    s->region = 256;
-                    s->tile_steps = 224;
-                    s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
-                }
-            }
-            if (steps_given >= 16 && steps_given <= (long)s->region) s->tile_steps = (uint32_t)steps_given;
-        }
+        // (Rounds 3-4 fitted R to the launch — the multiple of 8 in [240, 272] whose work items filled their two or three rounds
+        // over the resident workgroups best, R = 248 at config 4 — which a window's tiles as several work items made
+        // pointless: build_launch_items.  Measured with those, five workgroups per CU: R = 248 / 256 / 264 / 272 / 288 ->
+        // 0.636 / 0.634 / 0.623 / 0.618 / 0.600.)
+        if (!region_given && steps_given >= 16 && steps_given <= (long)s->region) s->tile_steps = (uint32_t)steps_given;
         s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
         // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one

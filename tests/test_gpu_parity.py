@@ -560,12 +560,14 @@ def test_synthetic_million_node_properties(oa, orc):
     with oa.LayoutSession(g, p2) as s:
         got = s.trace_terms(True, 4)
     assert np.array_equal(got, orc.trace_terms(og, orc.params_from(p2), p2.seed, 256, 0, True, 4))
-    # the default schedule runs the tile kernel, every tile with a window, and the region size is fitted to the launch: on
-    # MI355X (256 CUs x 4 workgroups) R = 248 makes 2017 / 2016 work items per colour — two full rounds (R = 256: 1953)
+    # the default schedule runs the tile kernel, every tile with a window; 1954 / 1953 windows per colour would be a launch of
+    # a round and a half over MI355X's 256 CUs x 5 workgroups, so every window's ~53 tiles run as 13 consecutive work items
     with oa.LayoutSession(g, _params(oa, g)) as s:
         info = s.tile_info()
+        assert s.n_streams == 256 * 5 * 256          # five workgroups per CU: 123 outbox buckets, 30 KB of LDS
     assert info["tiled"] and not info["warm_per_lane"] and info["n_nonlocal_tiles"] == 0
-    assert (info["region_nodes"], info["tile_steps"], info["n_work_items"]) == (248, 217, 4033), info
+    assert (info["region_nodes"], info["tile_steps"], info["n_work_items"], info["parts"]) == (256, 224, 3907, 13), info
+    assert 12 * 3907 < info["n_launch_items"] <= 13 * 3907
 
 
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds

@@ -482,23 +482,17 @@ def test_gfa_lowering_is_the_same_on_one_thread_and_on_many(oa, tmp_path):
     assert np.array_equal(a.edges[:3], [[0, 3], [2, 4], [4, 6]])   # 1+ -> 2- (every 97th edge), 2+ -> 3+, 3+ -> 4+
 
 
-def test_tile_region_size_fills_the_rounds_of_a_launch(oa):
-    """A tiled launch hands one work item per region of a colour to the resident workgroups in rounds; the region size is
-    the multiple of 8 near 256 that fills them best (1 953 items at R = 256 are two rounds with the second
-    91 % full, 2 084 at R = 240 a third round for 36 items).  Pure host arithmetic: no GPU."""
+def test_tile_windows_are_cut_into_parts_when_a_launch_has_few_rounds(oa):
+    """A tiled launch hands its work items to the resident workgroups in rounds and ends with a tail: slots idle while the last
+    items finish.  A session whose windows fill the device at least once but fewer than 24 times cuts every window's tiles
+    into consecutive parts — 24 rounds, parts of at least four tiles, at most 16 per window.  Host arithmetic."""
     from odgi_amd._lib import lib
-    f = lib.pgsgd_tile_region_for
-    items = lambda n, r: ((n + r - 1) // r + 1) // 2
-    assert f(1_000_000, 1024) == 248 and items(1_000_000, 248) == 2017           # BASELINE config 4 on MI355X
-    assert f(300_000, 1024) == 256 and f(10_000_000, 1024) == 256                # one round; twenty rounds
-    assert f(0, 1024) == 256 and f(1_000_000, 0) == 256
-    for n in (600_000, 1_500_000):                                               # two or three rounds: the best fill
-        r = f(n, 1024)
-        assert 240 <= r <= 272 and r % 8 == 0
-        fill = lambda rr: items(n, rr) / (1024 * -(-items(n, rr) // 1024))
-        assert all(fill(r) >= fill(c) - 1e-9 for c in range(240, 273, 8)), (n, r)
-    for n in (2_000_000, 3_000_000, 4_000_000):                                  # four rounds and more: measured no gain
-        assert f(n, 1024) == 256
+    f = lib.pgsgd_tile_parts_for
+    assert f(2016, 53, 1280) == 13 and f(2016, 53, 1024) == 13       # BASELINE config 4 on MI355X (five / four workgroups per CU): by length
+    assert f(20161, 53, 1024) == 2                                   # config 5: twenty rounds already
+    assert f(50000, 53, 1024) == 1 and f(500, 53, 1024) == 1         # many rounds; not one full round
+    assert f(2016, 7, 1024) == 1 and f(2016, 200, 1024) == 13        # short windows stay whole; long ones: 24 rounds (ceil(24 * 1024 / 2016))
+    assert f(1024, 1000, 1024) == 16 and f(0, 53, 1024) == 1 and f(2016, 53, 0) == 1
 
 
 def test_tile_sampler_rules_host_copies_match_the_oracle(orc):
