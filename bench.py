@@ -211,8 +211,11 @@ def main():
                 pj = json.load(f)
             rf["traffic"] = pj.get("hbm_bytes_per_launch")
             rf["traffic_over_algorithmic"] = pj.get("hbm_bytes_per_launch") / (BYTES_PER_TERM * my_terms) if my_terms else None
+            rf["hbm_bandwidth_TB_per_s"] = pj.get("hbm_bandwidth_TB_per_s")
             rf["memory_requests_per_launch"] = pj.get("requests_per_launch")
             rf["memory_requests_per_term"] = pj.get("requests_per_launch") / my_terms if my_terms else None
+            rf["memory_read_requests_per_launch"] = pj.get("read_requests_per_launch")
+            rf["memory_read_request_rate_per_s"] = pj.get("read_request_rate_per_s")
             rf["random_request_ceiling_per_s"] = pj.get("random_request_ceiling_per_s")
             rf["traffic_note"] = pj.get("note")
             rf["traffic_source"] = "profiled offline, not in this run: " + str(pj.get("source"))

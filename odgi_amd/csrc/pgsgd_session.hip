@@ -822,6 +822,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
         s->tile_tail = pgsgd::debug_env("PGSGD_TILE_TAIL") != nullptr;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
+        if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_QUADS")) s->tile_pair_uniform = 2;  // experiment: partner quads (no mirror in the oracle)
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52

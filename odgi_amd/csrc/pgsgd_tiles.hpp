@@ -836,9 +836,13 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         b_rank = below32_hi(rng, cnt, unused);
                         // partner pairs (tile_pair_partner): an odd lane takes the step that shares a 64-byte unit with its even
                         // neighbour's partner — one memory request for the two of them
-                        if (ta.pair_uniform) {
+                        if (ta.pair_uniform == 1u) {
                             const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0xA0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]: the even lane's step
                             if (threadIdx.x & 1u) b_rank = tile_pair_partner(lead, pstart, cnt, b_rank);
+                        } else if (ta.pair_uniform == 2u) {  // experiment (PGSGD_TILE_QUADS, not mirrored by the oracle): four lanes share a 128-byte line of four records
+                            const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
+                            const uint32_t twin = (lead ^ (threadIdx.x & 3u)) - pstart;
+                            if ((threadIdx.x & 3u) && twin < cnt) b_rank = twin;
                         }
                     }
                     // the partner's record: the tile's LDS copy when it is a step of the tile (read where it is used), otherwise

@@ -327,6 +327,21 @@ __global__ void cal_gather_group(const uint4* buf, uint64_t n32, uint64_t iters,
     }
     if (acc == 0x12345678u) *sink = acc;
 }
+// Does a gather fill a 64-byte sector or the whole 128-byte line?  Few lanes (the L2 is not turned over between a lane's two reads): a
+// random record, then MODE 0 nothing, 1 the other 64-byte half of the same 128-byte line, 2 another random record (each read depends on the one before).
+template <int MODE>
+__global__ void cal_line_fill(const uint4* buf, uint64_t n128, uint64_t iters, uint32_t* sink) {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < iters; ++i) {
+        const uint64_t r = xs(s) + acc, line = __umul64hi(r, n128), half = r & 1;
+        const uint4 a = buf[line * 8 + half * 4];
+        acc += a.x;
+        if (MODE == 1) acc += buf[line * 8 + (half ^ 1) * 4 + (a.x & 3)].y;
+        if (MODE == 2) acc += buf[__umul64hi(xs(s) + a.x, n128) * 8 + (a.x & 3)].y;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
 int main() {
     const int grid = 256 * 8, block = 256;
     const uint64_t lanes = (uint64_t)grid * block;
@@ -364,6 +379,20 @@ int main() {
                    G, req, ms, req / ms / 1e6, req / G / ms / 1e6);
             hipEventDestroy(a); hipEventDestroy(b);
         };
+        for (int g2 : {32, 256, 2048}) {   // workgroups of 256 lanes: 8k, 64k, 512k lanes in flight
+            auto fill = [&](int mode, auto kernel) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+                hipDeviceSynchronize();
+                hipEventRecord(a);
+                hipLaunchKernelGGL(kernel, dim3(g2), dim3(256), 0, 0, g, (uint64_t)big2 / 128, (uint64_t)512, sink);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                printf("{\"local\": \"line fill: random record, then 0 nothing / 1 other half of its 128-byte line / 2 another random record\", \"mode\": %d, \"lanes\": %d, \"ms\": %.4f, \"ns_per_iteration\": %.1f}\n",
+                       mode, g2 * 256, ms, ms * 1e6 / 512);
+                hipEventDestroy(a); hipEventDestroy(b);
+            };
+            fill(0, cal_line_fill<0>); fill(1, cal_line_fill<1>); fill(2, cal_line_fill<2>);
+        }
         for (int rep = 0; rep < 2; ++rep) {
             group(1, cal_gather_group<1>);
             group(2, cal_gather_group<2>);

@@ -46,16 +46,20 @@ drain = traffic("bench:far_drain_kernel")
 res = {"source": "rocprofv3 --pmc passes (TCC_EA0_RDREQ by size class, TCC_EA0_WRREQ, TCC_HIT/MISS; one group per pass) of `bench.py --cpu-seconds 0 --steps 20 "
                  "--warmup 5`, tools/profile_cal.sh + tools/summarize_cal.py; " + src,
        "note": "Calibrated on kernels of known traffic (pmc_calibration.json): the L2's memory-side request COUNTS are exact (a random 16- or 32-byte "
-               "gather = 1.00 read request, a 64-byte line write = 1.00 write request of 64 bytes, a streaming read = one request per 128 bytes), the "
-               "size class of a read request is not (TCC_EA0_RDREQ_128B files a random gather under 128 bytes, yet reading the two 64-byte halves of "
-               "one 128-byte line one after the other costs 1.72 requests, and four lanes sharing a 128-byte line of step records were 2 % faster "
-               "than two sharing a 64-byte unit: a gather moves a 64-byte sector).  hbm_bytes_per_launch = 64 B x read requests + 64 B x 64-byte write "
-               "requests (+ 32 B x the others); hbm_bytes_per_launch_by_size_class takes the counter's size classes at their word (an upper bound: "
-               "128 B per gather).  What the kernel is bound by is the request RATE: requests_per_launch over the launch's duration against "
-               "random_request_ceiling_per_s (the rate of cal_gather16/32, whatever the request's size or cache policy).  Mean of the warm and the "
-               "cooling instance, as the driver's window (iterations 5..24) weighs them.",
-       "hbm_bytes_per_launch": 64.0 * mix["rdreq"] + mix["bytes_written"], "hbm_bytes_per_launch_by_size_class": mix["bytes_read"] + mix["bytes_written"],
-       "requests_per_launch": mix["rdreq"] + mix["wrreq"],
+               "gather = 1.00 read request, a 64-byte line write = 1.00 write request of 64 bytes, a streaming read = one request per 128 bytes), and a "
+               "read request moves a whole 128-BYTE LINE, as its size class says: with few lanes in flight the other half of a gathered line is an L2 "
+               "hit (+385 ns against +640 ns for another random record, microbench_wave_local.jsonl: line fill), lanes of one instruction that cover "
+               "a line cost one request, and random gathers top out at 51-55 G requests/s = 6.5-7.0 TB/s of lines — the HBM ceiling, not a request "
+               "ceiling.  (Earlier in round 4 the second half's misses under 524 288 lanes were read as 64-byte sector fills; they were capacity "
+               "misses.  FETCH_SIZE counts 64 bytes per read request: half, the guide's gfx950 correction.)  hbm_bytes_per_launch = 128 B x 128-byte "
+               "read requests + 64 B x 64-byte ones + 32 B x 32-byte ones + the same for writes; hbm_bytes_if_64B_sectors is the earlier reading, "
+               "kept for comparison.  Mean of the warm and the cooling instance, as the driver's window (iterations 5..24) weighs them.",
+       "hbm_bytes_per_launch": mix["bytes_read"] + mix["bytes_written"], "hbm_bytes_if_64B_sectors": 64.0 * mix["rdreq"] + mix["bytes_written"],
+       "hbm_bandwidth_TB_per_s": {"warm": (warm["bytes_read"] + warm["bytes_written"]) / warm["mean_duration_ms"] / 1e9 if warm["mean_duration_ms"] else None,
+                                  "cooling": (cool["bytes_read"] + cool["bytes_written"]) / cool["mean_duration_ms"] / 1e9 if cool["mean_duration_ms"] else None},
+       "requests_per_launch": mix["rdreq"] + mix["wrreq"], "read_requests_per_launch": mix["rdreq"], "write_requests_per_launch": mix["wrreq"],
+       "read_request_rate_per_s": {"warm": warm["rdreq"] / warm["mean_duration_ms"] * 1e3 if warm["mean_duration_ms"] else None,
+                                   "cooling": cool["rdreq"] / cool["mean_duration_ms"] * 1e3 if cool["mean_duration_ms"] else None},
        "random_request_ceiling_per_s": ceil, "tile_kernel_warm": warm, "tile_kernel_cooling": cool, "tile_kernel_window_mean": mix, "far_drain_kernel": drain}
 json.dump(res, open(os.path.join(out_dir, "pmc_traffic_r04.json"), "w"), indent=1)
 for k in ("tile_kernel_warm", "tile_kernel_cooling", "far_drain_kernel"):
