@@ -567,9 +567,9 @@ __host__ __device__ inline uint64_t tile_coin_seed(uint64_t seed_base, uint64_t 
     return seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (1023u - wave));
 }
 
-// Partner pairs.  A uniform partner (path_sgd_layout.cpp:235-237) is a random step of the path: one memory request per
-// term that nothing else shares, and the memory system retires ~50 G random 64-byte requests per second whatever their
-// size (profiles/r04/pmc_calibration*.json) — the tile kernel's warm iterations ran at that ceiling.  A 64-byte unit
+// Partner pairs.  A uniform partner (path_sgd_layout.cpp:235-237) is a random step of the path: one 128-byte line from HBM
+// per term that nothing else shares, and HBM delivers 51-55 G random lines per second (profiles/r04/NOTES.md section 6) —
+// the tile kernel's warm iterations ran at that ceiling.  A 64-byte half of a line
 // holds the records of TWO consecutive steps, so the lanes of a wave pair up in a uniform trip: the even lane draws its
 // partner as before, the odd lane draws its own (its stream advances the same way) and then takes the step that shares
 // the even lane's unit, flat step ^ 1, when that is a step of the path (it is, but for the one step at either end of a
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     // (relaxed: an acquire at agent scope invalidates the XCD's L2 on every poll, and the words that follow are read with agent-scope loads anyway)
                     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
                         __builtin_amdgcn_s_sleep(32);
-                        if (wall_clock64() - t_wait > 100000000ull) __builtin_trap();  // 1 s of 100 MHz ticks: never seen; a dead launch, not a hung device
+                        if (wall_clock64() - t_wait > 500000000ull) __builtin_trap();  // 5 s of 100 MHz ticks: never seen; a dead launch, not a hung device
                     }
                 }
             }

@@ -349,6 +349,29 @@ int main() {
     const size_t big = 1ull << 30;  // 1 GiB
     uint4* g; CK(hipMalloc(&g, big)); CK(hipMemset(g, 1, big));
     printf("{\"lanes\": %llu}\n", (unsigned long long)lanes);
+    if (getenv("MICROBENCH_WS")) {   // the random-line ceiling against the working set (TLB reach): 32-byte records gathered from 1.5 ... 48 GB
+        (void)hipFree(g);
+        const uint64_t iters = 128;
+        const double req = (double)lanes * iters;
+        for (unsigned long long gb10 : {15ull, 60ull, 240ull, 480ull}) {
+            const size_t bytes = (size_t)(gb10 * 100) << 20;
+            uint4* w = nullptr;
+            if (hipMalloc(&w, bytes) != hipSuccess) { printf("{\"ws\": \"allocation of %llu MB failed\"}\n", gb10 * 100); continue; }
+            hipMemset(w, 1, bytes);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+                hipDeviceSynchronize();
+                hipEventRecord(a);
+                hipLaunchKernelGGL(cal_gather_group<1>, dim3(grid), dim3(block), 0, 0, w, (uint64_t)bytes / 32, iters, sink);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                printf("{\"ws\": \"random 32-byte records\", \"working_set_MB\": %llu, \"ms\": %.4f, \"G_gathers_per_s\": %.2f}\n", gb10 * 100, ms, req / ms / 1e6);
+                hipEventDestroy(a); hipEventDestroy(b);
+            }
+            (void)hipFree(w);
+        }
+        return 0;
+    }
     if (getenv("MICROBENCH_LOCAL")) {
         (void)hipFree(g);
         const size_t big2 = 1536ull << 20;
