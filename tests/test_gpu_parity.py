@@ -383,8 +383,10 @@ def test_full_layout_stress_matches_cpu_oracle(oa, orc, graphs, ographs, name, f
     print(f"{name} flags {flags} m {m}: stress gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} "
           f"mean/median {s_gpu:.4f}/{s_cpu:.4f} band {band}; path distance {d_gpu:.3f}/{d_cpu:.3f}; streams {gpu[0][2]}")
     # two-sided: not worse than the CPU restatement's median by more than the band, and not BETTER than its best run by
-    # more than 10 % either — a sampler that drew too many short pairs would look better by this metric
-    lo_s, lo_d = min(r[0] for r in cpu) / 1.10, min(r[1] for r in cpu) / 1.10
+    # more than 15 % (stress) / 10 % (path distance) either — a sampler that drew too many short pairs would look better by
+    # this metric.  (The lower side is set by the CPU runs' own scatter: 256 Hogwild threads on LPA ended at 0.825-1.185
+    # over four suite runs, best of three 0.825-0.925, while the GPU's mean stayed at 0.831-0.832: profiles/r04/pytest_gpu_*.log.)
+    lo_s, lo_d = min(r[0] for r in cpu) / 1.15, min(r[1] for r in cpu) / 1.10
     print(f"   ratios: stress gpu/cpu-median {s_gpu / s_cpu:.3f} gpu/cpu-best {s_gpu / min(r[0] for r in cpu):.3f}; path distance {d_gpu / d_cpu:.3f}")
     assert lo_s <= s_gpu <= band * s_cpu
     assert lo_d <= d_gpu <= band * d_cpu
