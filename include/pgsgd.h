@@ -279,6 +279,12 @@ int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_launch_items);
 /* The rule behind it, pure host arithmetic: 1 when the `windows` of a launch do not fill the resident workgroups once;
  * otherwise what brings the launch to 24 rounds of work items, parts of at least four tiles, at most 16 per window. */
 uint32_t pgsgd_tile_parts_for(uint64_t windows, uint64_t tiles_per_window, uint64_t resident_workgroups);
+/* The cut itself on caller's arrays (host only, tests): the items of one launch — windows first, the last n_windowless
+ * without a window — with every window's tiles in k consecutive parts: part 0 of every window, then part 1, ...; out_flags =
+ * bit 0 window | bit 1 another item waits for this one | (1 + index of the item this one waits for) << 2.  Returns the
+ * number of items (call with capacity 0 to size the arrays), < 0 on error. */
+int64_t pgsgd_tile_split_items(const uint32_t* tile_begin, const uint32_t* tile_end, const uint32_t* win0, uint64_t n_items, uint32_t n_windowless,
+                               uint32_t k, uint32_t* out_begin, uint32_t* out_end, uint32_t* out_win0, uint32_t* out_flags, uint64_t capacity);
 /* Two rules of the tile kernel's sampler, restated on the host for tests: the Zipf/uniform coin (path_sgd_layout.cpp:205)
  * that the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration (a SplitMix64 stream per
  * wave, seeded like a lane's generator with lane id 1023 - wave), and the partner (rank in its path) an odd lane takes in

@@ -500,6 +500,28 @@ static std::vector<pgsgd::WorkItem> split_items(const std::vector<pgsgd::WorkIte
     return out;
 }
 
+// split_items on caller's arrays (tests without a device: the item list a session of these windows would launch).
+// flags: WorkItem::local — bit 0 window, bit 1 another item waits for this one, bits 31..2: 1 + the item it waits for.
+extern "C" int64_t pgsgd_tile_split_items(const uint32_t* tile_begin, const uint32_t* tile_end, const uint32_t* win0, uint64_t n_items, uint32_t n_windowless,
+                                          uint32_t k, uint32_t* out_begin, uint32_t* out_end, uint32_t* out_win0, uint32_t* out_flags, uint64_t capacity) {
+    if (!tile_begin || !tile_end || !win0 || n_windowless > n_items || k == 0) return PGSGD_E_INVALID;
+    std::vector<pgsgd::WorkItem> items(n_items);
+    for (uint64_t i = 0; i < n_items; ++i) {
+        items[i].tile_begin = tile_begin[i];
+        items[i].tile_end = tile_end[i];
+        items[i].win0 = win0[i];
+        items[i].local = i + n_windowless < n_items ? pgsgd::kItemLocal : 0u;
+    }
+    const std::vector<pgsgd::WorkItem> cut = split_items(items, n_windowless, k);
+    for (uint64_t i = 0; i < cut.size() && i < capacity; ++i) {
+        if (out_begin) out_begin[i] = cut[i].tile_begin;
+        if (out_end) out_end[i] = cut[i].tile_end;
+        if (out_win0) out_win0[i] = cut[i].win0;
+        if (out_flags) out_flags[i] = cut[i].local;
+    }
+    return (int64_t)cut.size();
+}
+
 // The item lists a session launches.  A launch of few rounds of work items loses 7-10 % of its workgroup-time to its tail
 // (WorkItem in pgsgd_tiles.hpp), so when the session's windows fill the device at least once but fewer than 24 times, every
 // window's tiles are cut into k parts: k = what brings a launch to 24 rounds, parts no shorter than four tiles, at most 16

@@ -565,3 +565,45 @@ def test_path_order_renames_nodes_along_the_paths(oa):
     comp_a, comp_b = new2[0::2][visited], new2[1::2][visited]   # (the nodes no path visits are components of their own, at the end)
     assert comp_a.max() < comp_b.min() or comp_b.max() < comp_a.min()
     assert d1 < 0.01
+
+
+def test_tile_windows_cut_into_parts_keep_order_and_dependencies(oa):
+    """The cut of a launch's work items (pgsgd_tile_split_items = what a session launches) against the independent restatement
+    in tests/pyref.py, and its invariants: every part waits for the part before it of the same window, which sits earlier in
+    the queue and ends where this one begins; the parts of a window cover its tiles exactly once, in order; window-less items
+    stay whole at the end."""
+    import ctypes as C
+    from odgi_amd._lib import lib
+    import pyref
+    g = oa.Graph.synthetic(3000, 4, seed=3)
+    tiles, items = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56)
+    u32p = C.POINTER(C.c_uint32)
+    ptr = lambda a: a.ctypes.data_as(u32p)
+    for colour, (lo, hi) in enumerate(((0, items["n_first"]), (items["n_first"], len(items["local"])))):
+        tb, te, w0 = (np.ascontiguousarray(items[k][lo:hi]) for k in ("tile_begin", "tile_end", "win0"))
+        n_windowless = int((items["local"][lo:hi] == 0).sum())
+        for k in (1, 2, 3, 7, 64):
+            cnt = lib.pgsgd_tile_split_items(ptr(tb), ptr(te), ptr(w0), len(tb), n_windowless, k, None, None, None, None, 0)
+            ob, oe, ow, of = (np.zeros(cnt, dtype=np.uint32) for _ in range(4))
+            assert lib.pgsgd_tile_split_items(ptr(tb), ptr(te), ptr(w0), len(tb), n_windowless, k, ptr(ob), ptr(oe), ptr(ow), ptr(of), cnt) == cnt
+            _, cut = pyref.build_tiles_py(g.path_first, g.step_handle, 64, 56, split=k)
+            clo, chi = (0, cut["n_first"]) if colour == 0 else (cut["n_first"], len(cut["local"]))
+            assert np.array_equal(ob, cut["tile_begin"][clo:chi]) and np.array_equal(oe, cut["tile_end"][clo:chi]) and np.array_equal(ow, cut["win0"][clo:chi])
+            assert np.array_equal(of & 1, cut["local"][clo:chi])
+            dep, has_next = (of >> 2).astype(np.int64) - 1, (of >> 1) & 1
+            waited_for = np.zeros(cnt, dtype=bool)
+            for i in range(cnt):
+                if dep[i] >= 0:
+                    assert dep[i] < i and ow[dep[i]] == ow[i] and oe[dep[i]] == ob[i] and has_next[dep[i]]
+                    assert not waited_for[dep[i]]
+                    waited_for[dep[i]] = True
+            assert np.array_equal(waited_for, has_next.astype(bool))
+            assert np.all(oe > ob) and (k > 1 or cnt == len(tb))
+            covered = np.zeros(int(te.max()) + 1, dtype=np.int32)
+            for b, e in zip(ob, oe):
+                covered[b:e] += 1
+            want = np.zeros_like(covered)
+            for b, e in zip(tb, te):
+                want[b:e] += 1
+            assert np.array_equal(covered, want)
+    assert lib.pgsgd_tile_split_items(None, None, None, 0, 0, 2, None, None, None, None, 0) < 0
