@@ -55,7 +55,7 @@ struct WorkItem {
 // sits in the queue behind part j - 1 of every window and starts when its predecessor has written the window back — the
 // same tiles in the same order on the same window, in items a k-th as long.  The predecessor was taken from the queue
 // earlier, so it is running or done when its successor is taken: the wait cannot deadlock (and gives up with a trap
-// after ~1 s instead of hanging the device, should that reasoning ever fail).
+// after 5 s instead of hanging the device, should that reasoning ever fail).
 constexpr uint32_t kItemLocal = 1u;
 constexpr uint32_t kItemHasNext = 2u;   // another item of this launch waits for this one: write the window through and raise its flag
 constexpr uint32_t kItemDepShift = 2;   // bits 31..2: 1 + index (in the launch's item list) of the item this one waits for; 0: none
@@ -175,9 +175,10 @@ struct TileArgs {
 };
 
 // The head of the tile kernel's argument segment as the ABI lays it out (arguments in order, each at its natural
-// alignment; the sampler's tables and the iteration's numbers follow), and a read of one argument from it AT THE PLACE OF USE.  The kernel has ~45 pointer-sized arguments; the compiler loads them
-// all on entry and keeps them in scalar registers across the term loop, where two thirds are never used — 70-90 scalar
-// registers spilled into vector lanes (profiles/r03: .sgpr_spill_count) and read back with v_readlane inside the loop.
+// alignment; the sampler's tables and the iteration's numbers follow), and a read of one argument from it AT THE PLACE
+// OF USE.  The kernel has ~45 pointer-sized arguments; the compiler loads them all on entry and keeps them in scalar
+// registers across the term loop, where two thirds are never used — 70-90 scalar registers spilled into vector lanes
+// (profiles/r03: .sgpr_spill_count) and read back with v_readlane inside the loop.
 // Arguments that only cold code needs (work-item pick-up, the staging of a window, the outbox's line replacement and
 // flush, the epilogue) are read through TILE_COLD where they are used: one s_load there, no register held in between.
 // (The empty asm hides the segment's address from the optimiser, which would otherwise merge the load with the entry
