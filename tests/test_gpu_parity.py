@@ -446,12 +446,15 @@ def test_hilbert_init_theta_sweep_and_cooling(oa, orc, graphs, ographs, theta):
     # scatter by < 2 % and agree within 5 %: 10 % up against the median, 10 % down against the CPU restatement's best
     # run.  Measured ratios of all twelve points: profiles/r04/pytest_gpu_two_sided_ratios.log.
     band = 2.0 if theta == 0.5 else 1.3 if theta == 0.9 else 1.10
+    # (downwards at theta 0.9: the CPU restatement's best of three was 1.59 .. 1.67 at -K 0.5 over the round's suite runs with single
+    # runs up to 3.8, the GPU's mean 1.37 .. 1.39 — 0.83-0.87 of the best; 1.4 leaves room for three high CPU runs)
+    down = 1.4 if theta == 0.9 else band
     for K in (0.25, 0.5, 0.75):
         p = _params(oa, g, theta=theta, cooling_start=K)
         gpu, cpu = _gpu_runs(oa, orc, g, og, p, init="h"), _cpu_runs(oa, orc, g, og, "chr6.C4", p, init="h")
         s_gpu, s_cpu, best = float(np.mean([r[0] for r in gpu])), float(np.median([r[0] for r in cpu])), min(r[0] for r in cpu)
         print(f"theta {theta} K {K}: gpu {[round(r[0], 4) for r in gpu]} cpu {[round(r[0], 4) for r in cpu]} gpu/cpu-median {s_gpu / s_cpu:.3f} gpu/cpu-best {s_gpu / best:.3f}")
-        assert best / band <= s_gpu <= band * s_cpu, (theta, K, s_gpu, s_cpu, best)
+        assert best / down <= s_gpu <= band * s_cpu, (theta, K, s_gpu, s_cpu, best)
 
 
 def test_delta_early_stop_and_counts(oa, graphs):
