@@ -120,6 +120,7 @@ struct pgsgd_session {
     uint32_t* d_item_done = nullptr;      // [max items of a launch] TileArgs::item_done
     uint32_t launch_stamp = 0;            // TileArgs::stamp of the last tile launch
     uint32_t item_chunk[2][pgsgd::kItemQueues + 1] = {};  // per colour: runs of the windowed items, one per XCD
+    uint32_t item_chunk_split[2][pgsgd::kItemQueues + 1] = {};  // the same for the items in parts (experiment: PGSGD_TILE_ORDER=region with PGSGD_TILE_SPLIT)
     uint32_t n_windowless = 0;            // the last n_windowless items of colour 0 have no window (their own launch)
     uint32_t* d_queue = nullptr;          // [3][kItemQueues] work-item counters: colour 0, colour 1, colour 0's window-less items
     uint64_t tile_steps_total = 0;
@@ -536,7 +537,42 @@ static int build_launch_items(pgsgd_session* s) {
     s->h_items_split.clear();
     s->tile_split = 1;
     s->n_items_split[0] = s->n_items_split[1] = 0;
-    if (!s->items_one_run || s->h_items.empty()) return PGSGD_OK;
+    if (s->h_items.empty()) return PGSGD_OK;
+    if (!s->items_one_run) {
+        // experiment (PGSGD_TILE_ORDER=region with PGSGD_TILE_SPLIT=k, unsharded): every XCD's run cut on its own — a workgroup
+        // takes the items of a run in order, so a part's predecessor in its run has been taken before it
+        if (!s->tile_split_knob || s->tile_split_knob < 2 || s->shard_world > 1) return PGSGD_OK;
+        const uint32_t k = s->tile_split_knob;
+        std::vector<pgsgd::WorkItem> cut[2];
+        for (int colour = 0; colour < 2; ++colour) {
+            const uint32_t base = colour ? s->n_items[0] : 0, windowless = colour == 0 ? s->n_windowless : 0, n_local = s->n_items[colour] - windowless;
+            for (uint32_t q = 0; q < pgsgd::kItemQueues; ++q) {
+                s->item_chunk_split[colour][q] = (uint32_t)cut[colour].size();
+                const uint32_t lo = std::min(s->item_chunk[colour][q], n_local), hi = std::min(s->item_chunk[colour][q + 1], n_local);
+                std::vector<pgsgd::WorkItem> run(s->h_items.begin() + base + lo, s->h_items.begin() + base + hi);
+                std::vector<pgsgd::WorkItem> parts = split_items(run, 0, k);
+                const uint32_t off = (uint32_t)cut[colour].size();
+                for (pgsgd::WorkItem& wi : parts)
+                    if (wi.local >> pgsgd::kItemDepShift) wi.local += off << pgsgd::kItemDepShift;  // (indices are relative to the launch's list)
+                cut[colour].insert(cut[colour].end(), parts.begin(), parts.end());
+            }
+            s->item_chunk_split[colour][pgsgd::kItemQueues] = (uint32_t)cut[colour].size();
+            cut[colour].insert(cut[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);
+        }
+        s->tile_split = k;
+        s->n_items_split[0] = (uint32_t)cut[0].size();
+        s->n_items_split[1] = (uint32_t)cut[1].size();
+        s->h_items_split = cut[0];
+        s->h_items_split.insert(s->h_items_split.end(), cut[1].begin(), cut[1].end());
+        const size_t n_flags = std::max<size_t>(1, std::max(cut[0].size(), cut[1].size()));
+        hipError_t e = hipSetDevice(s->device);
+        if (e == hipSuccess) e = hipMalloc(&s->d_items_split, s->h_items_split.size() * sizeof(pgsgd::WorkItem));
+        if (e == hipSuccess) e = hipMalloc(&s->d_item_done, n_flags * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(s->d_items_split, s->h_items_split.data(), s->h_items_split.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(s->d_item_done, 0, n_flags * sizeof(uint32_t));
+        if (e != hipSuccess) { set_error("work-item lists: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
+        return PGSGD_OK;
+    }
     std::vector<pgsgd::WorkItem> own[2];
     uint64_t n_local_min = ~0ull, tiles = 0, windows = 0;
     for (int colour = 0; colour < 2; ++colour) {
@@ -1671,8 +1707,10 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own
             const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
             ta.n_items = n_items_now[colour] - windowless;
-            if (split)
+            if (split && s->items_one_run)
                 for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) ta.chunk[q] = ta.n_items;  // one run
+            else if (split)
+                memcpy(ta.chunk, s->item_chunk_split[colour], sizeof ta.chunk);
             // The far pulls the launch before this one collected are delivered now, right before the windows are staged:
             // an iteration ends with a launch's window-local terms, not with the arrival of a launch's worth of far
             // pulls (each an average of a dozen long-range pulls — noise at the scale of neighbouring nodes until the
