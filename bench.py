@@ -196,7 +196,8 @@ def main():
                                     "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
     if info["tiled"]:
         out["config"]["tile_plan"] = {"region_nodes": info["region_nodes"], "tile_steps": info["tile_steps"], "windows": info["n_work_items"],
-                                      "parts_per_window": info["parts"], "work_items_launched": info["n_launch_items"]}
+                                      "parts_per_window": info["parts"], "work_items_launched": info["n_launch_items"],
+                                      "order": "node order, one run per XCD" if info["xcd_runs"] else "one run by size"}
     # the shader clock the last tile launch of the window ran at (s_memtime against the 100 MHz s_memrealtime, read by the
     # kernel's first workgroup): a 20-step window is 0.2 s long and every figure above moves with the clock
     rf["shader_clock_mhz"] = clock_mhz

@@ -276,6 +276,10 @@ int pgsgd_session_tile_info(const pgsgd_session* s, uint64_t* n_tiles, uint64_t*
  * shrinks with the items).  Returns k (1: whole windows; 0: per-lane kernel); *n_launch_items: items of the two launches.
  * pgsgd_session_tile_items lists them in launch order for an unsharded session. */
 int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_launch_items);
+/* 1 when the session takes its windows in node order, one run of work items per XCD (what a session whose windows are cut
+ * into parts does: the workgroups of an XCD share the step records around neighbouring windows in their L2); 0: one run by
+ * decreasing size. */
+int pgsgd_session_tile_order(const pgsgd_session* s);
 /* The rule behind it, pure host arithmetic: 1 when the `windows` of a launch do not fill the resident workgroups once;
  * otherwise what brings the launch to 24 rounds of work items, parts of at least four tiles, at most 16 per window. */
 uint32_t pgsgd_tile_parts_for(uint64_t windows, uint64_t tiles_per_window, uint64_t resident_workgroups);

@@ -100,6 +100,7 @@ SIGNATURES = [
     ("pgsgd_session_shader_clock", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_tile_tail", C.c_int, [C.c_void_p, P(f64), P(f64), P(C.c_uint32)]),
     ("pgsgd_session_tile_parts", C.c_int, [C.c_void_p, P(C.c_uint64)]),
+    ("pgsgd_session_tile_order", C.c_int, [C.c_void_p]),
     ("pgsgd_tile_parts_for", u32, [u64, u64, u64]),
     ("pgsgd_tile_split_items", C.c_int64, [P(u32), P(u32), P(u32), u64, u32, u32, P(u32), P(u32), P(u32), P(u32), u64]),
     ("pgsgd_session_tile_conflicts", C.c_int, [C.c_void_p, P(u64), P(u64)]),

@@ -120,7 +120,7 @@ struct pgsgd_session {
     uint32_t* d_item_done = nullptr;      // [max items of a launch] TileArgs::item_done
     uint32_t launch_stamp = 0;            // TileArgs::stamp of the last tile launch
     uint32_t item_chunk[2][pgsgd::kItemQueues + 1] = {};  // per colour: runs of the windowed items, one per XCD
-    uint32_t item_chunk_split[2][pgsgd::kItemQueues + 1] = {};  // the same for the items in parts (experiment: PGSGD_TILE_ORDER=region with PGSGD_TILE_SPLIT)
+    uint32_t item_chunk_split[2][pgsgd::kItemQueues + 1] = {};  // the same for the list in parts (build_launch_items)
     uint32_t n_windowless = 0;            // the last n_windowless items of colour 0 have no window (their own launch)
     uint32_t* d_queue = nullptr;          // [3][kItemQueues] work-item counters: colour 0, colour 1, colour 0's window-less items
     uint64_t tile_steps_total = 0;
@@ -538,58 +538,42 @@ static int build_launch_items(pgsgd_session* s) {
     s->tile_split = 1;
     s->n_items_split[0] = s->n_items_split[1] = 0;
     if (s->h_items.empty()) return PGSGD_OK;
-    if (!s->items_one_run) {
-        // experiment (PGSGD_TILE_ORDER=region with PGSGD_TILE_SPLIT=k, unsharded): every XCD's run cut on its own — a workgroup
-        // takes the items of a run in order, so a part's predecessor in its run has been taken before it
-        if (!s->tile_split_knob || s->tile_split_knob < 2 || s->shard_world > 1) return PGSGD_OK;
-        const uint32_t k = s->tile_split_knob;
-        std::vector<pgsgd::WorkItem> cut[2];
-        for (int colour = 0; colour < 2; ++colour) {
-            const uint32_t base = colour ? s->n_items[0] : 0, windowless = colour == 0 ? s->n_windowless : 0, n_local = s->n_items[colour] - windowless;
-            for (uint32_t q = 0; q < pgsgd::kItemQueues; ++q) {
-                s->item_chunk_split[colour][q] = (uint32_t)cut[colour].size();
-                const uint32_t lo = std::min(s->item_chunk[colour][q], n_local), hi = std::min(s->item_chunk[colour][q + 1], n_local);
-                std::vector<pgsgd::WorkItem> run(s->h_items.begin() + base + lo, s->h_items.begin() + base + hi);
-                std::vector<pgsgd::WorkItem> parts = split_items(run, 0, k);
-                const uint32_t off = (uint32_t)cut[colour].size();
-                for (pgsgd::WorkItem& wi : parts)
-                    if (wi.local >> pgsgd::kItemDepShift) wi.local += off << pgsgd::kItemDepShift;  // (indices are relative to the launch's list)
-                cut[colour].insert(cut[colour].end(), parts.begin(), parts.end());
-            }
-            s->item_chunk_split[colour][pgsgd::kItemQueues] = (uint32_t)cut[colour].size();
-            cut[colour].insert(cut[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);
-        }
-        s->tile_split = k;
-        s->n_items_split[0] = (uint32_t)cut[0].size();
-        s->n_items_split[1] = (uint32_t)cut[1].size();
-        s->h_items_split = cut[0];
-        s->h_items_split.insert(s->h_items_split.end(), cut[1].begin(), cut[1].end());
-        const size_t n_flags = std::max<size_t>(1, std::max(cut[0].size(), cut[1].size()));
-        hipError_t e = hipSetDevice(s->device);
-        if (e == hipSuccess) e = hipMalloc(&s->d_items_split, s->h_items_split.size() * sizeof(pgsgd::WorkItem));
-        if (e == hipSuccess) e = hipMalloc(&s->d_item_done, n_flags * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(s->d_items_split, s->h_items_split.data(), s->h_items_split.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(s->d_item_done, 0, n_flags * sizeof(uint32_t));
-        if (e != hipSuccess) { set_error("work-item lists: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
-        return PGSGD_OK;
-    }
-    std::vector<pgsgd::WorkItem> own[2];
+    // the windows this session runs, run by run (one run, or one per XCD: item_chunk): those a kernel with the session's
+    // shard arguments would take — every shard_world-th of a run
+    std::vector<pgsgd::WorkItem> own[2][pgsgd::kItemQueues];
     uint64_t n_local_min = ~0ull, tiles = 0, windows = 0;
     for (int colour = 0; colour < 2; ++colour) {
         const uint32_t base = colour ? s->n_items[0] : 0, windowless = colour == 0 ? s->n_windowless : 0, n_local = s->n_items[colour] - windowless;
-        for (uint32_t w = s->shard_rank; w < n_local; w += s->shard_world) {  // (the items a kernel with these shard arguments would take)
-            own[colour].push_back(s->h_items[base + w]);
-            tiles += s->h_items[base + w].tile_end - s->h_items[base + w].tile_begin;
+        uint64_t mine = 0;
+        for (uint32_t q = 0; q < pgsgd::kItemQueues; ++q) {
+            const uint32_t lo = std::min(s->item_chunk[colour][q], n_local), hi = std::min(s->item_chunk[colour][q + 1], n_local);
+            for (uint32_t w = lo + s->shard_rank; w < hi; w += s->shard_world) {
+                own[colour][q].push_back(s->h_items[base + w]);
+                tiles += s->h_items[base + w].tile_end - s->h_items[base + w].tile_begin;
+                ++mine;
+            }
         }
-        if (!own[colour].empty()) n_local_min = std::min<uint64_t>(n_local_min, own[colour].size());
-        windows += own[colour].size();
-        own[colour].insert(own[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);  // every window-less item
+        if (mine) n_local_min = std::min<uint64_t>(n_local_min, mine);
+        windows += mine;
     }
     uint32_t k = 1;
     if (s->tile_split_knob) k = s->tile_split_knob;
     else if (windows && n_local_min != ~0ull) k = pgsgd_tile_parts_for(n_local_min, tiles / windows / std::max<uint32_t>(1, s->tshard_world), s->tile_grid);
     if (k <= 1) return PGSGD_OK;
-    std::vector<pgsgd::WorkItem> cut[2] = {split_items(own[0], s->n_windowless, k), split_items(own[1], 0, k)};
+    std::vector<pgsgd::WorkItem> cut[2];
+    for (int colour = 0; colour < 2; ++colour) {
+        const uint32_t base = colour ? s->n_items[0] : 0, windowless = colour == 0 ? s->n_windowless : 0, n_local = s->n_items[colour] - windowless;
+        for (uint32_t q = 0; q < pgsgd::kItemQueues; ++q) {
+            s->item_chunk_split[colour][q] = (uint32_t)cut[colour].size();
+            std::vector<pgsgd::WorkItem> parts = split_items(own[colour][q], 0, k);
+            const uint32_t off = (uint32_t)cut[colour].size();
+            for (pgsgd::WorkItem& wi : parts)
+                if (wi.local >> pgsgd::kItemDepShift) wi.local += off << pgsgd::kItemDepShift;  // (a part names its predecessor by its index in the launch's list)
+            cut[colour].insert(cut[colour].end(), parts.begin(), parts.end());
+        }
+        s->item_chunk_split[colour][pgsgd::kItemQueues] = (uint32_t)cut[colour].size();
+        cut[colour].insert(cut[colour].end(), s->h_items.begin() + base + n_local, s->h_items.begin() + base + s->n_items[colour]);  // every window-less item
+    }
     s->tile_split = k;
     s->n_items_split[0] = (uint32_t)cut[0].size();
     s->n_items_split[1] = (uint32_t)cut[1].size();
@@ -911,9 +895,30 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             std::vector<RawTile> raw = cut_tiles(g, s->tile_steps);
             rc = device_tile_stats(s->stream, d_handle, s->tile_steps, raw);
             if (rc) return fail(rc);
-            // experiment knob: "region" = work items in node order, one run per XCD (TileArgs::chunk); measured slower, see group_tiles
+            // Work order.  By default the items of a colour are one run by decreasing size.  A session whose windows are cut
+            // into parts (build_launch_items: launches of few rounds on a full device) takes them in NODE order instead, one run
+            // per XCD (TileArgs::chunk), every run cut on its own: the workgroups of an XCD then work on neighbouring windows
+            // and find the partner records just outside a tile in their common L2.  Whole windows in that order were slower
+            // (rounds 3-4: neighbours in lock step); in parts, with the kernel bound by HBM lines, it is 3 % faster (config 4,
+            // driver's window 0.635 -> 0.654, whole schedule 0.644 -> 0.667, same stress: profiles/r04/NOTES.md section 6).
+            // PGSGD_TILE_ORDER=region / size forces either (experiments; the parity tests' small sessions are whole windows by size).
             const char* order = pgsgd::debug_env("PGSGD_TILE_ORDER");
-            HostTiles ht = group_tiles(raw, g->n_nodes, s->region, !(order && !strcmp(order, "region")));
+            bool by_size = !(order && !strcmp(order, "region"));
+            HostTiles ht = group_tiles(raw, g->n_nodes, s->region, by_size);
+            if (!order && !pgsgd::debug_env("PGSGD_TILE_GRID") && !pgsgd::debug_env("PGSGD_TILE_SPLIT")) {
+                uint64_t n_local_min = ~0ull, windows = 0, tiles = 0;
+                for (int colour = 0; colour < 2; ++colour) {
+                    uint64_t n_local = 0;
+                    for (const pgsgd::WorkItem& wi : ht.items[colour])
+                        if (wi.local) { ++n_local; tiles += wi.tile_end - wi.tile_begin; }
+                    if (n_local) n_local_min = std::min(n_local_min, n_local);
+                    windows += n_local;
+                }
+                if (windows && pgsgd_tile_parts_for(n_local_min, tiles / windows, (uint64_t)prop.multiProcessorCount * bpc) > 1) {
+                    by_size = false;
+                    ht = group_tiles(raw, g->n_nodes, s->region, false);
+                }
+            }
             memcpy(s->item_chunk, ht.chunk, sizeof s->item_chunk);
             if (const char* e = pgsgd::debug_env("PGSGD_TILE_LANES")) {
                 const long l = atol(e);
@@ -960,7 +965,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 all.insert(all.end(), ht.items[1].begin(), ht.items[1].end());
                 s->h_items = all;
                 if (const char* e = pgsgd::debug_env("PGSGD_TILE_SPLIT")) s->tile_split_knob = (uint32_t)std::min(256, std::max(1, atoi(e)));
-                s->items_one_run = !(order && !strcmp(order, "region"));
+                s->items_one_run = by_size;
                 rc = build_launch_items(s);
                 if (rc) return fail(rc);
                 S_TRY(hipMalloc(&s->d_tiles, std::max<size_t>(1, ht.tiles.size()) * sizeof(pgsgd::Tile)));
@@ -1429,6 +1434,12 @@ extern "C" int pgsgd_session_tile_parts(const pgsgd_session* s, uint64_t* n_laun
     return s->tiled ? (int)s->tile_split : 0;
 }
 
+// 1: the work items of a colour are in node order, one run per XCD (sessions whose windows are cut into parts); 0: one run by size.
+extern "C" int pgsgd_session_tile_order(const pgsgd_session* s) {
+    if (!s) return PGSGD_E_INVALID;
+    return s->tiled && !s->items_one_run ? 1 : 0;
+}
+
 extern "C" int pgsgd_session_tile_math(const pgsgd_session* s) {
     if (!s) return PGSGD_E_INVALID;
     return s->tile_math;
@@ -1707,10 +1718,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // colour 0's window-less items (tiles of unsorted stretches; usually none) run in a launch of their own
             const uint32_t windowless = colour == 0 ? s->n_windowless : 0;
             ta.n_items = n_items_now[colour] - windowless;
-            if (split && s->items_one_run)
-                for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) ta.chunk[q] = ta.n_items;  // one run
-            else if (split)
-                memcpy(ta.chunk, s->item_chunk_split[colour], sizeof ta.chunk);
+            if (split) memcpy(ta.chunk, s->item_chunk_split[colour], sizeof ta.chunk);  // the runs of the list in parts
             // The far pulls the launch before this one collected are delivered now, right before the windows are staged:
             // an iteration ends with a launch's window-local terms, not with the arrival of a launch's worth of far
             // pulls (each an average of a dozen long-range pulls — noise at the scale of neighbouring nodes until the

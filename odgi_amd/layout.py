@@ -197,7 +197,8 @@ class LayoutSession:
         n_launch = C.c_uint64()
         parts = lib.pgsgd_session_tile_parts(self._h, C.byref(n_launch))
         return dict(tiled=bool(on), warm_per_lane=(on == 2), n_tiles=a.value, n_nonlocal_tiles=b.value, n_work_items=c_.value, region_nodes=r.value, tile_steps=t.value,
-                    fast_math=lib.pgsgd_session_tile_math(self._h) == 1, parts=max(0, parts), n_launch_items=n_launch.value)
+                    fast_math=lib.pgsgd_session_tile_math(self._h) == 1, parts=max(0, parts), n_launch_items=n_launch.value,
+                    xcd_runs=lib.pgsgd_session_tile_order(self._h) == 1)
 
     def split_info(self):
         """dict(split, apply_lanes): whether per-lane iterations run in two passes (a small lane-bound graph: n_streams

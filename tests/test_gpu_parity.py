@@ -572,7 +572,7 @@ def test_synthetic_million_node_properties(oa, orc):
         assert s.n_streams == 256 * 5 * 256          # five workgroups per CU: 123 outbox buckets, 30 KB of LDS
     assert info["tiled"] and not info["warm_per_lane"] and info["n_nonlocal_tiles"] == 0
     assert (info["region_nodes"], info["tile_steps"], info["n_work_items"], info["parts"]) == (256, 224, 3907, 13), info
-    assert 12 * 3907 < info["n_launch_items"] <= 13 * 3907
+    assert 12 * 3907 < info["n_launch_items"] <= 13 * 3907 and info["xcd_runs"]    # ... in node order, one run per XCD
 
 
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
