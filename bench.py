@@ -234,7 +234,14 @@ def main():
         from oracle import oracle as orc
         og = orc.Graph.from_product(g)
         cores = os.cpu_count() or 1
-        _, _, st = orc.layout_hogwild(og, orc.params_from(p), cores, X0, Y0, max_seconds=args.cpu_seconds, fast=True)
+        # the loop's shared coordinates are seq-cst atomic<double>s (path_sgd_layout.cpp:316-363): more threads than one
+        # socket holds can be slower than fewer, so the baseline is the BEST of a quarter, half and all of the host's
+        # hardware threads (a third of the budget each), and the line says which
+        scan = []
+        for t in sorted({max(1, cores // 4), max(1, cores // 2), cores}):
+            _, _, st_t = orc.layout_hogwild(og, orc.params_from(p), t, X0, Y0, max_seconds=max(1.0, args.cpu_seconds / 3), fast=True)
+            scan.append((st_t["terms"] / st_t["seconds"] if st_t["seconds"] > 0 else 0.0, t, st_t))
+        best_rate, best_threads, st = max(scan)
         # the same loop on ONE thread (`-t 1`), a quarter of the budget
         _, _, st1 = orc.layout_hogwild(og, orc.params_from(p), 1, X0, Y0, max_seconds=max(1.0, args.cpu_seconds / 4), fast=True)
         cpu_model = "unknown"
@@ -244,10 +251,12 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         out["cpu_baseline"] = {
-            "value": st["terms"] / st["seconds"] if st["seconds"] > 0 else 0.0,
-            "unit": "terms/s", "cores": cores, "kind": "port",
+            "value": best_rate,
+            "unit": "terms/s", "cores": best_threads, "kind": "port",
             "sample": f"{st['terms']} terms in {st['seconds']:.1f} s of the same workload "
-                      f"({cores} Hogwild threads, fp64, CPU restatement of the reference — upstream is unbuildable here)",
+                      f"({best_threads} Hogwild threads — the best of {[t for _, t, _ in scan]} on a host of {cores} hardware threads — fp64, "
+                      f"CPU restatement of the reference; upstream is unbuildable here)",
+            "thread_scan": [{"threads": t, "value": r} for r, t, _ in scan], "host_threads": cores,
             "single_thread": {"value": st1["terms"] / st1["seconds"] if st1["seconds"] > 0 else 0.0, "cores": 1,
                               "sample": f"{st1['terms']} terms in {st1['seconds']:.1f} s, same loop, one thread (-t 1)"},
             "cpu_model": cpu_model,

@@ -261,7 +261,10 @@ uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
  *   by_region = 2: by region with the EXACT exchange (pgsgd_session_exchange_exact_begin / _end below): an iteration is two
  *                  parts, one per region colour, each followed by an integer exchange — the devices then hold, bit for
  *                  bit, one GPU's coordinates.
- *   by_region -1: by region when that leaves every launch at least a thousand work items per device, by tile otherwise.
+ *   by_region -1: the session's rule, the one both drivers use: by region when that leaves every launch at least a thousand
+ *                  WINDOWS per device (windows, not the parts a one-GPU session cuts them into) — with the exact exchange (2)
+ *                  when the coordinates are fixed-point, the default, with the merge rule (1) otherwise — and by tile (0)
+ *                  when it does not.
  * Returns 1 (sharded by tile), 2 (by region) or 3 (by region, exact) when the session is tiled, 0 when it runs the
  * per-lane kernel (shard the term count instead), < 0 on error.  The tile streams of a sharded session are keyed on (seed, iteration,
  * tile, lane) — stream_offset, which the devices' per-lane streams need to differ, does not enter them. */

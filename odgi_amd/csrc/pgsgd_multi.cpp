@@ -196,12 +196,10 @@ void rank_main(Shared& sh, int r) {
         if (const char* e = pgsgd::debug_env("PGSGD_MULTI_SHARD"))  // test knob: tiles / regions / exact whatever the graph's size
             want = !strcmp(e, "tiles") ? 0 : !strcmp(e, "regions") ? 1 : !strcmp(e, "exact") ? 2 : -1;
         if (want > 0 && info <= 0) want = -1;   // (the knob asks for a way of sharding TILES: a per-lane session shards its term count)
+        // (-1: the session's own rule — by region with the exact exchange when a launch keeps a thousand windows per rank and
+        // the coordinates are fixed-point, by region with the merge rule when they are not, by tile otherwise; the
+        // torch.distributed route, odgi_amd/distributed.py, passes the same -1)
         int rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, want);
-        if (rcs == 2 && want < 0) {  // by region: with the exact exchange (fixed-point coordinates: the default format)
-            int fixed = 0;
-            (void)pgsgd_session_coord_format(s, &fixed, nullptr, nullptr, nullptr);
-            if (fixed) rcs = pgsgd_session_set_shard(s, (uint32_t)r, (uint32_t)G, 2);
-        }
         if (rcs < 0) R_TRY(rcs);
         engine_sharded = rcs > 0;
         exact = rcs == 3;

@@ -1389,8 +1389,9 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
 // Multi-GPU: this session is rank `rank` of `world`.  by_region 0: every work item's tiles are dealt out to the ranks
 // (tile shard); 1: every world-th work item (node region) with all its tiles belongs to this rank — the ranks' private
 // windows are then disjoint, which keeps the one-GPU layout quality, but a launch has only (work items / world) items to
-// fill the GPU with; -1: by region when that still leaves a launch a thousand items per rank (BASELINE config 5 at
-// G = 8), by tile otherwise; 2: by region with the EXACT exchange — pgsgd_session_iteration_part(c, 2) then
+// fill the GPU with; -1: by region when that still leaves a launch a thousand windows per rank (BASELINE config 5 at
+// G = 8) — with the exact exchange when the coordinates are fixed-point (the default format), with the merge rule otherwise —
+// and by tile when it does not; 2: by region with the EXACT exchange — pgsgd_session_iteration_part(c, 2) then
 // runs colour c alone and the caller exchanges integer deltas after each colour (pgsgd_session_exchange_exact_begin / _end):
 // the ranks' coordinates are then, bit for bit, what one GPU computes.  Returns 0: not a tiled session (the caller shards
 // the term count), 1: sharded by tile, 2: by region, 3: by region, exact.
@@ -1400,7 +1401,9 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
 extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region) {
     pgsgd::clear_error();
     if (!s || world == 0 || rank >= world || by_region > 2) return PGSGD_E_INVALID;
-    if (by_region < 0) by_region = s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000 ? 1 : 0;
+    // -1: the one rule both drivers use (pgsgd_multi.cpp and odgi_amd/distributed.py pass -1 and take what comes back).  It counts
+    // WINDOWS (n_items: the session's unsplit work items per colour), not the parts a one-GPU session cuts them into.
+    if (by_region < 0) by_region = !(s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000) ? 0 : s->fmt == pgsgd::kFmtQ32 ? 2 : 1;
     if (by_region == 2 && (!s->tiled || s->fmt != pgsgd::kFmtQ32)) { set_error("the exact exchange needs a tiled session with fixed-point coordinates"); return PGSGD_E_UNSUPPORTED; }
     s->shard_rank = by_region ? rank : 0;
     s->shard_world = by_region ? world : 1;

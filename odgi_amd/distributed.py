@@ -84,17 +84,14 @@ class HipEngine:
         return bool(self.session.tile_info()["warm_per_lane"])
 
     def set_shard(self, rank, world, by_region=None):
-        """by_region None: by node region with the exact exchange when that leaves a launch a thousand work items per
-        rank, by tile otherwise; True / False force region (merge rule) / tile; "exact" forces region with the exact
+        """by_region None: by node region with the exact exchange when that leaves a launch a thousand WINDOWS per
+        rank (fixed-point coordinates; the merge rule otherwise), by tile when it does not — decided by the session, the
+        same rule the C++ driver uses; True / False force region (merge rule) / tile; "exact" forces region with the exact
         exchange (pgsgd_session_set_shard).  True when the engine shards by tile or by region itself (tile kernel):
         iteration() then takes the full term count of a block; False when the caller must shard the term count
         (per-lane kernel)."""
         if by_region is None:
-            ti = self.session.tile_info()
-            items = self.session.tile_items() if ti["tiled"] else None
-            per_colour = min(int(items["n_first"]), len(items["local"]) - int(items["n_first"])) if items is not None else 0
-            fixed = bool(self.session.coord_format()[0])
-            mode = 2 if ti["tiled"] and fixed and per_colour // int(world) >= 1000 else 0
+            mode = -1   # the session's own rule (pgsgd_session_set_shard), the one `odgi layout --gpus N` (pgsgd_multi.cpp) uses too
         else:
             mode = 2 if by_region == "exact" else 1 if by_region else 0
         rc = lib.pgsgd_session_set_shard(self.session._h, int(rank), int(world), mode)

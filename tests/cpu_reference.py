@@ -1,0 +1,108 @@
+"""Committed distributions of the CPU restatement's Hogwild runs (tests/golden/cpu_reference_distributions.json).
+
+The reference's loop is non-deterministic by construction (path_sgd_layout.cpp:120-163: a controller thread polling
+every millisecond; :165-377: lock-free workers), and so is the oracle's restatement of it (orc_layout_hogwild).  A GPU
+test that re-rolls that loop on the GPU box compares against a yardstick that moves from run to run (round 4's red
+record: one 64-thread run landed at 0.1308 where the band had been set on 0.159).  So the yardstick is rolled ONCE, here
+in the build container, by tools/make_cpu_reference_distributions.py (>= 8 runs per configuration), committed, and
+every statistical GPU test reads it: nothing under oracle/ runs a layout during `pytest -m gpu` for these tests (the
+oracle's evaluators — sampled stress, path distance — still score the GPU's layouts, the same code that scored the
+CPU's).
+
+This module also holds the small workloads that both the generator and the tests must build identically."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PATH = os.path.join(GOLDEN, "cpu_reference_distributions.json")
+INIT_SEEDS = (11, 12, 13)       # initial layouts of the fixture configurations (GPU runs use the same three)
+EVAL_PAIRS = 1_000_000          # orc.path_stress_sampled(og, X, Y, EVAL_PAIRS) with its default evaluator seed
+
+
+def many_paths_graph(oa):
+    """3000 nodes, 5000 short paths (1..29 steps, some single-step): more paths than the LDS path table holds."""
+    rs = np.random.RandomState(11)
+    n_nodes, n_paths = 3000, 5000
+    node_len = rs.randint(1, 40, n_nodes).astype(np.uint32)
+    counts = rs.randint(1, 30, n_paths)           # includes single-step paths
+    first = np.r_[0, np.cumsum(counts)].astype(np.uint64)
+    starts = rs.randint(0, n_nodes - 40, n_paths)
+    handles = np.concatenate([(2 * (s + np.arange(c)) + (rs.rand(c) < 0.1)).astype(np.uint32) for s, c in zip(starts, counts)])
+    return oa.Graph.from_arrays(node_len, first, handles)
+
+
+def synthetic_300k(oa):
+    """The 300k-node / 24-path synthetic pangenome of the tile-vs-per-lane test."""
+    return oa.Graph.synthetic(300_000, 24, seed=7)
+
+
+def shuffled_linear_graph(oa, n_nodes=4000, n_paths=6, seed=3):
+    """A linear pangenome whose node ranks are a random permutation of their true order: the 1D SGD (`odgi sort -Y`)
+    has to recover the order from the paths.  Returns (graph, true_order)."""
+    rs = np.random.RandomState(seed)
+    true_order = rs.permutation(n_nodes)          # true position -> node rank
+    node_len = rs.randint(1, 20, n_nodes).astype(np.uint32)
+    handles, first = [], [0]
+    for _ in range(n_paths):
+        keep = rs.rand(n_nodes) > 0.05            # each path skips 5 % of the nodes
+        h = (2 * true_order[keep]).astype(np.uint32)
+        handles.append(h)
+        first.append(first[-1] + len(h))
+    g = oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
+    return g, true_order
+
+
+def order_quality(order, true_order):
+    """Spearman-like: |correlation| between recovered position and true position of every node."""
+    n = len(order)
+    pos = np.empty(n)
+    pos[np.asarray(order, dtype=np.int64)] = np.arange(n)     # node rank -> recovered position
+    true_pos = np.empty(n)
+    true_pos[true_order] = np.arange(n)                        # node rank -> true position
+    return abs(np.corrcoef(pos, true_pos)[0, 1])
+
+
+def key(name, p, init="d"):
+    """One configuration = graph name, initial layout mode and every parameter the CPU loop reads."""
+    return (f"{name}|init={init}|theta={p.theta:g}|K={p.cooling_start:g}|iters={p.iter_max}|terms={p.min_term_updates}"
+            f"|space={p.space}|space_max={p.space_max}|quant={p.space_quantization_step}")
+
+
+def summarize(values):
+    v = np.asarray(values, dtype=np.float64)
+    med = float(np.median(v))
+    return {"runs": [float(x) for x in v], "n": int(len(v)), "mean": float(v.mean()), "sigma": float(v.std(ddof=1)) if len(v) > 1 else 0.0,
+            "min": float(v.min()), "max": float(v.max()), "median": med,
+            # robust sigma: 1.4826 x median absolute deviation (LPA's CPU runs have a heavy upper tail: 0.83 .. 2.2)
+            "sigma_robust": float(1.4826 * np.median(np.abs(v - med)))}
+
+
+_DB = None
+
+
+def load():
+    global _DB
+    if _DB is None:
+        with open(PATH) as f:
+            _DB = json.load(f)
+    return _DB
+
+
+def entry(name, p, init="d"):
+    """The committed distribution of a configuration; a missing one is an error, never a silent re-roll."""
+    db, k = load(), key(name, p, init)
+    if k not in db["entries"]:
+        raise KeyError(f"no committed CPU reference distribution for {k!r}: run tools/make_cpu_reference_distributions.py "
+                       f"(have: {sorted(db['entries'])[:4]} ...)")
+    return db["entries"][k]
+
+
+def band(dist, up=0.10, down=0.10):
+    """Two-sided acceptance interval for the MEAN of the GPU's runs against a committed CPU distribution:
+    centre = the CPU runs' median (their mean where the distribution has no tail makes no difference; on LPA the mean
+    is pulled up by runs that never unfold), half-width = max(3 robust sigma, the stated fraction of the centre)."""
+    c, s3 = dist["median"], 3.0 * dist["sigma_robust"]
+    return c - max(s3, down * c), c + max(s3, up * c)

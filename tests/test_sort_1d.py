@@ -4,33 +4,15 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN  # noqa: F401
+import cpu_reference as cr
 
 
 def _shuffled_linear_graph(oa, n_nodes=4000, n_paths=6, seed=3):
-    """A linear pangenome whose node ranks are a random permutation of their true order: the 1D SGD
-    has to recover the order from the paths."""
-    rs = np.random.RandomState(seed)
-    true_order = rs.permutation(n_nodes)          # true position -> node rank
-    node_len = rs.randint(1, 20, n_nodes).astype(np.uint32)
-    handles, first = [], [0]
-    for _ in range(n_paths):
-        keep = rs.rand(n_nodes) > 0.05            # each path skips 5 % of the nodes
-        h = (2 * true_order[keep]).astype(np.uint32)
-        handles.append(h)
-        first.append(first[-1] + len(h))
-    g = oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
-    return g, true_order
+    return cr.shuffled_linear_graph(oa, n_nodes, n_paths, seed)
 
 
-def _order_quality(order, true_order):
-    """Spearman-like: |correlation| between recovered position and true position of every node."""
-    n = len(order)
-    pos = np.empty(n)
-    pos[np.asarray(order, dtype=np.int64)] = np.arange(n)     # node rank -> recovered position
-    true_pos = np.empty(n)
-    true_pos[true_order] = np.arange(n)                        # node rank -> true position
-    return abs(np.corrcoef(pos, true_pos)[0, 1])
+_order_quality = cr.order_quality
 
 
 def test_sort_defaults_follow_sort_main(oa, graphs):
@@ -107,10 +89,12 @@ def test_1d_two_pass_iterations_of_small_lane_bound_graphs(oa, orc, graphs, ogra
                 assert st["iterations"] == p.iter_max + 1 and st["term_updates"] == (p.iter_max + 1) * p.min_term_updates
                 vals.append((orc.sort_stress(og, X, 300000), st["kernel_ms"], st["n_streams"], st["apply_lanes"]))
             res[form] = vals
-        Xo, _ = orc.sort_hogwild(og, orc.params_from(sort_params_defaults(g)), 4, orc.sort_initial(og))
-        s_cpu = orc.sort_stress(og, Xo, 300000)
+        # the CPU restatement's side is committed (nine sort_hogwild runs: tests/golden/cpu_reference_distributions.json), not re-rolled
+        cpu = cr.entry("1d:" + name, sort_params_defaults(g), "1d")["stress"]
+        s_cpu = cpu["median"]
         a, b = float(np.mean([v[0] for v in res["two passes"]])), float(np.mean([v[0] for v in res["single pass"]]))
-        print(f"1D {name}: stress two passes {[round(v[0], 3) for v in res['two passes']]} single pass {[round(v[0], 3) for v in res['single pass']]} cpu {s_cpu:.3f}; "
+        print(f"1D {name}: stress two passes {[round(v[0], 3) for v in res['two passes']]} single pass {[round(v[0], 3) for v in res['single pass']]} "
+              f"cpu median {s_cpu:.3f} range {cpu['min']:.3f}..{cpu['max']:.3f} n {cpu['n']}; "
               f"kernel ms {np.mean([v[1] for v in res['two passes']]):.1f} / {np.mean([v[1] for v in res['single pass']]):.1f}; "
               f"streams {res['two passes'][0][2]} lanes {res['two passes'][0][3]}")
         assert 0.90 * b <= a <= 1.10 * b and a <= 1.25 * s_cpu + 0.02
@@ -123,9 +107,9 @@ def test_1d_layout_and_order_match_oracle(oa, orc):
     og = orc.Graph.from_product(g)
     p = sort_params_defaults(g, iter_max=30, min_term_updates=10 * g.n_steps, device=0)
     order, X, st = path_linear_sgd_order(g, p)
-    Xo, _ = orc.sort_hogwild(og, orc.params_from(p), 4, orc.sort_initial(og))
-    s_gpu, s_cpu = orc.sort_stress(og, X, 500000), orc.sort_stress(og, Xo, 500000)
-    q_gpu, q_cpu = _order_quality(order, true_order), _order_quality(np.argsort(Xo, kind="stable"), true_order)
+    cpu = cr.entry("1d:shuffled-20000", sort_params_defaults(g, iter_max=30, min_term_updates=10 * g.n_steps), "1d")   # committed CPU runs
+    s_gpu, s_cpu = orc.sort_stress(og, X, 500000), cpu["stress"]["median"]
+    q_gpu, q_cpu = _order_quality(order, true_order), cpu["order_quality"]["median"]
     print(f"1D: stress gpu {s_gpu:.4f} cpu {s_cpu:.4f}; order quality gpu {q_gpu:.5f} cpu {q_cpu:.5f}; streams {st['n_streams']}")
     assert st["iterations"] == 31 and np.isfinite(X).all()
     assert s_gpu <= 1.25 * s_cpu + 0.02 and q_gpu > 0.99 and q_gpu >= q_cpu - 0.005

@@ -37,6 +37,14 @@ for rep in range(reps):
                     total = torch.stack(bufs).sum(0)
                     for e in engines: e.exchange_end(total, G)
                 for e in engines: e.sync()
+        # the far pulls of every rank's last launch: delivered, then merged like any other move (DistributedLayout.finish)
+        for e in engines: e.flush()
+        if G > 1:
+            for e, b in zip(engines, bufs): e.exchange_begin(b)
+            torch.cuda.synchronize()
+            total = torch.stack(bufs).sum(0)
+            for e in engines: e.exchange_end(total, G)
+        for e in engines: e.sync()
         ms, n = engines[0].session.kernel_time()
         X, Y = engines[0].result()
         print(json.dumps(dict(exp="ranks_tiled", shard=mode, rep=rep, G=G, exchanges_per_iteration=blocks, stress=oa.path_stress(g, X, Y, 2_000_000, seed=1),
