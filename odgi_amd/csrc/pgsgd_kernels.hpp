@@ -1090,8 +1090,18 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const uint32_t* step_ha
     }
 }
 
-// recs2 (tile kernel only, may be null): 32-byte records whose first half is the same record and whose second half
-// is refreshed with the node's coordinates before every tile launch (snapshot_kernel)
+// The tile kernel's gather records (recs2).  A step has a static 16-byte piece — the record {handle, length, position} — and a
+// 16-byte snapshot piece, the coordinate words of its node's two ends (the end the step enters first in front).  They are laid
+// out in groups of FOUR steps per 128-byte line: [s0 s1 s2 s3 | n0 n1 n2 n3] — static pieces in the first 64-byte unit,
+// snapshot pieces in the second.  A partner outside the tile still costs ONE line (a read request moves a whole 128-byte line:
+// profiles/r04/pmc_calibration.json), and whoever refreshes snapshots — a tile for its own steps, snapshot_kernel for all of
+// them — writes whole 64-byte units of snapshot pieces only: half the bytes of the round-4 layout ({s, n} pairs of 32 bytes,
+// where leaving the static halves out would have cost a read-for-ownership of every unit).
+__host__ __device__ inline uint64_t recs2_pieces(uint64_t n_steps) { return ((n_steps + 3) / 4) * 8; }   // uint4 pieces in the array
+__host__ __device__ inline uint64_t recs2_static_piece(uint64_t k) { return ((k >> 2) << 3) | (k & 3u); }
+__host__ __device__ inline uint64_t recs2_snap_piece(uint64_t k) { return ((k >> 2) << 3) | 4u | (k & 3u); }
+// recs2 (tile kernel only, may be null): the static pieces are the same records; the snapshot pieces are filled by
+// snapshot_kernel before the first tile launch
 // bad_handle: set when a step names a node rank outside the graph (the caller's arrays are not trusted: such a step
 // would index node_len and, later, the coordinates out of bounds)
 __global__ void build_step_records(const uint32_t* step_handle, const uint64_t* step_pos, const uint32_t* node_len, uint32_t n_nodes,
@@ -1106,8 +1116,8 @@ __global__ void build_step_records(const uint32_t* step_handle, const uint64_t* 
         const uint4 r = make_uint4(h, node_len[h >> 1], (uint32_t)pos, (uint32_t)(pos >> 32));
         recs[k] = r;
         if (recs2) {
-            recs2[2 * k] = r;
-            recs2[2 * k + 1] = make_uint4(0, 0, 0, 0);
+            recs2[recs2_static_piece(k)] = r;
+            recs2[recs2_snap_piece(k)] = make_uint4(0, 0, 0, 0);
         }
     }
 }

@@ -84,7 +84,8 @@ struct pgsgd_session {
     bool tile_tail = false;                 // debug knob PGSGD_TILE_TAIL: the launches record their workgroups' lifetimes
     unsigned long long* d_far = nullptr;  // [2 colours][2]: far-partner updates of the last two launches of each colour
     uint32_t far_launches[2] = {0, 0};    // tile launches so far, per colour (parity selects the counter a launch writes)
-    uint4* d_recs2 = nullptr;             // [2S] 32-byte step records: {handle, len, pos} + coordinate snapshot
+    uint4* d_recs2 = nullptr;             // the tile kernel's gather records: static + snapshot pieces, four steps per 128-byte group (pgsgd_kernels.hpp)
+    uint32_t* d_step_handle = nullptr;    // [S] step handles, kept by a tiled session for snapshot_kernel
     std::vector<uint64_t> ob_bucket_steps;  // path steps on the nodes of each outbox bucket (sizes the pool shares)
     std::vector<uint32_t> node_steps;       // path steps on every node (automatic stream count only)
     uint32_t* d_node_steps = nullptr;       // uploaded when the hot-node learning-rate cap is active
@@ -243,7 +244,9 @@ static uint32_t auto_streams(const pgsgd_session* s, int cus, int blocks_per_cu)
     // in flight on the busiest node and diverge beyond; the cap is 2.  (Hogwild stores never
     // diverge but lose quality at about the same point, so they share the rule.)
     const uint64_t full = (uint64_t)cus * (uint64_t)blocks_per_cu * pgsgd::kBlock;
-    const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
+    uint64_t in_flight = 2;
+    if (const char* e = pgsgd::debug_env("PGSGD_LANE_CAP")) in_flight = (uint64_t)std::min(64, std::max(1, atoi(e)));  // experiment knob (tools/gpu_lane_cap.py)
+    const uint64_t cap = in_flight * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
     uint64_t n = std::min(full, std::max<uint64_t>(cap, 64));
     n = std::max<uint64_t>(64, (n / 64) * 64);
     if (n >= pgsgd::kBlock) n = (n / pgsgd::kBlock) * pgsgd::kBlock;
@@ -993,7 +996,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         uint32_t* d_len = nullptr;
         uint64_t* d_pos = nullptr;
         S_TRY(hipMalloc(&s->d_recs, g->n_steps * sizeof(uint4)));
-        if (s->tiled) S_TRY(hipMalloc(&s->d_recs2, 2 * g->n_steps * sizeof(uint4)));
+        if (s->tiled) S_TRY(hipMalloc(&s->d_recs2, pgsgd::recs2_pieces(g->n_steps) * sizeof(uint4)));
         S_TRY(hipMalloc(&d_pos, g->n_steps * sizeof(uint64_t)));
         S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
         S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
@@ -1017,6 +1020,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         }
         (void)hipFree(d_pos);
         (void)hipFree(d_len);
+    }
+    if (s->tiled) {  // the snapshot pass reads the handles (4 bytes per step), not the records: the session keeps them
+        s->d_step_handle = d_handle;
+        d_handle = nullptr;
     }
     timer.lap("step records (upload + pack)");
     S_TRY(hipMalloc(&s->d_path_first, (g->n_paths + 1) * sizeof(uint64_t)));
@@ -1126,6 +1133,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_far) (void)hipFree(s->d_far);
     if (s->d_clock) (void)hipFree(s->d_clock);
     if (s->d_recs2) (void)hipFree(s->d_recs2);
+    if (s->d_step_handle) (void)hipFree(s->d_step_handle);
     if (s->ob.pool) (void)hipFree(s->ob.pool);
     if (s->ob.next) (void)hipFree(s->ob.next);
     if (s->ob.fill) (void)hipFree(s->ob.fill);
@@ -1741,7 +1749,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const bool sharded = s->shard_world > 1 || s->tshard_world > 1 || tile_parts > 1 || s->tile_substeps > 1 || s->snapshot_pass || exact;  // this launch runs a share of the tiles
             ta.recs2_out = sharded ? nullptr : s->d_recs2;
             if (!snapshot_taken && (sharded || s->snap_stale)) {
-                hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_recs, s->d_coords, s->n_steps, s->d_recs2);
+                hipLaunchKernelGGL(pgsgd::snapshot_kernel, dim3(snap_grid), dim3(256), 0, s->stream, s->d_step_handle, s->d_coords, s->n_steps, s->d_recs2);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());
                 snapshot_taken = true;

@@ -127,7 +127,6 @@ __device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg
     const int64_t qy = (int64_t)(msg << (64u - ob.shift - 2u * ob.qbits)) >> (64u - ob.qbits);
     return (uint64_t)qx + ((uint64_t)qy << 32);
 }
-
 constexpr uint32_t kItemQueues = 8;
 constexpr uint32_t kNoItem = 0xffffffffu;
 constexpr int kTileBlock = 256;
@@ -157,7 +156,7 @@ struct TileArgs {
     uint32_t far_from_prev;
     const unsigned long long* far_prev;
     unsigned long long* far_count;     // partner ends updated outside the window, this launch
-    const uint4* recs2;                // [2S] step records with the coordinate snapshot: {handle,len,pos}, {w_first, w_second}
+    const uint4* recs2;                // gather records with the coordinate snapshot, four steps per 128-byte group (recs2_static_piece / recs2_snap_piece)
     uint4* recs2_out;                  // the same array, written by a tile for its own steps when its terms are done; null: a
                                        // sharded session, whose records are all rewritten by snapshot_kernel before a launch
     uint64_t seed_base;                // of the tile streams (tile_stream_seed)
@@ -852,8 +851,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     const uint32_t kb = pstart + b_rank;
                     Qw.kb_off = kb - t0;
                     if (!(Qw.kb_off < t.n)) {
-                        Qw.rb_g = ta.recs2[2 * (uint64_t)kb];
-                        Qw.snapw = reinterpret_cast<const unsigned long long*>(ta.recs2)[4 * (uint64_t)kb + 2 + ((Kr.flags >> 28) & 1u)];
+                        Qw.rb_g = ta.recs2[recs2_static_piece(kb)];
+                        Qw.snapw = reinterpret_cast<const unsigned long long*>(ta.recs2)[2 * recs2_snap_piece(kb) + ((Kr.flags >> 28) & 1u)];
                     }
                 }
                 return Qw;
@@ -983,27 +982,24 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 K1 = pick_stage(j + 1);
                 send(m);
             }
-            // The tile's terms are done: rewrite the snapshot records of its OWN steps — the static half from the LDS copy,
-            // the coordinates of the step's node from the window (a tile with a window has all its nodes in it) — so that
+            // The tile's terms are done: rewrite the snapshot pieces of its OWN steps' records — the coordinates of the step's
+            // node from the window (a tile with a window has all its nodes in it) — so that
             // a partner outside somebody's window is seen as its tile last left it, this iteration or the one before,
             // and no pass over all the records is needed between iterations (snapshot_kernel: 0.45 ms per iteration at
-            // config 4, a twentieth of the iteration).  Consecutive lanes write consecutive 16-byte pieces of the tile's 32 n
-            // bytes: whole 64-byte units per store instruction.  Readers in other workgroups may see a record's old or new
+            // config 4, a twentieth of the iteration).  Four consecutive lanes write the four snapshot pieces of a 128-byte group:
+            // one whole 64-byte unit (only the units at a tile's two ends are shared with the neighbouring tile), and the static
+            // pieces are never written again (recs2_snap_piece).  Readers in other workgroups may see a record's old or new
             // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
             // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
             uint4* const recs2_out = TILE_COLD(ta.recs2_out);
             if (recs2_out && (TILE_COLD(ta.snap_every) <= 1u || ((uint32_t)a.epoch + ti) % TILE_COLD(ta.snap_every) == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
                 __syncthreads();
-                uint4* dst = recs2_out + 2 * (uint64_t)t.t0;
-                for (uint32_t piece = threadIdx.x; piece < 2 * t.n; piece += blockDim.x) {
-                    uint4 v = trec[piece >> 1];
-                    if (piece & 1u) {  // the two ends of the step's node, the one the step enters first in front
-                        const uint32_t e0 = v.x;
-                        const uint64_t w0 = LOCAL ? win[e0 - wbase] : load_word<COORD_LOAD>(c.coords, e0);
-                        const uint64_t w1 = LOCAL ? win[(e0 ^ 1u) - wbase] : load_word<COORD_LOAD>(c.coords, e0 ^ 1u);
-                        v = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
-                    }
-                    dst[piece] = v;  // (plain stores; write-through (sc1) and non-temporal ones measured the same: profiles/r03/bench_variants_call4.txt)
+                for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) {  // the two ends of the step's node, the one the step enters first in front
+                    const uint32_t e0 = trec[i].x;
+                    const uint64_t w0 = LOCAL ? win[e0 - wbase] : load_word<COORD_LOAD>(c.coords, e0);
+                    const uint64_t w1 = LOCAL ? win[(e0 ^ 1u) - wbase] : load_word<COORD_LOAD>(c.coords, e0 ^ 1u);
+                    // (plain stores; write-through (sc1) and non-temporal ones measured the same: profiles/r03/bench_variants_call4.txt)
+                    recs2_out[recs2_snap_piece((uint64_t)t.t0 + i)] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                 }
             }
         }
@@ -1064,32 +1060,20 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(TILE_COLD(c.frame_flag), 1u);
 }
 
-// Every 32-byte step record rewritten in one pass — the static half from the 16-byte records, the second half with the
-// coordinates of the two ends of the step's node (the end the step enters first) — so that a partner outside the window
-// costs one gather, not a record gather plus a dependent coordinate load.  Run when the records do not follow from the
-// tile kernel's own writes (sgd_tile_kernel rewrites a tile's records when its terms are done): before a session's first
-// tile launch, after iterations of the per-lane kernel, after the frame was widened or the coordinates were merged with
-// other devices', and before every launch of a sharded session (which runs only its share of the tiles).  Whole-line
-// writes (writing only the second halves costs a read-for-ownership of every line: 0.70 against 0.47 ms at 4.7e7
-// steps, profiles/r02/microbench_r2b.jsonl).
-__global__ __launch_bounds__(256) void snapshot_kernel(const uint4* recs, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
-    // A lane builds the record of one step; the 8 KiB a workgroup builds go out through LDS so that one store
-    // instruction writes 64 consecutive 16-byte pieces — whole 64-byte units.  (A lane storing its own two halves
-    // writes half of every unit per instruction.)
-    __shared__ uint4 stage[512];
-    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_steps; k0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t k = k0 + threadIdx.x;
-        if (k < n_steps) {
-            const uint4 r = recs[k];
-            const uint4 pr = *reinterpret_cast<const uint4*>(coords + (r.x & ~1u));  // both ends of the node, 16-byte aligned
-            stage[2 * threadIdx.x] = r;
-            stage[2 * threadIdx.x + 1] = (r.x & 1u) ? make_uint4(pr.z, pr.w, pr.x, pr.y) : pr;
-        }
-        __syncthreads();
-        const uint64_t left = n_steps - k0, pieces = left < 256 ? 2 * left : 512;
-        if (threadIdx.x < pieces) recs2[2 * k0 + threadIdx.x] = stage[threadIdx.x];
-        if (threadIdx.x + 256 < pieces) recs2[2 * k0 + 256 + threadIdx.x] = stage[256 + threadIdx.x];
-        __syncthreads();
+// The snapshot pieces of all step records rewritten in one pass — the coordinates of the two ends of the step's node (the
+// end the step enters first in front) — so that a partner outside the window costs one gather, not a record gather plus a
+// dependent coordinate load.  Run when the pieces do not follow from the tile kernel's own writes (sgd_tile_kernel rewrites a
+// tile's when its terms are done): before a session's first tile launch, after iterations of the per-lane kernel, after the
+// frame was widened or the coordinates were merged with other devices', and once per iteration of a sharded session (which
+// runs only its share of the tiles).  Reads the 4-byte step handles and the (cache-resident) coordinates, writes the 64-byte
+// units of snapshot pieces: 20 bytes of memory traffic per step where the round-4 layout's pass read the 16-byte records and
+// wrote whole 32-byte records (48 bytes per step: 0.45 ms at config 4's 4.7e7 steps).
+__global__ __launch_bounds__(256) void snapshot_kernel(const uint32_t* step_handle, const uint64_t* coords, uint64_t n_steps, uint4* recs2) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * 256) {
+        const uint32_t h = step_handle[k];
+        const uint4 pr = *reinterpret_cast<const uint4*>(coords + (h & ~1u));  // both ends of the node, 16-byte aligned
+        // (consecutive lanes, consecutive steps: every store instruction covers whole 64-byte units of snapshot pieces)
+        recs2[recs2_snap_piece(k)] = (h & 1u) ? make_uint4(pr.z, pr.w, pr.x, pr.y) : pr;
     }
 }
 
@@ -1122,6 +1106,10 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     const uint32_t* fill = ob.fill + ob.chunk0[b];
     static_assert(kObChunk == 128, "one chunk = 64 lanes x 2 messages");
     // (the fill words of a pass are loaded during the pass before: a pass then waits for memory once, not twice)
+    // Round 5 looked for what the drain waits for (4.4 TB/s of a 6.2 TB/s streaming ceiling, 9 % of a step): not the loads
+    // in flight (16 or 24 chunks per wave and pass: the same, or slower with spills), not the vector instructions (a 32-bit
+    // unpack without the three variable 64-bit shifts: the same), not the parts per bucket (four: slower) — what remains is
+    // the LDS adds: one workgroup per CU sends ~21 000 wave-wide 64-bit atomics through one LDS (profiles/r05/NOTES.md).
     constexpr int kU = 8;  // chunks per wave and pass
     uint32_t f[kU];
 #pragma unroll
