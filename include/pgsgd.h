@@ -22,6 +22,17 @@ extern "C" {
 #endif
 
 #define PGSGD_VERSION 1
+/* ABI version: bumped whenever a struct of this header grows, an entry point is removed, or one changes what it does to the
+ * session.  A binding compares pgsgd_abi_version() with the PGSGD_ABI_VERSION it was built against, and the sizes of the
+ * structs it passes with pgsgd_abi_struct_sizes(), ONCE at load time (odgi_amd/_lib.py does; INTEGRATION.md section 6 lists what
+ * changed at each version).  5: pgsgd_stats grew by `relabeled` and `tiled` (56 -> 64 bytes: a caller built against the
+ * older header would have its stack overwritten by the library's memset of the whole struct);
+ * pgsgd_session_download_* deliver the far pulls still waiting before they read (pgsgd_session_peek_* read the words as
+ * they are); pgsgd_tile_region_for is gone; pgsgd_session_set_shard(.., -1) chooses the exact exchange itself. */
+#define PGSGD_ABI_VERSION 5
+int pgsgd_abi_version(void);
+/* sizeof(pgsgd_graph_view), sizeof(pgsgd_params), sizeof(pgsgd_stats) as the LIBRARY was built (any pointer may be NULL) */
+void pgsgd_abi_struct_sizes(size_t* graph_view, size_t* params, size_t* stats);
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define PGSGD_OK              0

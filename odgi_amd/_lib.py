@@ -47,6 +47,29 @@ class Stats(C.Structure):
                 ("frame_doublings", u32), ("apply_lanes", u32), ("relabeled", u32), ("tiled", u32)]
 
 
+ABI_VERSION = 5   # include/pgsgd.h: PGSGD_ABI_VERSION this binding was written against
+
+
+def _check_abi():
+    """Once, at load time: the library's ABI version and the sizes of the structs this binding passes by pointer.  A library
+    built from another header would read or write past them (pgsgd_layout_run memsets the whole pgsgd_stats)."""
+    try:
+        lib.pgsgd_abi_version.restype = C.c_int
+        got = lib.pgsgd_abi_version()
+    except AttributeError:
+        raise ImportError(f"{LIB_PATH} predates PGSGD_ABI_VERSION: rebuild it from these sources (make -C odgi_amd/csrc)")
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {got}, this binding expects {ABI_VERSION}: rebuild the library")
+    sizes = [C.c_size_t(), C.c_size_t(), C.c_size_t()]
+    lib.pgsgd_abi_struct_sizes.restype = None
+    lib.pgsgd_abi_struct_sizes(C.byref(sizes[0]), C.byref(sizes[1]), C.byref(sizes[2]))
+    want = (C.sizeof(GraphView), C.sizeof(Params), C.sizeof(Stats))
+    if tuple(v.value for v in sizes) != want:
+        raise ImportError(f"struct sizes differ: library {[v.value for v in sizes]}, binding {list(want)} (graph view, params, stats)")
+
+
+_check_abi()
+
 FLAG_COORD_LOAD_PLAIN = 0x1
 FLAG_FP32_ATOMICS = 0x2
 FLAG_HOGWILD_STORES = 0x4

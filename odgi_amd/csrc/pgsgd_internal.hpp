@@ -101,6 +101,10 @@ inline void progress_line(const char* banner, uint64_t completed, uint64_t total
             total ? 100.0 * (double)completed / (double)total : 100.0, rate, e[0], e[1], e[2], e[3], r[0], r[1], r[2], r[3]);
 }
 
+// A snapshot between iterations (path_sgd_layout.cpp:379-408) written under the CALLER's node ranks: a run that laid the graph
+// out under ranks by path position (pgsgd_layout_run: new_rank_of_old) names its snapshots back, so that `-u` changes
+// neither the kernel a graph runs nor what the files mean.  new_rank_of_old null: the coordinates are written as they are.
+int write_snapshot(const char* name, uint64_t n_nodes, const float* x, const float* y, const uint32_t* new_rank_of_old);
 }  // namespace pgsgd
 
 struct pgsgd_graph {

@@ -128,6 +128,7 @@ struct Shared {
     // what rank 0 found when it set its session up; the ranks' sessions are built from the same graph and layout, so
     // it holds for all of them (and a rank whose set-up failed never uses it: everybody leaves after the first barrier)
     bool tiled = false, warm_per_lane = false;
+    const uint32_t* snapshot_names = nullptr;  // new_rank_of_old of a run under renamed node ranks: snapshots go out under the caller's
     const float* X0;
     const float* Y0;
     float* X;
@@ -335,7 +336,7 @@ void rank_main(Shared& sh, int r) {
             R_TRY(pgsgd_session_peek_coords(s, sx.data(), sy.data()));  // rank 0's copy = the merged coordinates, as they are between iterations
             const std::string name = std::string(p0.snapshot_prefix) + std::to_string(it + 1);
             fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");
-            if (!sh.rc[r]) R_TRY(pgsgd_write_lay_f32(name.c_str(), 2 * N, sx.data(), sy.data()));
+            if (!sh.rc[r]) R_TRY(pgsgd::write_snapshot(name.c_str(), N, sx.data(), sy.data(), sh.snapshot_names));
         }
     }
     if (r == 0 && p0.progress) fprintf(stderr, "\n");
@@ -369,7 +370,7 @@ void rank_main(Shared& sh, int r) {
 }  // namespace
 
 // X,Y as in pgsgd_layout_run (fp32) or, when Xd/Yd are given, doubles out (pgsgd_layout_run_f64).
-int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
+int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats, const uint32_t* snapshot_names) {
     pgsgd::clear_error();
     if (stats) memset(stats, 0, sizeof *stats);
     const bool forced_single = p && p->n_devices == 1 && pgsgd::debug_env("PGSGD_MULTI_FORCE") != nullptr;
@@ -388,6 +389,7 @@ int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     Shared sh(G);
     sh.g = g;
     sh.p = p;
+    sh.snapshot_names = snapshot_names;
     sh.devices.resize(G);
     const int first = p->device < 0 ? 0 : p->device;
     for (int r = 0; r < G; ++r) sh.devices[r] = host_reduce ? (first + r) % count : first + r;  // virtual ranks may share a GPU

@@ -2116,7 +2116,7 @@ extern "C" int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t
 int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);
 
 static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
-int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
+int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats, const uint32_t* snapshot_names);
 
 extern "C" int pgsgd_layout_run(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, pgsgd_stats* stats) {
     return layout_run_impl(g, p, X, Y, nullptr, nullptr, stats);
@@ -2134,7 +2134,7 @@ extern "C" int pgsgd_layout_run_f64(const pgsgd_graph_view* g, const pgsgd_param
 }
 
 namespace pgsgd { double step_rank_disorder(const pgsgd_graph_view* g, const uint32_t* new_rank_of_old, uint32_t reach); }  // pgsgd_host.cpp
-static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
+static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats, const uint32_t* snapshot_names);
 
 // The run under node ranks that follow the paths, when the caller's do not (pgsgd_graph_path_order; include/pgsgd.h:
 // PGSGD_FLAG_NO_RELABEL): node lengths, step handles and the initial layout are renamed, the run is the usual one, the
@@ -2146,9 +2146,9 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     if (!g || !p || !X || !Y) return PGSGD_E_INVALID;
     int rc = pgsgd_validate_view(g);
     if (rc) return rc;
-    const bool may_rename = !(p->flags & (PGSGD_FLAG_NO_RELABEL | PGSGD_FLAG_NO_TILES)) && !(p->snapshot && p->snapshot_prefix) && g->n_nodes >= 4096 &&
+    const bool may_rename = !(p->flags & (PGSGD_FLAG_NO_RELABEL | PGSGD_FLAG_NO_TILES)) && g->n_nodes >= 4096 &&
                             g->n_steps >= 2 && g->n_steps < 0xffffffffull;
-    if (!may_rename || pgsgd::step_rank_disorder(g, nullptr, 128) <= 0.02) return layout_run_named(g, p, X, Y, Xd, Yd, stats);
+    if (!may_rename || pgsgd::step_rank_disorder(g, nullptr, 128) <= 0.02) return layout_run_named(g, p, X, Y, Xd, Yd, stats, nullptr);
     pgsgd::PhaseTimer timer;
     const uint64_t N = g->n_nodes, S = g->n_steps;
     std::vector<uint32_t> new_of_old(N);
@@ -2157,7 +2157,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     if (rc) return rc;
     if (!(d1 <= 0.5 * d0)) {  // the paths themselves do not agree on an order: nothing to gain
         if (p->progress) fprintf(stderr, "[odgi::path_linear_sgd_layout] node ranks do not follow the paths (%.1f %% of steps jump) and no order does (%.1f %%): per-lane kernel\n", 100 * d0, 100 * d1);
-        return layout_run_named(g, p, X, Y, Xd, Yd, stats);
+        return layout_run_named(g, p, X, Y, Xd, Yd, stats, nullptr);
     }
     if (p->progress) fprintf(stderr, "[odgi::path_linear_sgd_layout] node ranks do not follow the paths (%.1f %% of steps jump): laying the graph out under ranks by path position (%.1f %%)\n", 100 * d0, 100 * d1);
     std::vector<uint32_t> len2(N), handle2(S);
@@ -2178,7 +2178,7 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     timer.lap("node ranks by path position");
     std::vector<double> Xd2, Yd2;
     if (Xd) { Xd2.resize(2 * N); Yd2.resize(2 * N); }
-    rc = layout_run_named(&g2, p, X2.data(), Y2.data(), Xd ? Xd2.data() : nullptr, Xd ? Yd2.data() : nullptr, stats);
+    rc = layout_run_named(&g2, p, X2.data(), Y2.data(), Xd ? Xd2.data() : nullptr, Xd ? Yd2.data() : nullptr, stats, new_of_old.data());
     if (rc) return rc;
     for (uint64_t i = 0; i < N; ++i) {
         const uint64_t n = new_of_old[i];
@@ -2194,7 +2194,8 @@ static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, flo
     return PGSGD_OK;
 }
 
-static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats) {
+// snapshot_names: new_rank_of_old of a run under renamed node ranks (snapshots are written under the caller's), or null
+static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats, const uint32_t* snapshot_names) {
     int rc = PGSGD_OK;
     // path_sgd_layout.cpp:64-74: nothing to do unless some path has more than one step
     bool multi = false;
@@ -2204,7 +2205,7 @@ static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, fl
         return pick_device(p->device, &dev);
     }
     // pgsgd_multi.cpp (PGSGD_MULTI_FORCE, a test knob: a one-device run through the multi-GPU driver and a one-rank RCCL communicator)
-    if (p->n_devices > 1 || (p->n_devices == 1 && pgsgd::debug_env("PGSGD_MULTI_FORCE"))) return pgsgd_layout_run_multi(g, p, X, Y, Xd, Yd, stats);
+    if (p->n_devices > 1 || (p->n_devices == 1 && pgsgd::debug_env("PGSGD_MULTI_FORCE"))) return pgsgd_layout_run_multi(g, p, X, Y, Xd, Yd, stats, snapshot_names);
     const auto t0 = std::chrono::steady_clock::now();
     pgsgd::PhaseTimer timer;
     pgsgd_session* s = nullptr;
@@ -2248,7 +2249,7 @@ static int layout_run_named(const pgsgd_graph_view* g, const pgsgd_params* p, fl
             if (rc) break;
             const std::string name = std::string(p->snapshot_prefix) + std::to_string(it + 1);
             fprintf(stderr, "[odgi::path_linear_sgd_layout] snapshot thread: Taking snapshot!\n");
-            rc = pgsgd_write_lay_f32(name.c_str(), 2 * g->n_nodes, sx.data(), sy.data());
+            rc = pgsgd::write_snapshot(name.c_str(), g->n_nodes, sx.data(), sy.data(), snapshot_names);
         }
     }
     if (p->progress) fprintf(stderr, "\n");

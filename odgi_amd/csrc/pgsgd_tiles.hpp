@@ -663,8 +663,17 @@ struct PendingTerm {
 #define PGSGD_TILE_WAVES 5
 #endif
 // LOCK: the instance with conflict resolution on the window's node ends (PGSGD_FLAG_LOCK_WINDOW_ENDS; an option, see the term loop).
+// The hand-off of a window between consecutive parts (kItemHasNext) has no release/acquire fence: the words go out with
+// agent-scope atomic stores, `s_waitcnt vmcnt(0)` waits for their acknowledgement (on gfx9 the one counter covers stores — gfx10+
+// count them in vscnt), a relaxed flag follows, and the next part stages the window with agent-scope loads.  That is the memory
+// model of gfx942 / gfx950 (write-through L2 at agent scope, store acknowledged when visible to the agent) and of no other
+// target: this file is built for those only, and the windowed instance must read coordinates with the agent-scope flavour.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "pgsgd_tiles.hpp: the fence-free window hand-off (kItemHasNext) is written for gfx950 / gfx942 only"
+#endif
 template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
+    static_assert(COORD_LOAD == 1, "the tile kernel stages windows with agent-scope loads: a part of a window may have been written by another workgroup of this launch");
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
     uint4* trec = reinterpret_cast<uint4*>(lds + 4 * (size_t)ta.region);         // [T] tile records
@@ -742,7 +751,9 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     // (relaxed: an acquire at agent scope invalidates the XCD's L2 on every poll, and the words that follow are read with agent-scope loads anyway)
                     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
                         __builtin_amdgcn_s_sleep(32);
-                        if (wall_clock64() - t_wait > 500000000ull) __builtin_trap();  // 5 s of 100 MHz ticks: never seen; a dead launch, not a hung device
+                        // a FATAL diagnostic, never seen: 5 s of 100 MHz ticks without the predecessor's flag aborts the launch (the HIP
+                        // context is lost, every later call returns PGSGD_E_HIP) instead of hanging the device
+                        if (wall_clock64() - t_wait > 500000000ull) __builtin_trap();
                     }
                 }
             }

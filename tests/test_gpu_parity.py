@@ -774,6 +774,54 @@ def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
     assert curves["tile"][0] <= 1.1 * curves["per_lane"][0]   # before cooling the tile kernel is ahead
 
 
+def test_config5_size_truncated_schedule_against_the_committed_cpu_point(oa):
+    """Oracle evidence at BASELINE config 5's size.  The CPU restatement cannot run the whole schedule at 1e7 nodes (1.4e11
+    terms: hours on 256 threads), so it ran a truncated one — `-x 15 -G 2`: 15 iterations of 2*S terms, the shortest schedule
+    the product runs the tile kernel on — once per initial layout (tools/make_config5_cpu_point.py, committed as
+    tests/golden/config5_cpu_point.json: 1.4e10 terms, 17 minutes per run on this container's 8 cores).  Both GPU kernels
+    run the same schedule from the same initial layout (seed 42) and are scored with the same evaluator (2e6 pairs, seed 1):
+    final stress two-sided against the CPU runs."""
+    import json
+    from odgi_amd import _lib
+    with open(os.path.join(GOLDEN, "config5_cpu_point.json")) as f:
+        ref = json.load(f)
+    g, (X0, Y0) = _config5_graph(oa)
+    assert ref["graph"] == {"nodes": g.n_nodes, "paths": g.n_paths, "steps": g.n_steps, "seed": 42}
+    assert ref["runs"][0]["init_seed"] == 42 and ref["eval_pairs"] == 2_000_000 and ref["eval_seed"] == 1
+    cpu_final = [r["stress_final"] for r in ref["runs"]]
+    cpu_at = np.array([r["stress_at"] for r in ref["runs"]])
+    res = {}
+    for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES)):
+        p = _params(oa, g, flags=flags, iter_max=ref["params"]["iter_max"], min_term_updates=ref["params"]["min_term_updates"])
+        assert p.theta == ref["params"]["theta"] and p.cooling_start == ref["params"]["cooling_start"]
+        etas = oa.path_linear_sgd_layout_schedule(p)
+        out = []
+        with oa.LayoutSession(g, p) as s:
+            s.upload(X0, Y0)
+            assert s.tile_info()["tiled"] == (name == "tile")
+            for it in range(p.iter_max):
+                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+                s.sync()
+                if it + 1 in ref["snap_iters"]:
+                    X, Y = s.download_f64(flush=it + 1 == p.iter_max)
+                    out.append(oa.path_stress(g, X, Y, ref["eval_pairs"], seed=ref["eval_seed"]))
+            assert s.outbox_overflow() == 0
+        res[name] = out
+    print(f"config 5 size, -x 15 -G 2: stress after iterations {ref['snap_iters']}: tile {res['tile']}, per-lane {res['per_lane']}, "
+          f"CPU restatement {cpu_at.tolist()} (final {cpu_final}, {ref['threads']} threads)")
+    c = float(np.mean(cpu_final))
+    # Measured (profiles/r05/pytest_config5_truncated.log): CPU restatement 1.27e5 / 7.99 / 0.1148 after iterations 5 / 10 / 15,
+    # per-lane kernel 1.23e5 / 7.73 / 0.1129 — the reference's rule term by term follows the restatement within 2-4 % all the
+    # way at this size too — and the tile kernel 7.9e6 / 26.3 / 0.1324: its own transient (far pulls capped, DESIGN 4.5; on a
+    # schedule of 2*S terms per iteration there is a fifth of the local terms to absorb them) and a final layout 15 % above
+    # the restatement's.  That is the open 1e7-node gap of the next test (+10 % against the per-lane kernel over the whole
+    # schedule), now measured against the oracle: the per-lane kernel gets +-8 %, the tile kernel -10 % ... +25 % — a band that
+    # STATES the gap, not one that hides it (PGSGD_FLAG_NO_TILES / `--gpu-no-tiles` is the reference-quality plan at this size).
+    assert 0.92 * c <= res["per_lane"][-1] <= 1.08 * c, (res["per_lane"], cpu_final)
+    assert 0.90 * c <= res["tile"][-1] <= 1.25 * c, (res["tile"], cpu_final)
+    assert 0.5 * cpu_at[:, 1].mean() <= res["per_lane"][1] <= 2.0 * cpu_at[:, 1].mean()   # the transient of the reference's rule (iteration 10)
+
+
 def _words_conserved(w0, w1):
     """Every term adds -(qx, qy) to one node end and +(qx, qy) to another: the sums of the X and Y fields never change
     — unless the session widened its fixed-point frame on the way (every word re-quantised: nothing to compare)."""
@@ -1630,6 +1678,22 @@ def test_kernel_plan_follows_graph_order_and_initial_layout(oa):
         st = oa.path_linear_sgd_layout_gpu(gr, dataclasses.replace(p, seed=9399220 + 7919 * rep), X, Y)
         assert st["relabeled"] == 1 and st["tiled"] == 1 and np.isfinite(X).all()
         s_renamed.append(oa.path_stress(gr, X, Y, 1_000_000, seed=1))
+        if rep == 0:
+            # snapshots (-u) change neither the plan nor what the files mean: the same run with a snapshot prefix still renames,
+            # still runs the tile kernel, and its snapshots are written under the CALLER's node ranks — the last one lies next
+            # to the final layout node for node (under the renamed ranks it would be a permutation of it: ~the layout's extent off)
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                Xu, Yu = np.empty_like(Xs), np.empty_like(Ys)
+                for e in (0, 1):
+                    Xu[2 * perm + e], Yu[2 * perm + e] = Xs[e::2], Ys[e::2]
+                stu = oa.path_linear_sgd_layout_gpu(gr, dataclasses.replace(p, seed=9399220, snapshot_prefix=os.path.join(td, "snap_")), Xu, Yu)
+                assert stu["relabeled"] == 1 and stu["tiled"] == 1
+                assert sorted(os.listdir(td), key=lambda n: int(n[5:])) == [f"snap_{k}" for k in range(1, p.iter_max)]
+                lay = oa.Layout.load(os.path.join(td, f"snap_{p.iter_max - 1}"))
+                extent = float(Xu.max() - Xu.min())
+                off = np.hypot(lay.X - Xu, lay.Y - Yu)
+                assert lay.size() == 2 * gr.n_nodes and float(np.median(off)) < 1e-3 * extent, (float(np.median(off)), extent)
     # (b), (c) sorted graph, Gaussian vs default initial layout
     res = {}
     for init in "gd":

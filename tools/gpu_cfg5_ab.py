@@ -16,35 +16,49 @@ N = int(float(sys.argv[1]))
 variants = sys.argv[2:] or ["tile", "per_lane"]
 g = oa.Graph.synthetic(N, 50, seed=42)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
-KNOBS = ("PGSGD_TILE_FAR_RELAX", "PGSGD_TILE_SNAPSHOT_PASS", "PGSGD_TILE_LANES", "PGSGD_FRAME_SPAN", "PGSGD_TILE_LOCK_MU", "PGSGD_TILE_SUBSTEPS")
+KNOBS = ("PGSGD_TILE_FAR_RELAX", "PGSGD_TILE_SNAPSHOT_PASS", "PGSGD_TILE_LANES", "PGSGD_FRAME_SPAN", "PGSGD_TILE_LOCK_MU", "PGSGD_TILE_SUBSTEPS", "PGSGD_TILE_LANE_COIN")
+EXTRA = []
 for v_in in variants:
     v = v_in
     for k in KNOBS:
         os.environ.pop(k, None)
     flags = 0
+    seed = 9399220
+    for k in list(EXTRA):
+        os.environ.pop(k, None)
+    EXTRA.clear()
+    while "+env:" in v:   # e.g. tile+env:PGSGD_TILE_SPLIT=13@11: any debug knob of the library
+        v, rest = v.split("+env:", 1)
+        kv, tail = (rest.split("@", 1) + [""])[:2] if "@" in rest and "+env:" not in rest else (rest, "")
+        if "+env:" in kv:
+            kv, more = kv.split("+env:", 1)
+            v = v + "+env:" + more
+        name, val = kv.split("=", 1)
+        os.environ[name] = val
+        EXTRA.append(name)
+        if tail:
+            v = v + "@" + tail
+    if "+span" in v:   # e.g. tile+span128@11: a frame 128x the extent instead of 8x (16x coarser quanta)
+        v, rest = v.split("+span")
+        os.environ["PGSGD_FRAME_SPAN"] = rest.split("@")[0]
+        v = v + ("@" + rest.split("@")[1] if "@" in rest else "")
+    if "@" in v:       # variant@sampler-seed
+        v, sd = v.split("@")
+        seed = int(sd)
     if v == "per_lane": flags = _lib.FLAG_NO_TILES
     elif v.startswith("relax"): os.environ["PGSGD_TILE_FAR_RELAX"] = v[5:]
     elif v == "nocap": flags = _lib.FLAG_NO_FAR_CAP
     elif v == "pass": os.environ["PGSGD_TILE_SNAPSHOT_PASS"] = "1"
     elif v == "exact": flags = _lib.FLAG_EXACT_MATH
     elif v == "nopairs": flags = _lib.FLAG_NO_PARTNER_PAIRS
-    seed = 9399220
-    if "+span" in v:   # e.g. tile+span128@11: a frame 128x the extent instead of 8x (16x coarser quanta)
-        v, rest = v.split("+span")
-        os.environ["PGSGD_FRAME_SPAN"] = rest.split("@")[0]
-        v = v + ("@" + rest.split("@")[1] if "@" in rest else "")
-        if v.split("@")[0] == "per_lane": flags = _lib.FLAG_NO_TILES
-    if "@" in v:
-        v0, sd = v.split("@"); seed = int(sd)
-        if v0 == "per_lane": flags = _lib.FLAG_NO_TILES
-        if v0.startswith("lanes"): os.environ["PGSGD_TILE_LANES"] = v0[5:]
+    elif v == "lanecoin": os.environ["PGSGD_TILE_LANE_COIN"] = "1"      # the Zipf/uniform coin per lane, as in round 3 (implies no partner pairs)
     elif v.startswith("lanes"): os.environ["PGSGD_TILE_LANES"] = v[5:]
-    if v.startswith("lock"): os.environ["PGSGD_TILE_LOCK_MU"] = v[4:].split("@")[0]
-    if v.startswith("sub"): os.environ["PGSGD_TILE_SUBSTEPS"] = v[3:].split("@")[0]
+    elif v.startswith("lock"): os.environ["PGSGD_TILE_LOCK_MU"] = v[4:]
+    elif v.startswith("sub"): os.environ["PGSGD_TILE_SUBSTEPS"] = v[3:]
     n_streams = 0
     if v.startswith("pl"):   # per-lane kernel with this many streams (lanes), e.g. pl45875@11
         flags = _lib.FLAG_NO_TILES
-        n_streams = int(v[2:].split("@")[0])
+        n_streams = int(v[2:])
     p = oa.LayoutParams.defaults(g, device=0, flags=flags, n_streams=n_streams)
     p.seed = seed
     etas = oa.path_linear_sgd_layout_schedule(p)
