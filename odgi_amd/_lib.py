@@ -118,6 +118,8 @@ SIGNATURES = [
     ("pgsgd_session_frame_status", C.c_int, [C.c_void_p, P(C.c_int), P(u32)]),
     ("pgsgd_session_reframe", C.c_int, [C.c_void_p]),
     ("pgsgd_session_kernel_time", C.c_int, [C.c_void_p, P(f64), P(u64), C.c_int]),
+    ("pgsgd_abi_version", C.c_int, []),
+    ("pgsgd_abi_struct_sizes", None, [P(C.c_size_t), P(C.c_size_t), P(C.c_size_t)]),
     ("pgsgd_session_aux_time", C.c_int, [C.c_void_p, P(f64), P(f64)]),
     ("pgsgd_session_launch_counts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_shader_clock", C.c_int, [C.c_void_p, P(f64), P(f64)]),

@@ -20,20 +20,6 @@ void set_error(const char* fmt, ...) {
 void clear_error() { g_err[0] = 0; }
 }  // namespace pgsgd
 
-int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);  // pgsgd_session.hip
-namespace pgsgd {
-int write_snapshot(const char* name, uint64_t n_nodes, const float* x, const float* y, const uint32_t* new_rank_of_old) {
-    if (!new_rank_of_old) return pgsgd_write_lay_f32(name, 2 * n_nodes, x, y);
-    std::vector<float> sx(2 * n_nodes), sy(2 * n_nodes);
-    for (uint64_t i = 0; i < n_nodes; ++i) {
-        const uint64_t n = new_rank_of_old[i];
-        sx[2 * i] = x[2 * n]; sx[2 * i + 1] = x[2 * n + 1];
-        sy[2 * i] = y[2 * n]; sy[2 * i + 1] = y[2 * n + 1];
-    }
-    return pgsgd_write_lay_f32(name, 2 * n_nodes, sx.data(), sy.data());
-}
-}  // namespace pgsgd
-
 extern "C" const char* pgsgd_last_error(void) { return pgsgd::g_err; }
 
 extern "C" int pgsgd_abi_version(void) { return PGSGD_ABI_VERSION; }

@@ -2115,6 +2115,19 @@ extern "C" int pgsgd_session_trace_terms(pgsgd_session* s, int cooling, uint64_t
 // the one-shot run: iteration control of path_sgd_layout.cpp:120-163 with exact iteration lengths
 int pgsgd_write_lay_f32(const char* path, uint64_t n_ends, const float* X, const float* Y);
 
+namespace pgsgd {
+int write_snapshot(const char* name, uint64_t n_nodes, const float* x, const float* y, const uint32_t* new_rank_of_old) {
+    if (!new_rank_of_old) return pgsgd_write_lay_f32(name, 2 * n_nodes, x, y);
+    std::vector<float> sx(2 * n_nodes), sy(2 * n_nodes);
+    for (uint64_t i = 0; i < n_nodes; ++i) {
+        const uint64_t n = new_rank_of_old[i];
+        sx[2 * i] = x[2 * n]; sx[2 * i + 1] = x[2 * n + 1];
+        sy[2 * i] = y[2 * n]; sy[2 * i + 1] = y[2 * n + 1];
+    }
+    return pgsgd_write_lay_f32(name, 2 * n_nodes, sx.data(), sy.data());
+}
+}  // namespace pgsgd
+
 static int layout_run_impl(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats);
 int pgsgd_layout_run_multi(const pgsgd_graph_view* g, const pgsgd_params* p, float* X, float* Y, double* Xd, double* Yd, pgsgd_stats* stats, const uint32_t* snapshot_names);
 
