@@ -104,6 +104,8 @@ struct pgsgd_session {
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
     uint64_t term0_terms = 0;
     uint32_t ob_part_shift = 13;          // log2 of the node ends one drain workgroup accumulates in LDS
+    uint32_t ob_slices = 1;               // workgroups that share a (bucket, part)'s message stream (far_drain_kernel); > 1: d_ob_partial
+    uint64_t* d_ob_partial = nullptr;     // [ob_slices][2N] the slices' sums, added to the coordinates by far_combine_kernel
     unsigned long long* d_ob_spill = nullptr;
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     std::vector<pgsgd::WorkItem> h_items; // host copy of the work items, colour 0 first (parity hooks)
@@ -739,8 +741,20 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         s->ob.qbits = pgsgd::outbox_qbits(ob_shift);
         if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_QBITS"))  // test knob: narrow packed steps, so that most messages take the path of a step too wide for the packed form
             s->ob.qbits = (uint32_t)std::min<int>((int)s->ob.qbits, std::max(2, atoi(e)));
-        s->ob_part_shift = std::min<uint32_t>(buckets_at(ob_shift) <= 128 && ob_shift > 10 ? ob_shift - 1 : ob_shift, 14);
+        // A drain workgroup accumulates a whole bucket (at most 2^14 node ends = 128 KiB of LDS; wider buckets in parts).  Where
+        // that leaves fewer workgroups than the device has CUs, a bucket's message stream is cut into slices (far_drain_kernel):
+        // config 4, 123 buckets -> two slices each, every message unpacked once by a workgroup that sees half of them.
+        // (Round 4 ran two PARTS per bucket there: 0.30 ms per launch; slices: see profiles/r05/NOTES.md.)
+        s->ob_part_shift = std::min<uint32_t>(ob_shift, 14);
         if (const char* e = pgsgd::debug_env("PGSGD_OUTBOX_PART_SHIFT")) s->ob_part_shift = (uint32_t)std::min<int>((int)ob_shift, std::max(10, atoi(e)));  // experiment knob
+        {
+            const uint64_t base_wgs = buckets_at(ob_shift) << (ob_shift - s->ob_part_shift);
+            int cus = 256;
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+            s->ob_slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4, (uint64_t)cus / std::max<uint64_t>(1, base_wgs)));
+            if (const char* e = pgsgd::debug_env("PGSGD_DRAIN_SLICES")) s->ob_slices = (uint32_t)std::min(8, std::max(1, atoi(e)));  // experiment knob
+        }
         s->ob.n_buckets = (uint32_t)(((2 * g->n_nodes - 1) >> ob_shift) + 1);
         s->ob_bucket_steps.assign(s->ob.n_buckets, 0);
         for (uint64_t i = 0; i < g->n_nodes; ++i) {
@@ -1141,6 +1155,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_ob_cap) (void)hipFree(s->d_ob_cap);
     if (s->d_ob_overflow) (void)hipFree(s->d_ob_overflow);
     if (s->d_ob_spill) (void)hipFree(s->d_ob_spill);
+    if (s->d_ob_partial) (void)hipFree(s->d_ob_partial);
     if (s->d_term0) (void)hipFree(s->d_term0);
     if (s->h_delta_max) (void)hipHostFree(s->h_delta_max);
     if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
@@ -1571,10 +1586,18 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
 static int drain_outbox(pgsgd_session* s, unsigned long long* far_next) {
     if (!s->ob_pending) return PGSGD_OK;
     // (a bucket's parts run on one XCD: the grid is the buckets rounded up to a multiple of the 8 XCDs, times the parts)
-    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3((((s->ob.n_buckets + pgsgd::kItemQueues - 1) / pgsgd::kItemQueues) * pgsgd::kItemQueues) << (s->ob.shift - s->ob_part_shift)), dim3(1024),
-                       sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, 2 * s->n_nodes, s->ob_part_shift, s->dc.frame_flag);
+    const uint64_t n_ends = 2 * s->n_nodes;
+    if (s->ob_slices > 1 && !s->d_ob_partial) HIP_TRY(hipMalloc(&s->d_ob_partial, (size_t)s->ob_slices * n_ends * sizeof(uint64_t)));
+    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(((((s->ob.n_buckets + pgsgd::kItemQueues - 1) / pgsgd::kItemQueues) * pgsgd::kItemQueues) << (s->ob.shift - s->ob_part_shift)) * s->ob_slices), dim3(1024),
+                       sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, n_ends, s->ob_part_shift, s->dc.frame_flag, s->ob_slices, s->d_ob_partial);
     s->n_kernels++;
     HIP_TRY(hipGetLastError());
+    if (s->ob_slices > 1) {
+        hipLaunchKernelGGL(pgsgd::far_combine_kernel, dim3((unsigned)std::min<uint64_t>((n_ends + 255) / 256, 2048)), dim3(256), 0, s->stream, s->d_coords, s->d_ob_partial, n_ends,
+                           s->ob_slices, s->dc.frame_flag);
+        s->n_kernels++;
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
                        s->d_queue, far_next);
     s->n_kernels++;

@@ -1088,20 +1088,28 @@ __global__ __launch_bounds__(256) void snapshot_kernel(const uint32_t* step_hand
     }
 }
 
-// After every tile launch: one workgroup per (bucket, part) adds the messages that fall into its part of the bucket's
-// node range up in LDS and moves the node ends.  Nothing else writes coordinates while it runs, so the
-// read-modify-write of a word is plain.  part_shift = log2 of the node ends one workgroup accumulates; a bucket wider
-// than that is read by several workgroups, each keeping its own part (large graphs only).
-__global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift, unsigned int* frame_flag) {
+// After every tile launch: one workgroup per (bucket, part, slice) adds the messages of its SLICE of the bucket's chunks that
+// fall into its PART of the bucket's node range up in LDS.  part_shift = log2 of the node ends one workgroup accumulates (at
+// most 2^14 = 128 KiB of LDS); a bucket wider than that is read by several workgroups, each keeping its own part (large graphs
+// only: every part unpacks every message).  slices: where buckets x parts would not fill the device (config 4: 123 buckets), a
+// bucket's message stream is cut into `slices` runs of chunks, one workgroup each: every message is unpacked ONCE, by a
+// workgroup that sees half (a third, a quarter) of them — round 4 ran two parts per bucket there instead, both unpacking
+// everything: its instruction issue and LDS adds, not the memory, were what the drain waited for (profiles/r05/NOTES.md).
+// With one slice the workgroup moves the node ends itself (nothing else writes coordinates while the drain runs: a plain
+// read-modify-write); with several, each writes its sums to partial[slice][2N] — every word, zero where nothing arrived — and
+// far_combine_kernel adds them to the coordinates: exact 64-bit integer adds, the sum direct atomics would give.
+__global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift, unsigned int* frame_flag,
+                                                         uint32_t slices, uint64_t* partial) {
     extern __shared__ uint64_t acc[];
     const uint32_t parts = 1u << (ob.shift - part_shift);
     // The parts of one bucket stream the SAME messages, each keeping its share.  Workgroups are dealt to the 8 XCDs round-robin
     // by index, so workgroup 8 m + x is XCD x's m-th: XCD x takes buckets x, x + 8, ... and runs a bucket's parts back to back
     // — at the same time, on CUs that share an L2: one of them fetches a line from memory, the others find it there (1e7
     // nodes, 8 parts: the drain's memory reads fall from 8x the messages towards 1x; with a bucket's parts on 8 different
-    // XCDs every part fetched everything itself).  One part per bucket: the identity.
+    // XCDs every part fetched everything itself).  One part per bucket: the identity.  (A bucket's slices follow one another too.)
     const uint32_t xcd = blockIdx.x % kItemQueues, m = blockIdx.x / kItemQueues;
-    const uint32_t b = (m / parts) * kItemQueues + xcd, part = m % parts, span = 1u << part_shift;
+    const uint32_t slice = m % slices, mp = m / slices;
+    const uint32_t b = (mp / parts) * kItemQueues + xcd, part = mp % parts, span = 1u << part_shift;
     if (b >= ob.n_buckets) return;
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) acc[i] = 0;
     __syncthreads();
@@ -1112,43 +1120,43 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     // filled is a single (wave-uniform) word.  Eight chunks per wave in flight before the LDS adds.
     const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(ob.pool) + first / 2;
     const uint32_t n_chunks = handed < cap ? handed : cap;
+    const uint32_t c_lo = (uint32_t)((uint64_t)n_chunks * slice / slices), c_hi = (uint32_t)((uint64_t)n_chunks * (slice + 1) / slices);  // this slice's chunks
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint32_t part_off = part << part_shift;
     const uint32_t* fill = ob.fill + ob.chunk0[b];
     static_assert(kObChunk == 128, "one chunk = 64 lanes x 2 messages");
-    // (the fill words of a pass are loaded during the pass before: a pass then waits for memory once, not twice)
-    // Round 5 looked for what the drain waits for (4.4 TB/s of a 6.2 TB/s streaming ceiling, 9 % of a step): not the loads
-    // in flight (16 or 24 chunks per wave and pass: the same, or slower with spills), not the vector instructions (a 32-bit
-    // unpack without the three variable 64-bit shifts: the same), not the parts per bucket (four: slower) — what remains is
-    // the LDS adds: one workgroup per CU sends ~21 000 wave-wide 64-bit atomics through one LDS (profiles/r05/NOTES.md).
+    // (the fill words of a pass are loaded during the pass before: a pass then waits for memory once, not twice.  Round 5
+    // measured 16 and 24 chunks per wave and pass — the same, slower with spills — and a 32-bit unpack without the three
+    // variable 64-bit shifts — the same.  With two slices per bucket the kernel streams its 1.33 GB in ~0.21 ms, the memory's
+    // streaming rate; three or four slices of 128 KiB of LDS each no longer fit one round of workgroups and are slower.)
     constexpr int kU = 8;  // chunks per wave and pass
     uint32_t f[kU];
 #pragma unroll
     for (int k = 0; k < kU; ++k) {
-        const uint32_t c = wave + (uint32_t)k * waves;
-        f[k] = c < n_chunks ? fill[c] : 0u;
+        const uint32_t c = c_lo + wave + (uint32_t)k * waves;
+        f[k] = c < c_hi ? fill[c] : 0u;
     }
-    for (uint32_t c0 = wave; c0 < n_chunks; c0 += kU * waves) {
-        ulonglong2 m[kU];
+    for (uint32_t c0 = c_lo + wave; c0 < c_hi; c0 += kU * waves) {
+        ulonglong2 m2[kU];
         bool ok[kU];
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
             const uint32_t c = c0 + (uint32_t)k * waves;
             ok[k] = 2 * lane < f[k];  // (0 past the end; fill is a whole number of 8-message lines)
-            if (ok[k]) m[k] = pairs[(uint64_t)c * (kObChunk / 2) + lane];
+            if (ok[k]) m2[k] = pairs[(uint64_t)c * (kObChunk / 2) + lane];
         }
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
             const uint32_t c = c0 + (uint32_t)(kU + k) * waves;
-            f[k] = c < n_chunks ? fill[c] : 0u;
+            f[k] = c < c_hi ? fill[c] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
             if (!ok[k]) continue;
             uint32_t off;
-            uint64_t d = outbox_unpack(ob, m[k].x, off);
+            uint64_t d = outbox_unpack(ob, m2[k].x, off);
             if (d && off - part_off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + (off - part_off)), (unsigned long long)d);
-            d = outbox_unpack(ob, m[k].y, off);
+            d = outbox_unpack(ob, m2[k].y, off);
             if (d && off - part_off < span) atomicAdd(reinterpret_cast<unsigned long long*>(acc + (off - part_off)), (unsigned long long)d);
         }
     }
@@ -1156,11 +1164,31 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     bool guard = false;
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
         if (base + i >= n_ends) break;
-        const uint64_t sp = ob.spill[base + i];
-        if (sp) ob.spill[base + i] = 0;
-        if (acc[i] + sp != 0) {
+        uint64_t sp = 0;
+        if (slice == 0) {  // (the spill words — steps too wide for a message, a pool that ran out: rare — go with the first slice)
+            sp = ob.spill[base + i];
+            if (sp) ob.spill[base + i] = 0;
+        }
+        if (slices > 1) {
+            partial[(uint64_t)slice * n_ends + base + i] = acc[i] + sp;
+        } else if (acc[i] + sp != 0) {
             const uint64_t w = coords[base + i] + acc[i] + sp;
             coords[base + i] = w;
+            guard |= in_frame_guard(w);
+        }
+    }
+    if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(frame_flag, 1u);
+}
+
+// coords += the slices' partial sums (far_drain_kernel with several slices)
+__global__ __launch_bounds__(256) void far_combine_kernel(uint64_t* coords, const uint64_t* partial, uint64_t n_ends, uint32_t slices, unsigned int* frame_flag) {
+    bool guard = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t d = 0;
+        for (uint32_t sl = 0; sl < slices; ++sl) d += partial[(uint64_t)sl * n_ends + i];
+        if (d) {
+            const uint64_t w = coords[i] + d;
+            coords[i] = w;
             guard |= in_frame_guard(w);
         }
     }
