@@ -203,13 +203,16 @@ def main():
     rf["shader_clock_mhz"] = clock_mhz
     # HBM traffic per launch: NOT measured in this run — the memory-side request counters of the L2 (TCC_EA0_RDREQ by size
     # class, TCC_EA0_WRREQ) from the committed rocprofv3 PMC passes of this same command, with the request sizes calibrated on
-    # kernels of known traffic (tools/profile_cal.sh -> profiles/r04/pmc_traffic_r04.json, pmc_calibration*.json), labelled so
-    prof = os.path.join(ROOT, "profiles", "r04", "pmc_traffic_r04.json")
-    same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles
+    # kernels of known traffic (tools/profile_cal.sh -> profiles/r05/pmc_traffic_r05.json, pmc_calibration*.json), labelled so —
+    # and labelled STALE when the library's sources have changed since the passes were taken (library_source_id)
+    prof = os.path.join(ROOT, "profiles", "r05", "pmc_traffic_r05.json")
+    same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles and not args.flags
     if os.path.exists(prof) and same_workload:
         try:
             with open(prof) as f:
                 pj = json.load(f)
+            import __graft_entry__ as ge
+            current = pj.get("library_source_id") == ge.built_id()
             rf["traffic"] = pj.get("hbm_bytes_per_launch")
             rf["traffic_over_algorithmic"] = pj.get("hbm_bytes_per_launch") / (BYTES_PER_TERM * my_terms) if my_terms else None
             rf["hbm_bandwidth_TB_per_s"] = pj.get("hbm_bandwidth_TB_per_s")
@@ -219,7 +222,9 @@ def main():
             rf["memory_read_request_rate_per_s"] = pj.get("read_request_rate_per_s")
             rf["random_request_ceiling_per_s"] = pj.get("random_request_ceiling_per_s")
             rf["traffic_note"] = pj.get("note")
-            rf["traffic_source"] = "profiled offline, not in this run: " + str(pj.get("source"))
+            rf["traffic_source"] = ("profiled offline, not in this run" + ("" if current else " — STALE: taken with library sources " + str(pj.get("library_source_id")) +
+                                    ", this run's are " + ge.built_id()) + ": " + str(pj.get("source")))
+            rf["traffic_source_current"] = bool(current)
         except Exception as e:  # noqa: BLE001
             log(f"[bench] could not read {prof}: {e}")
 

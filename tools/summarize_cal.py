@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r04/pmc_calibration.json and pmc_traffic_r04.json from a tools/profile_cal.sh run (gpurun_out/prof_cal_<tag>/summary.json).
+"""profiles/<round>/pmc_calibration_<tag>.json and pmc_traffic_<tag>.json from a tools/profile_cal.sh run (gpurun_out/prof_cal_<tag>/summary.json):
+    python tools/summarize_cal.py gpurun_out/prof_cal_<tag>/summary.json profiles/r05 r05
+(`library_source_id` = odgi_amd/lib/BUILD_ID of the profiled library: bench.py says "stale" when the sources have changed since.)
 
 Calibration: for each kernel of known traffic (tools/microbench.hip, MICROBENCH_CAL=1) the memory-side read requests of the
 L2 by size class (TCC_EA0_RDREQ_32B / _64B / _128B) and its write requests (TCC_EA0_WRREQ, _64B) against the bytes and
@@ -7,7 +9,13 @@ requests the kernel is known to make.  Traffic of the tile kernel: the same coun
 weighted as the driver's window weighs them (20 warm + 20 cooling launches of iterations 5..24)."""
 import json, sys, os
 src = sys.argv[1]
-out_dir = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
+out_dir = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:
+    build_id = open(os.path.join(ROOT, "odgi_amd", "lib", "BUILD_ID")).read().strip()   # hash of the sources the profiled library was built from
+except OSError:
+    build_id = "unknown"
 d = json.load(open(src))
 C, K = d["counters"], d["known"]
 def cnt(k, c):
@@ -39,11 +47,12 @@ for name, kn in K.items():
                  "fetch_size_over_known": t["fetch_size_bytes"] / known_read if known_read else None,
                  "read_requests_per_known_request": t["rdreq"] / (kn["requests"] * (0.75 if name == "cal_stream_read" and disp == 2 else 1.0)) if kn["bytes_read"] else None}
 ceil = max((K[n]["G_requests_per_s"] for n in ("cal_gather16", "cal_gather32") if n in K), default=0.0) * 1e9
-json.dump({"source": src, "random_64B_request_ceiling_per_s": ceil, "kernels": cal}, open(os.path.join(out_dir, "pmc_calibration.json"), "w"), indent=1)
+json.dump({"source": src, "library_source_id": build_id, "random_64B_request_ceiling_per_s": ceil, "kernels": cal}, open(os.path.join(out_dir, f"pmc_calibration_{tag}.json"), "w"), indent=1)
 warm, cool = traffic("bench:sgd_tile_kernel_warm"), traffic("bench:sgd_tile_kernel_cooling")
 mix = {k: 0.5 * (warm[k] + cool[k]) for k in warm}
 drain = traffic("bench:far_drain_kernel")
-res = {"source": "rocprofv3 --pmc passes (TCC_EA0_RDREQ by size class, TCC_EA0_WRREQ, TCC_HIT/MISS; one group per pass) of `bench.py --cpu-seconds 0 --steps 20 "
+res = {"library_source_id": build_id,
+       "source": "rocprofv3 --pmc passes (TCC_EA0_RDREQ by size class, TCC_EA0_WRREQ, TCC_HIT/MISS; one group per pass) of `bench.py --cpu-seconds 0 --steps 20 "
                  "--warmup 5`, tools/profile_cal.sh + tools/summarize_cal.py; " + src,
        "note": "Calibrated on kernels of known traffic (pmc_calibration.json): the L2's memory-side request COUNTS are exact (a random 16- or 32-byte "
                "gather = 1.00 read request, a 64-byte line write = 1.00 write request of 64 bytes, a streaming read = one request per 128 bytes), and a "
@@ -61,7 +70,7 @@ res = {"source": "rocprofv3 --pmc passes (TCC_EA0_RDREQ by size class, TCC_EA0_W
        "read_request_rate_per_s": {"warm": warm["rdreq"] / warm["mean_duration_ms"] * 1e3 if warm["mean_duration_ms"] else None,
                                    "cooling": cool["rdreq"] / cool["mean_duration_ms"] * 1e3 if cool["mean_duration_ms"] else None},
        "random_request_ceiling_per_s": ceil, "tile_kernel_warm": warm, "tile_kernel_cooling": cool, "tile_kernel_window_mean": mix, "far_drain_kernel": drain}
-json.dump(res, open(os.path.join(out_dir, "pmc_traffic_r04.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out_dir, f"pmc_traffic_{tag}.json"), "w"), indent=1)
 for k in ("tile_kernel_warm", "tile_kernel_cooling", "far_drain_kernel"):
     t = res[k]
     ms = t["mean_duration_ms"]
