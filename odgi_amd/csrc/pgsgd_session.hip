@@ -320,7 +320,10 @@ typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::TileSampl
 template <int FAR, int MATH>
 static tile_kernel_t tile_kernel_f(bool cooling, bool local) {
     using namespace pgsgd;
-    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH> : sgd_tile_kernel<1, FAR, false, true, MATH>;
+#ifndef PGSGD_TILE_ABL
+#define PGSGD_TILE_ABL 0   // experiment builds (make libpgsgd_x<N>.so): a profiling instance of the windowed tile kernel, results invalid
+#endif
+    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH, false, PGSGD_TILE_ABL> : sgd_tile_kernel<1, FAR, false, true, MATH, false, PGSGD_TILE_ABL>;
     return cooling ? sgd_tile_kernel<1, FAR, true, false, MATH> : sgd_tile_kernel<1, FAR, false, false, MATH>;
 }
 // math: pgsgd::kMathFast (what sessions run) or kMathExact (PGSGD_FLAG_EXACT_MATH, paths of 2^32 bp and more); lock: the

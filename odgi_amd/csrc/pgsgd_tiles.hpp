@@ -127,6 +127,9 @@ __device__ __forceinline__ uint64_t outbox_unpack(const Outbox& ob, uint64_t msg
     const int64_t qy = (int64_t)(msg << (64u - ob.shift - 2u * ob.qbits)) >> (64u - ob.qbits);
     return (uint64_t)qx + ((uint64_t)qy << 32);
 }
+#ifndef PGSGD_TILE_ABL_NO_LINE_STORES
+#define PGSGD_TILE_ABL_NO_LINE_STORES 0   // experiment build: the rings' protocol runs, completed lines are not written out (results invalid)
+#endif
 constexpr uint32_t kItemQueues = 8;
 constexpr uint32_t kNoItem = 0xffffffffu;
 constexpr int kTileBlock = 256;
@@ -365,7 +368,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
                     const uint2 it = list[e];
                     const uint64_t m = L.stage()[it.x * kObLine + piece];
                     if (it.y != kObNoLine) {
-                        TILE_COLD(ta.ob.pool)[(uint64_t)it.y * kObLine + piece] = m;
+                        if (PGSGD_TILE_ABL_NO_LINE_STORES == 0) TILE_COLD(ta.ob.pool)[(uint64_t)it.y * kObLine + piece] = m;
                     } else {  // no room left in the pool: the spill words, added to the coordinates by the drain
                         const uint32_t mb = it.x < L.n_buckets ? it.x : L.ring_b0 + (it.x - L.n_buckets) / kObRingLines;  // the staged line's bucket
                         uint32_t off;
@@ -968,13 +971,13 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     if (LOCK && own_a) atomicAnd(lockw + (la >> 5), ~(1u << (la & 31u)));   // (LDS operations of a wave execute in order: after the adds)
                     if (LOCK && own_b) atomicAnd(lockw + (lb >> 5), ~(1u << (lb & 31u)));
                 }
-                if (ABL == 1) msg_a = msg_b = false;  // profiling instance: far updates are dropped (results invalid)
+                if (ABL == 1) msg_a = msg_b = false;  // profiling instances (results invalid; experiment builds libpgsgd_x<N>.so only): 1 far updates are dropped,
                 return FarMessages{mqx, mqy, end_a, end_b, msg_a, msg_b};
             };
             // messages wait in the wave's queue; the rings' protocol runs when 64 are there, one per lane
             auto send = [&](const FarMessages m) {
                 wq_append(ta.ob, wq, wq_n, m.to_b, m.end_b, m.qx, m.qy);
-                if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
+                if (wq_n >= ta.wq_threshold) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }  // 3 messages are queued but never leave the wave's queue,
                 if (!LOCAL) {
                     wq_append(ta.ob, wq, wq_n, m.to_a, m.end_a, -m.qx, -m.qy);
                     if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
             // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
             uint4* const recs2_out = TILE_COLD(ta.recs2_out);
-            if (recs2_out && (TILE_COLD(ta.snap_every) <= 1u || ((uint32_t)a.epoch + ti) % TILE_COLD(ta.snap_every) == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
+            if (ABL != 2 && recs2_out && (TILE_COLD(ta.snap_every) <= 1u || ((uint32_t)a.epoch + ti) % TILE_COLD(ta.snap_every) == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
                 __syncthreads();
                 for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) {  // the two ends of the step's node, the one the step enters first in front
                     const uint32_t e0 = trec[i].x;
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             }
         }
         // what still waits in the wave's queue goes to the rings while the hot ones are bound to this window
-        while (wq_n) wq_push(ta.ob, L, wq, wq_n);
+        while (wq_n) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }  // (ABL 2: the tiles do not rewrite their snapshot pieces)
         __syncthreads();
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
             const bool has_next = (wi.local & kItemHasNext) != 0;  // ... unless the window's next part may be staged by another workgroup in this launch
