@@ -18,10 +18,11 @@ namespace pgsgd {
 // ("colour"): windows of one parity are disjoint, so every window has a single owner and no two private
 // copies of a node end exist at the same time (summing the moves of several stale copies of one end
 // overshoots — reproduced for tiles in tools/tile_sim.c).  Around every launch:
-//   snapshot_kernel   streams the coordinates of every step's node into the second half of the step's 32-byte
-//                     record, so that a partner outside the window costs ONE gather that brings its handle,
-//                     position, node length and both end coordinates (as they were at the snapshot: before
-//                     every launch of a warm iteration, before the first launch of a cooling one);
+//   snapshot_kernel   streams the coordinates of every step's node into the snapshot piece of the step's gather
+//                     record (recs2: four steps per 128-byte line, pgsgd_kernels.hpp), so that a partner outside
+//                     the window costs ONE line that brings its handle, position, node length and both end
+//                     coordinates as they were at the snapshot — when a session starts, and whenever the
+//                     coordinates changed behind the tile kernel's back (a tile refreshes its own steps' pieces);
 //   sgd_tile_kernel   a workgroup takes a work item, stages the window's 4R coordinate words in LDS and
 //                     runs the item's tiles: tile records in LDS, first step uniform inside the tile (each
 //                     tile gets its exact share of the iteration's terms, so the first step is uniform
