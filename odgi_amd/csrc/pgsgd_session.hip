@@ -104,6 +104,7 @@ struct pgsgd_session {
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
     uint64_t term0_terms = 0;
     uint32_t ob_part_shift = 13;          // log2 of the node ends one drain workgroup accumulates in LDS
+    uint64_t tile_until = 0;              // experiment knob PGSGD_TILE_UNTIL
     uint32_t ob_slices = 1;               // workgroups that share a (bucket, part)'s message stream (far_drain_kernel); > 1: d_ob_partial
     uint64_t* d_ob_partial = nullptr;     // [ob_slices][2N] the slices' sums, added to the coordinates by far_combine_kernel
     unsigned long long* d_ob_spill = nullptr;
@@ -882,6 +883,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_SNAP_EVERY")) s->tile_snap_every = (uint32_t)std::min(8, std::max(1, atoi(e)));
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_UNTIL")) s->tile_until = (uint64_t)std::max(0L, atol(e));
         s->tile_tail = pgsgd::debug_env("PGSGD_TILE_TAIL") != nullptr;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_QUADS")) s->tile_pair_uniform = 2;  // experiment: partner quads (no mirror in the oracle)
@@ -1645,7 +1647,13 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     pgsgd::clear_error();
     if (!s || n_parts == 0 || part >= n_parts) return PGSGD_E_INVALID;
     // a tiled session whose initial layout had no global structure runs the per-lane kernel until cooling
-    const bool use_tiles = s->tiled && !(s->warm_per_lane && !cooling);
+    // (experiment knob PGSGD_TILE_UNTIL=k: the iterations from the k-th on, 0-based, run the per-lane kernel — does the 1e7-node
+    // gap come from the late, refining iterations?  profiles/r05/NOTES.md section 7)
+    const bool use_tiles = s->tiled && !(s->warm_per_lane && !cooling) && !(s->tile_until && s->relax_iter >= s->tile_until);
+    if (!use_tiles && s->ob_pending) {  // (the last tile launch's far pulls must not wait behind per-lane iterations)
+        const int rc = pgsgd_session_flush(s);
+        if (rc) return rc;
+    }
     if (!use_tiles) {
         // a sharded tiled session takes the whole iteration's term count (its tiles' share is applied); while it runs
         // the per-lane kernel (warm phase of a layout without global structure) it applies this device's 1/G of them,
