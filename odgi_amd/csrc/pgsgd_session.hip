@@ -98,7 +98,7 @@ struct pgsgd_session {
     uint64_t ob_total_chunks = 0;
     double aux_ms[2] = {0, 0};            // snapshot_kernel, far_drain_kernel (HIP events)
     bool ob_pending = false;              // the last tile launch's far pulls wait in the outbox (drained before the next launch)
-    bool snap_stale = true;               // the snapshot halves of the step records do not follow from the tile kernel's own writes
+    bool snap_stale = true;               // the snapshot pieces of the gather records do not follow from the tile kernel's own writes
     bool tile_forced = false;             // PGSGD_TILE_FORCE (parity knob) was set when the session was created
     bool snapshot_pass = false;           // PGSGD_TILE_SNAPSHOT_PASS (experiment knob): a pass over all records per iteration, as a sharded session takes
     uint64_t* d_term0 = nullptr;          // [n_tiles + 1] first term of every tile for term0_terms terms per call
@@ -1772,7 +1772,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             rc = drain_outbox(s, s->d_far + 2 * colour + (launches & 1u));
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.e[3], s->stream));
-            // Partners outside a window are read from the snapshot halves of the step records.  A tile rewrites the records
+            // Partners outside a window are read from the snapshot pieces of the gather records.  A tile rewrites the pieces
             // of its own steps when its terms are done (sgd_tile_kernel), so a session that runs every tile itself needs
             // the pass over all records only when the coordinates changed behind the tile kernel's back (snap_stale:
             // upload, per-lane iterations, a widened frame, a merge with other devices); a sharded session runs a share

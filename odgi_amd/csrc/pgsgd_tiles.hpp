@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         }
                     }
                     // the partner's record: the tile's LDS copy when it is a step of the tile (read where it is used), otherwise
-                    // ONE 32-byte line: the record and, of the coordinates both ends of its node had at the last snapshot, the
+                    // ONE 128-byte line of gather records: the static piece and, of the coordinates both ends of its node had at the last snapshot, the
                     // word of the end the term's coin chose (:262, bit 28)
                     const uint32_t kb = pstart + b_rank;
                     Qw.kb_off = kb - t0;
