@@ -406,6 +406,11 @@ void pgsgd_free(void* p);
 /* Sampled path stress: mean over sampled same-path end pairs of ((|p_a-p_b| - d)/d)^2. */
 int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, const double* Y,
                       uint64_t n_pairs, uint64_t seed, double* stress);
+/* The near pairs' part of that expectation WITHOUT sampling error: every pair of steps <= zmax steps apart, all end choices,
+ * weighted by the sampler's probability of drawing it (quality.cpp).  num/mass: [zmax*4], index (z-1)*4 + 2*flip_a + flip_b;
+ * hist_step [mod_step] / hist_rank [mod_rank] (optional, may be NULL): the numerator by step rank % mod_step / node rank % mod_rank. */
+int pgsgd_path_stress_near(const pgsgd_graph_view* g, const double* X, const double* Y, uint32_t zmax, double theta, uint32_t threads,
+                           double* num, double* mass, double* zero_mass, uint32_t mod_step, double* hist_step, uint32_t mod_rank, double* hist_rank);
 /* stats_main.cpp:667-716 (2D branch): sum over paths of consecutive-step distances, per node and per bp */
 int pgsgd_path_distance(const pgsgd_graph_view* g, const double* X, const double* Y,
                         double* per_node, double* per_bp);

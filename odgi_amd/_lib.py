@@ -168,6 +168,7 @@ SIGNATURES = [
     ("pgsgd_read_lay", C.c_int, [C.c_char_p, P(u64), P(P(f64)), P(P(f64))]),
     ("pgsgd_free", None, [C.c_void_p]),
     ("pgsgd_path_stress", C.c_int, [P(GraphView), P(f64), P(f64), u64, u64, P(f64)]),
+    ("pgsgd_path_stress_near", C.c_int, [P(GraphView), P(f64), P(f64), C.c_uint32, C.c_double, C.c_uint32, P(f64), P(f64), P(f64), C.c_uint32, P(f64), C.c_uint32, P(f64)]),
     ("pgsgd_path_distance", C.c_int, [P(GraphView), P(f64), P(f64), P(f64), P(f64)]),
     ("pgsgd_sort_params_defaults", C.c_int, [P(GraphView), P(Params)]),
     ("pgsgd_sort_initial", C.c_int, [P(GraphView), P(f64)]),

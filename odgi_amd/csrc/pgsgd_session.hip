@@ -134,7 +134,9 @@ struct pgsgd_session {
     uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
     float tile_lock_mu = 0.0f;        // TileArgs::lock_mu (debug knob PGSGD_TILE_LOCK_MU)
     uint32_t tile_snap_every = 1;     // debug knob PGSGD_TILE_SNAP_EVERY
+    uint32_t tile_rotate = 0;         // debug knob PGSGD_TILE_ROTATE
     uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
+    float tile_far_relax_max = 0.0f, tile_far_relax_slope = 0.0f;   // debug knobs PGSGD_TILE_FAR_RELAX_MAX / _SLOPE: min(max, slope * iteration) after the two gentle iterations
     float tile_far_relax_override = 0.0f;  // debug knob PGSGD_TILE_FAR_RELAX: a constant under-relaxation of the far pulls instead of tile_far_relax()
     uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
@@ -883,8 +885,11 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_SNAP_EVERY")) s->tile_snap_every = (uint32_t)std::min(8, std::max(1, atoi(e)));
         s->tile_lane_coin = pgsgd::debug_env("PGSGD_TILE_LANE_COIN") != nullptr;
+        s->tile_rotate = pgsgd::debug_env("PGSGD_TILE_ROTATE") != nullptr;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_UNTIL")) s->tile_until = (uint64_t)std::max(0L, atol(e));
         s->tile_tail = pgsgd::debug_env("PGSGD_TILE_TAIL") != nullptr;
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX_MAX")) s->tile_far_relax_max = (float)std::min(2.0, std::max(0.0, atof(e)));
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX_SLOPE")) s->tile_far_relax_slope = (float)std::min(2.0, std::max(0.0, atof(e)));
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_QUADS")) s->tile_pair_uniform = 2;  // experiment: partner quads (no mirror in the oracle)
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
@@ -1737,6 +1742,11 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
             ta.far_relax = s->tile_far_relax_override > 0.0f ? s->tile_far_relax_override : pgsgd::tile_far_relax(s->relax_iter - 1);
+            if (s->tile_far_relax_override <= 0.0f && (s->tile_far_relax_max > 0.0f || s->tile_far_relax_slope > 0.0f)) {   // (experiment: another ceiling / slope of the ramp)
+                const float mx = s->tile_far_relax_max > 0.0f ? s->tile_far_relax_max : 1.0f, sl = s->tile_far_relax_slope > 0.0f ? s->tile_far_relax_slope : 0.2f;
+                const uint64_t it = s->relax_iter - 1;
+                ta.far_relax = it < 2 ? std::min(mx, sl) : std::min(mx, sl * (float)it);
+            }
             ta.far_prev = s->d_far + 2 * colour + ((launches + 1) & 1u);
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
@@ -1744,6 +1754,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.wq_threshold = s->tile_wq_threshold;
             ta.lane_coin = s->tile_lane_coin;
             ta.snap_every = s->tile_snap_every;
+            ta.tile_rotate = s->tile_rotate;
             ta.lock_mu = s->tile_lock_mu;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;

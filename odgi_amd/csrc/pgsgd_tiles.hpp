@@ -174,6 +174,7 @@ struct TileArgs {
     uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
+    uint32_t tile_rotate;              // debug knob PGSGD_TILE_ROTATE: an item's tiles start at another one every iteration (which path has the last word on a window)
     Outbox ob;
 };
 
@@ -477,18 +478,21 @@ __device__ __forceinline__ void outbox_flush_rings(const Outbox& ob, const Outbo
 //                  iteration.  Measured (profiles/r01/one_sided_far_experiment.jsonl): stress +1..9 %; not the
 //                  reference's rule, never the default.
 constexpr int kFarTwoSided = 0, kFarExclusive = 2;
-// Under-relaxation of a launch's far pulls: together they amount to this fraction of a projection (see the kernel).
-// Half a projection — except in the first iterations: there the layout is globally inconsistent (a `-N d` layout has to
+// Relaxation of a launch's far pulls: together they amount to this fraction of a projection (see the kernel).
+// ONE projection: an end that h far terms pull in a launch moves by the mean of their h half-errors, which is what one term of
+// the reference does to it — except in the first iterations: there the layout is globally inconsistent (a `-N d` layout has to
 // contract by the share of nodes a path skips), the dozen-odd long-range pulls an end averages over are then a noisy
-// estimate of where it should go, and the noise — not the mean — is what neighbouring nodes see: at 0.5 the first
-// iteration leaves neighbours ten thousand bp apart (sampled stress 20-60x the reference's at that point).  Noise and
+// estimate of where it should go, and the noise — not the mean — is what neighbouring nodes see (at a constant 0.5 the first
+// iteration leaves neighbours ten thousand bp apart: sampled stress 20-60x the reference's at that point).  Noise and
 // mean both scale with the factor, the reference itself does not converge globally before its learning rate falls
 // (iteration ~15 of 30), so the first iterations pull gently and the factor ramps up while the windows' local terms and
-// the mean field bring the layout together: measured on the CPU mirror, 1e5 nodes (tools/cpu_transient.py,
-// profiles/r03/far_relax_schedules.txt) stress after iterations 1/2/3/5/10: 1.8e3 1.3e3 3.6e3 2.8e3 12 (reference:
-// 1.6e3 until iteration 10; constant 0.5: 3.1e4 5.2e3 9.2e2 45 11), the same final layout.
+// the mean field bring the layout together (tools/cpu_transient.py, profiles/r03/far_relax_schedules.txt).
+// Rounds 3-5 ramped 0.1 0.1 0.2 0.3 0.4 to HALF a projection.  Measured in round 6 with the evaluator that has no sampling
+// error (pgsgd_path_stress_near; profiles/r06/NOTES.md section 1) at 1e7 nodes: on the default schedule the ramp and its ceiling
+// change nothing (tile kernel +1.2 % over the per-lane kernel with either), on a SHORT schedule (`-x 15 -G 2`) the slow ramp
+// to 0.5 costs +7.3 %, this one +0.4 % (constant 0.75 / 1.0: -1.4 / -0.6 %; ramp 0.1.. to 1.0: +5.2 %; 0.25: +18 %).
 __host__ __device__ inline float tile_far_relax(uint64_t iteration /* 0-based */) {
-    return iteration < 2 ? 0.1f : iteration < 5 ? 0.1f * (float)iteration : 0.5f;   // 0.1 0.1 0.2 0.3 0.4 0.5 ...
+    return iteration < 2 ? 0.2f : iteration < 5 ? 0.2f * (float)iteration : 1.0f;   // 0.2 0.2 0.4 0.6 0.8 1.0 ...
 }
 
 // What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has
@@ -719,8 +723,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     // after the launch: all the far pulls an end receives during one launch are computed against one stale position
     // and land together — a Jacobi step.  With mu = 1 each is a full projection and h of them overshoot h-fold (stress
     // 1e7 in the first iterations, profiles/r01/convergence_*.jsonl), so such terms are capped at mu = far_relax / h,
-    // h = far pulls per node end in the previous launch of this colour: together they amount to half a projection,
-    // the usual under-relaxation of a Jacobi step (measured against 1 and 1/4: profiles/r02/curves_far_policy.jsonl),
+    // h = far pulls per node end in the previous launch of this colour: together they amount to one projection (rounds 2-5:
+    // half, the usual under-relaxation of a Jacobi step; measured again in round 6: tile_far_relax),
     // less in the first iterations (tile_far_relax).  Inactive once eta/d < far_relax / h.
     float far_mu_cap = TILE_COLD(ta.far_mu_cap_first);
     if (TILE_COLD(ta.far_from_prev)) {
@@ -773,7 +777,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
                 win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(LOCAL ? TILE_COLD(c.coords) : c.coords, wbase + i) : 0;
         }
-        for (uint32_t ti = wi.tile_begin; ti < wi.tile_end; ++ti) {
+        const uint32_t n_item_tiles = wi.tile_end - wi.tile_begin;
+        const uint32_t rot = TILE_COLD(ta.tile_rotate) && n_item_tiles ? (uint32_t)(((uint32_t)a.epoch * 0x9e3779b1u + wi.win0) % n_item_tiles) : 0u;
+        for (uint32_t tk = 0; tk < n_item_tiles; ++tk) {
+            const uint32_t ti = wi.tile_begin + (tk + rot >= n_item_tiles ? tk + rot - n_item_tiles : tk + rot);
             if (ti % TILE_COLD(ta.n_sub) != TILE_COLD(ta.sub)) continue;  // block-uniform
             const Tile t = TILE_COLD(ta.tiles)[ti];
             __syncthreads();  // previous tile's terms are done with trec; window staging is complete

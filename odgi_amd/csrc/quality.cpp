@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "pgsgd_internal.hpp"
@@ -62,6 +63,82 @@ extern "C" int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, con
         ++cnt;
     }
     *stress = cnt ? acc / (double)cnt : 0.0;
+    return PGSGD_OK;
+}
+
+// The NEAR part of the sampled path stress, exhaustively: every pair of steps at most zmax steps apart on a path, all four
+// end choices, weighted by the probability with which the warm-iteration sampler (and pgsgd_path_stress) draws it.  The sampled
+// stress is a mean of squared RELATIVE errors: pairs a few bp apart dominate it and its distribution is so heavy-tailed that a
+// hundred pairs of a 2e6-pair sample carry a third of the figure (profiles/r06/NOTES.md) — two layouts of equal quality can differ
+// by 10 % on one fixed sample.  This sum has no sampling error.
+//   num[(z-1)*4 + 2*flip_a + flip_b] = sum over pairs (k, k+z) of P(pair) * ((|p_a - p_b| - d) / d)^2      (d > 0)
+//   mass[...]                        = sum of P(pair) over the same pairs                                  (d > 0)
+//   zero_mass                        = probability of drawing a pair with d = 0 among these (skipped by the metric)
+// P(pair): first step uniform over all steps, Zipf branch 1/2, direction 1/2 (1 at a path's ends), jump z with probability
+// z^-theta / H(min(space, room)), either end choice 1/2 — from both sides of the pair.  sum(num) / (1 - P(d = 0) overall) is
+// the near pairs' exact contribution to the expected sampled stress.
+// hist_step[m] / hist_rank[m] (optional): the same numerator by (rank of the earlier step in its path) % mod_step and by
+// (node rank of the earlier step) % mod_rank — where along tiles / regions the stress sits.
+extern "C" int pgsgd_path_stress_near(const pgsgd_graph_view* g, const double* X, const double* Y, uint32_t zmax, double theta, uint32_t threads,
+                                      double* num, double* mass, double* zero_mass, uint32_t mod_step, double* hist_step, uint32_t mod_rank, double* hist_rank) {
+    pgsgd::clear_error();
+    int rc = pgsgd_validate_view(g);
+    if (rc) return rc;
+    if (!X || !Y || !num || !mass || zmax == 0 || zmax > 64) return PGSGD_E_INVALID;
+    uint64_t max_steps = 0;
+    for (uint64_t p = 0; p < g->n_paths; ++p) max_steps = std::max(max_steps, g->path_first[p + 1] - g->path_first[p]);
+    std::vector<double> H(max_steps + 1, 0.0);   // H[n] = sum_{k<=n} k^-theta (the sampler's space is the longest path)
+    for (uint64_t n = 1; n <= max_steps; ++n) H[n] = H[n - 1] + std::pow((double)n, -theta);
+    std::vector<double> zw(zmax + 1, 0.0);
+    for (uint32_t z = 1; z <= zmax; ++z) zw[z] = std::pow((double)z, -theta);
+    const uint32_t T = std::max<uint32_t>(1, threads);
+    const size_t nc = (size_t)zmax * 4;
+    std::vector<std::vector<double>> t_num(T, std::vector<double>(nc, 0.0)), t_mass(T, std::vector<double>(nc, 0.0)), t_hs(T), t_hr(T);
+    std::vector<double> t_zero(T, 0.0);
+    for (uint32_t t = 0; t < T; ++t) { if (hist_step) t_hs[t].assign(mod_step, 0.0); if (hist_rank) t_hr[t].assign(mod_rank, 0.0); }
+    const double inv_steps = 1.0 / (double)g->n_steps;
+    auto work = [&](uint32_t t) {
+        for (uint64_t p = 0; p < g->n_paths; ++p) {
+            const uint64_t b = g->path_first[p], c = g->path_first[p + 1] - b;
+            if (c < 2) continue;
+            const uint64_t lo = c * t / T, hi = c * (t + 1) / T;
+            for (uint64_t s = lo; s < hi; ++s) {
+                const uint64_t k = b + s;
+                const uint32_t ha = g->step_handle[k];
+                const double la = (double)g->node_len[ha >> 1], pa0 = (double)g->step_pos[k];
+                // k as the first step, jumping forward: direction coin 1/2, or certain at the path's first step
+                const double fwd_a = (s == 0 ? 1.0 : s == c - 1 ? 0.0 : 0.5) / H[std::min<uint64_t>(max_steps, c - s - 1)];
+                for (uint32_t z = 1; z <= zmax && s + z < c; ++z) {
+                    const uint64_t kb = k + z, sb = s + z;
+                    const uint32_t hb = g->step_handle[kb];
+                    const double lb = (double)g->node_len[hb >> 1], pb0 = (double)g->step_pos[kb];
+                    const double back_b = (sb == c - 1 ? 1.0 : 0.5) / H[std::min<uint64_t>(max_steps, sb)];   // kb as the first step, jumping back
+                    const double w = inv_steps * 0.5 * zw[z] * (fwd_a + back_b) * 0.25;
+                    for (uint32_t f = 0; f < 4; ++f) {
+                        const uint32_t fa = f >> 1, fb = f & 1u;
+                        const double d = std::fabs((pa0 + (fa ? la : 0.0)) - (pb0 + (fb ? lb : 0.0)));
+                        if (d == 0) { t_zero[t] += w; continue; }
+                        const uint64_t i = (uint64_t)(ha ^ fa), j = (uint64_t)(hb ^ fb);
+                        const double dx = X[i] - X[j], dy = Y[i] - Y[j];
+                        const double e = (std::sqrt(dx * dx + dy * dy) - d) / d;
+                        const size_t cl = (size_t)(z - 1) * 4 + f;
+                        t_num[t][cl] += w * e * e;
+                        t_mass[t][cl] += w;
+                        if (hist_step) t_hs[t][s % mod_step] += w * e * e;
+                        if (hist_rank) t_hr[t][(ha >> 1) % mod_rank] += w * e * e;
+                    }
+                }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (size_t i = 0; i < nc; ++i) { num[i] = mass[i] = 0.0; for (uint32_t t = 0; t < T; ++t) { num[i] += t_num[t][i]; mass[i] += t_mass[t][i]; } }
+    if (zero_mass) { *zero_mass = 0.0; for (uint32_t t = 0; t < T; ++t) *zero_mass += t_zero[t]; }
+    if (hist_step) for (uint32_t m = 0; m < mod_step; ++m) { hist_step[m] = 0.0; for (uint32_t t = 0; t < T; ++t) hist_step[m] += t_hs[t][m]; }
+    if (hist_rank) for (uint32_t m = 0; m < mod_rank; ++m) { hist_rank[m] = 0.0; for (uint32_t t = 0; t < T; ++t) hist_rank[m] += t_hr[t][m]; }
     return PGSGD_OK;
 }
 

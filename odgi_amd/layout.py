@@ -396,6 +396,29 @@ def path_stress(graph: Graph, X, Y, n_pairs=1_000_000, seed=0x5eed):
     return s.value
 
 
+def path_stress_near(graph: Graph, X, Y, zmax=3, theta=0.99, threads=0, mod_step=0, mod_rank=0):
+    """The near pairs' part of the expected sampled stress without sampling error (pgsgd_path_stress_near): every pair of
+    steps at most zmax apart, all end choices, weighted by the sampler's probability.  Returns dict(num [zmax, 2, 2], mass
+    [zmax, 2, 2], zero_mass, near = num.sum() / (1 - zero_mass): the pairs' contribution to the expectation when pairs
+    beyond zmax are ignored in the normalisation's d = 0 share; hist_step / hist_rank when asked for)."""
+    import os
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    num, mass = np.zeros(zmax * 4), np.zeros(zmax * 4)
+    zero = C.c_double()
+    hs = np.zeros(mod_step) if mod_step else None
+    hr = np.zeros(mod_rank) if mod_rank else None
+    threads = threads or min(64, os.cpu_count() or 1)
+    check(lib.pgsgd_path_stress_near(C.byref(graph.view), _f64(X), _f64(Y), zmax, theta, threads, _f64(num), _f64(mass), C.byref(zero),
+                                     mod_step, _f64(hs) if mod_step else None, mod_rank, _f64(hr) if mod_rank else None), "path_stress_near")
+    out = dict(num=num.reshape(zmax, 2, 2), mass=mass.reshape(zmax, 2, 2), zero_mass=zero.value, near=float(num.sum() / (1.0 - zero.value)))
+    if mod_step:
+        out["hist_step"] = hs
+    if mod_rank:
+        out["hist_rank"] = hr
+    return out
+
+
 def path_distance(graph: Graph, X, Y):
     X = np.ascontiguousarray(X, dtype=np.float64)
     Y = np.ascontiguousarray(Y, dtype=np.float64)

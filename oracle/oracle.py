@@ -204,9 +204,10 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
     return X, Y, d.value, ck
 
 
-TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN, TILE_NO_PAIRS = 1, 2, 4, 8, 16, 32, 64
+TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN, TILE_NO_PAIRS, TILE_RELAX_R5 = 1, 2, 4, 8, 16, 32, 64, 128
 TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN | TILE_NO_PAIRS   # the launch order, far-pull policy and per-lane coin of round 2
-TILE_ROUND3 = TILE_LANE_COIN | TILE_NO_PAIRS   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane
+TILE_ROUND3 = TILE_LANE_COIN | TILE_NO_PAIRS | TILE_RELAX_R5   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane, far pulls ramping to half a projection
+TILE_ROUND5 = TILE_RELAX_R5   # rounds 4-5: wave coin, partner pairs; far pulls ramping 0.1 .. 0.5 (round 6: 0.2 .. 1.0)
 
 
 def tile_wave_coin(seed_base, epoch, tile, wave, trip):
@@ -287,6 +288,19 @@ def _d(a):
 def path_stress_sampled(g, X, Y, n_pairs=1_000_000, seed=0x5eed):
     X, Y = _d(X), _d(Y)
     return lib().orc_path_stress_sampled(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), n_pairs, seed)
+
+
+def path_stress_near(g, X, Y, zmax=4, theta=0.99, threads=0):
+    """The near pairs' exact contribution to the expectation of path_stress_sampled (orc_path_stress_near):
+    dict(num [zmax, 2, 2], mass [zmax, 2, 2], zero_mass, near = num.sum() / (1 - zero_mass))."""
+    X, Y = _d(X), _d(Y)
+    num, mass, zero = np.zeros(zmax * 4), np.zeros(zmax * 4), C.c_double()
+    f = lib().orc_path_stress_near
+    f.restype = None
+    f.argtypes = [C.POINTER(OrcGraph), _F64P, _F64P, C.c_uint32, C.c_double, C.c_uint32, _F64P, _F64P, C.POINTER(C.c_double)]
+    f(C.byref(g.view), X.ctypes.data_as(_F64P), Y.ctypes.data_as(_F64P), zmax, theta, threads or (os.cpu_count() or 1),
+      num.ctypes.data_as(_F64P), mass.ctypes.data_as(_F64P), C.byref(zero))
+    return {"num": num.reshape(zmax, 2, 2), "mass": mass.reshape(zmax, 2, 2), "zero_mass": zero.value, "near": float(num.sum() / (1.0 - zero.value))}
 
 
 def path_stress_exhaustive(g, X, Y):

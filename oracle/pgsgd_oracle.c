@@ -887,6 +887,81 @@ double orc_path_stress_sampled(const orc_graph* g, const double* X, const double
     return cnt ? acc / (double)cnt : 0.0;
 }
 
+/* The near part of the EXPECTATION of orc_path_stress_sampled, term by term: every draw the warm-iteration sampler can make with a
+ * Zipf jump of at most zmax steps (path_sgd_layout.cpp:178-269: first step uniform over all steps, Zipf branch 1/2, direction coin —
+ * forced at a path's ends, :206-207 — jump z with probability z^-theta / H(min(space, room)), end coins 1/2 each), weighted by its
+ * probability.  Written from the sampler's side (first step, direction, jump), where the product's pgsgd_path_stress_near walks
+ * unordered pairs: two formulations of one sum, compared in tests/test_host_logic.py.
+ * num[(z-1)*4 + 2*flip_first + flip_partner] with the pair oriented (earlier step, later step); *zero_mass: probability of d = 0. */
+typedef struct { const orc_graph* g; const double *X, *Y, *H, *zw; uint32_t zmax, tid, nt; uint64_t max_steps; double *num, *mass, zero; } near_work;
+static void* near_run(void* arg) {
+    near_work* w = (near_work*)arg;
+    const orc_graph* g = w->g;
+    const double per_step = 1.0 / (double)g->n_steps;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) {
+        const uint64_t b = g->path_first[pi], c = g->path_first[pi + 1] - b;
+        if (c < 2) continue;
+        for (uint64_t s = c * w->tid / w->nt; s < c * (w->tid + 1) / w->nt; ++s)
+            for (int back = 0; back < 2; ++back) {
+                /* :206: the jump goes back when (s > 0 and the coin says so) or s is the path's last step */
+                const double p_dir = back ? (s == c - 1 ? 1.0 : s > 0 ? 0.5 : 0.0) : (s == 0 ? 1.0 : s < c - 1 ? 0.5 : 0.0);
+                if (p_dir == 0.0) continue;
+                const uint64_t room = back ? s : c - s - 1;
+                const uint64_t jump = room < w->max_steps ? room : w->max_steps;
+                for (uint32_t z = 1; z <= w->zmax && z <= jump; ++z) {
+                    const uint64_t ka = b + s, kb = back ? ka - z : ka + z;
+                    const double pr = per_step * 0.5 * p_dir * w->zw[z] / w->H[jump] * 0.25;
+                    for (uint32_t fa = 0; fa < 2; ++fa)
+                        for (uint32_t fb = 0; fb < 2; ++fb) {
+                            const uint32_t ha = g->step_handle[ka], hb = g->step_handle[kb];
+                            const double pa = (double)g->step_pos[ka] + (fa ? (double)g->node_len[ha >> 1] : 0.0);
+                            const double pb = (double)g->step_pos[kb] + (fb ? (double)g->node_len[hb >> 1] : 0.0);
+                            const double d = fabs(pa - pb);
+                            if (d == 0) { w->zero += pr; continue; }
+                            const uint64_t i = (uint64_t)(ha ^ fa), j = (uint64_t)(hb ^ fb);
+                            const double dx = w->X[i] - w->X[j], dy = w->Y[i] - w->Y[j];
+                            const double e = (sqrt(dx * dx + dy * dy) - d) / d;
+                            const size_t cl = (size_t)(z - 1) * 4 + (back ? 2 * fb + fa : 2 * fa + fb);   /* (earlier step, later step) */
+                            w->num[cl] += pr * e * e;
+                            w->mass[cl] += pr;
+                        }
+                }
+            }
+    }
+    return NULL;
+}
+void orc_path_stress_near(const orc_graph* g, const double* X, const double* Y, uint32_t zmax, double theta, uint32_t nthreads,
+                          double* num, double* mass, double* zero_mass) {
+    uint64_t max_steps = 0;
+    for (uint64_t pi = 0; pi < g->n_paths; ++pi) {
+        const uint64_t c = g->path_first[pi + 1] - g->path_first[pi];
+        if (c > max_steps) max_steps = c;
+    }
+    double* H = (double*)calloc(max_steps + 1, sizeof(double));
+    double* zw = (double*)calloc(zmax + 1, sizeof(double));
+    for (uint64_t n = 1; n <= max_steps; ++n) H[n] = H[n - 1] + pow((double)n, -theta);
+    for (uint32_t z = 1; z <= zmax; ++z) zw[z] = pow((double)z, -theta);
+    if (nthreads < 1) nthreads = 1;
+    near_work* ws = (near_work*)calloc(nthreads, sizeof(near_work));
+    pthread_t* th = (pthread_t*)calloc(nthreads, sizeof(pthread_t));
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        near_work* w = &ws[t];
+        w->g = g; w->X = X; w->Y = Y; w->H = H; w->zw = zw; w->zmax = zmax; w->tid = t; w->nt = nthreads; w->max_steps = max_steps;
+        w->num = (double*)calloc((size_t)zmax * 4, sizeof(double));
+        w->mass = (double*)calloc((size_t)zmax * 4, sizeof(double));
+        pthread_create(&th[t], NULL, near_run, w);
+    }
+    for (size_t i = 0; i < (size_t)zmax * 4; ++i) num[i] = mass[i] = 0.0;
+    *zero_mass = 0.0;
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        for (size_t i = 0; i < (size_t)zmax * 4; ++i) { num[i] += ws[t].num[i]; mass[i] += ws[t].mass[i]; }
+        *zero_mass += ws[t].zero;
+        free(ws[t].num); free(ws[t].mass);
+    }
+    free(ws); free(th); free(H); free(zw);
+}
+
 double orc_path_stress_exhaustive(const orc_graph* g, const double* X, const double* Y) {
     double acc = 0.0;
     uint64_t cnt = 0;
@@ -1188,9 +1263,11 @@ double orc_sort_stress(const orc_graph* g, const double* X, uint64_t n_pairs, ui
  * counted in the previous launch of the same parity (first iteration: 0.75 * 0.5 * n_terms / 2N assumed).
  * The tile table and the work items are the product's (pgsgd_session_tile_table / _tile_items); the test
  * checks them separately as an exact partition of steps and terms. */
-/* Under-relaxation of the far pulls of a launch (pgsgd_tiles.hpp: tile_far_relax): together they amount to this
- * fraction of a projection — half, less in the first five iterations.  ORC_FAR_RELAX="r0,r1,..." (experiments, tools/cpu_transient.py) overrides the schedule:
+/* Relaxation of the far pulls of a launch (pgsgd_tiles.hpp: tile_far_relax): together they amount to this
+ * fraction of a projection — one, less in the first five iterations (rounds 3-5: half, reached as slowly: orc_tile_far_relax_r5).
+ * ORC_FAR_RELAX="r0,r1,..." (experiments, tools/cpu_transient.py) overrides the schedule:
  * iteration i uses r_i, iterations past the list the last value. */
+static float orc_tile_far_relax_r5(uint64_t iter) { return iter < 2 ? 0.1f : iter < 5 ? 0.1f * (float)iter : 0.5f; }   /* 0.1 0.1 0.2 0.3 0.4 0.5 ... */
 float orc_tile_far_relax(uint64_t iter) {
     const char* e = getenv("ORC_FAR_RELAX");
     if (e) {
@@ -1204,7 +1281,7 @@ float orc_tile_far_relax(uint64_t iter) {
         }
         return v;
     }
-    return iter < 2 ? 0.1f : iter < 5 ? 0.1f * (float)iter : 0.5f;   /* 0.1 0.1 0.2 0.3 0.4 0.5 ... (pgsgd_tiles.hpp: tile_far_relax) */
+    return iter < 2 ? 0.2f : iter < 5 ? 0.2f * (float)iter : 1.0f;   /* 0.2 0.2 0.4 0.6 0.8 1.0 ... (pgsgd_tiles.hpp: tile_far_relax) */
 }
 
 static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t pos_b, float dx, float dy, float mu_cap,
@@ -1239,6 +1316,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
  *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
  *   ORC_TILE_NO_PAIRS       every lane keeps its own uniform partner (rounds 2 and 3; PGSGD_FLAG_NO_PARTNER_PAIRS)
+ *   ORC_TILE_RELAX_R5       the far pulls' relaxation of rounds 3-5: 0.1 0.1 0.2 0.3 0.4 then half a projection (round 6: 0.2 ... 0.8 then one)
  * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
 void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
@@ -1308,7 +1386,7 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
         const float eta = (float)etas[iter];
         const int cooling = iter >= first_cooling;
         const uint64_t epoch = iter + 1;
-        const float far_relax = (policy & ORC_TILE_CONSTANT_RELAX) ? 0.5f : orc_tile_far_relax(iter);
+        const float far_relax = (policy & ORC_TILE_CONSTANT_RELAX) ? 0.5f : (policy & ORC_TILE_RELAX_R5) ? orc_tile_far_relax_r5(iter) : orc_tile_far_relax(iter);
         float dmax = 0.0f;
         uint64_t far_count[2] = {0, 0};
         int snap_taken = 0;

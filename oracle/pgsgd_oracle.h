@@ -93,6 +93,7 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 #define ORC_TILE_SNAPSHOT_PASS 16u
 #define ORC_TILE_LANE_COIN 32u
 #define ORC_TILE_NO_PAIRS 64u
+#define ORC_TILE_RELAX_R5 128u
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
                          const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,
@@ -134,6 +135,8 @@ void orc_layout_hogwild_curve(const orc_graph* g, const orc_params* p, uint32_t 
 double orc_path_stress_sampled(const orc_graph* g, const double* X, const double* Y,
                                uint64_t n_pairs, uint64_t seed);
 /* all same-path step pairs a<b, step-start ends, d = pos_b - pos_a */
+void orc_path_stress_near(const orc_graph* g, const double* X, const double* Y, uint32_t zmax, double theta, uint32_t nthreads,
+                          double* num, double* mass, double* zero_mass);   /* expectation of the sampled stress over Zipf jumps <= zmax, exactly */
 double orc_path_stress_exhaustive(const orc_graph* g, const double* X, const double* Y);
 /* odgi stats -s, 2D branch (stats_main.cpp:667-716) */
 void orc_path_distance(const orc_graph* g, const double* X, const double* Y, double* per_node, double* per_bp);

@@ -50,6 +50,9 @@ out.update({f"tile_mirror_r2/{k}": v for k, v in tile_mirror_case(orc, pyref, or
 # ... and with round 3's pipeline (today's launch order, the Zipf/uniform coin of a warm term per lane instead of per
 # wave and trip): the vectors committed in round 3 as tile_mirror/*, unchanged
 out.update({f"tile_mirror_r3/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_ROUND3).items()})
+# ... and with rounds 4-5's (wave coin, partner pairs, far pulls ramping 0.1 .. to HALF a projection; round 6 ramps 0.2 .. to
+# one): the vectors committed in round 5 as tile_mirror/*, unchanged
+out.update({f"tile_mirror_r5/{k}": v for k, v in tile_mirror_case(orc, pyref, orc.TILE_ROUND5).items()})
 # a regeneration may add arrays and replace tile_mirror/* when the shipped pipeline changes; everything else must come
 # out as committed
 path = os.path.join(GOLDEN, "golden_vectors.npz")

@@ -270,6 +270,12 @@ def test_tile_mirror_golden_regression(orc):
     for k, v in r3.items():
         assert np.array_equal(v, gv[f"tile_mirror_r3/{k}"]), k
     assert not np.array_equal(r3["X"], got["X"])
+    # rounds 4-5 (today's sampler; the far pulls of a launch ramped 0.1 0.1 0.2 0.3 0.4 to half a projection where round 6
+    # ramps 0.2 .. 0.8 to one) still give the vectors committed in round 5
+    r5 = tile_mirror_case(orc, pyref, policy=orc.TILE_ROUND5)
+    for k, v in r5.items():
+        assert np.array_equal(v, gv[f"tile_mirror_r5/{k}"]), k
+    assert not np.array_equal(r5["X"], got["X"])
 
 
 def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):

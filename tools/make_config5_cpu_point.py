@@ -24,12 +24,19 @@ TERMS_PER_STEP = 2
 
 
 def main():
+    global ITER_MAX, TERMS_PER_STEP, SNAP_ITERS
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "config5_cpu_point.json"))
+    ap.add_argument("--iter-max", type=int, default=ITER_MAX)           # round 6: a second, longer point (-x 30 -G 2) in config5_cpu_point_x30.json
+    ap.add_argument("--terms-per-step", type=int, default=TERMS_PER_STEP)
+    ap.add_argument("--save-layout", default="")                        # .npz of the final X, Y (not committed: 320 MB)
+    ap.add_argument("--classes", action="store_true")                   # tools/stress_classes.py of the final layout into the record
     args = ap.parse_args()
+    ITER_MAX, TERMS_PER_STEP = args.iter_max, args.terms_per_step
+    SNAP_ITERS = [ITER_MAX // 3, 2 * ITER_MAX // 3, ITER_MAX]
     import odgi_amd as oa
     from oracle import oracle as orc
     g = oa.Graph.synthetic(args.nodes, 50, seed=42)
@@ -52,6 +59,15 @@ def main():
                "stress_at": [orc.path_stress_sampled(og, sx[k], sy[k], EVAL_PAIRS, EVAL_SEED) for k in range(len(SNAP_ITERS))],
                "stress_final": orc.path_stress_sampled(og, X, Y, EVAL_PAIRS, EVAL_SEED),
                "terms": st["terms"], "iterations": st["iterations"], "seconds": st["seconds"], "wall": time.time() - t}
+        ne = orc.path_stress_near(og, X, Y, zmax=4, threads=args.threads)   # no sampling error (oracle/pgsgd_oracle.c: orc_path_stress_near)
+        rec["near_exact"] = {"near": ne["near"], "by_z": ne["num"].sum(axis=(1, 2)).tolist(), "zero_mass": ne["zero_mass"], "zmax": 4}
+        if args.classes:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import stress_classes
+            rec["classes"] = stress_classes.classes(g, X, Y)
+        if args.save_layout:
+            import numpy as np
+            np.savez(args.save_layout + f".run{r}.npz", X=X, Y=Y)
         print(json.dumps(rec), flush=True)
         out["runs"].append(rec)
         with open(args.out, "w") as f:
