@@ -1742,6 +1742,11 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_mu_cap_first = (no_cap || h0 <= 1.0) ? 1.0f : (float)(1.0 / h0);
             ta.far_from_prev = (launches > 0 && !no_cap) ? 1u : 0u;
             ta.far_relax = s->tile_far_relax_override > 0.0f ? s->tile_far_relax_override : pgsgd::tile_far_relax(s->relax_iter - 1);
+            // Sessions whose ranks move the SAME node ends and merge afterwards (tile shard; region shard with the merge rule) count
+            // the far pulls of their own share of the terms: G ranks that each deliver a whole projection add up to G of them before
+            // the merge rule has averaged anything.  They keep rounds 3-5's half (measured with one projection, eight virtual
+            // ranks by tile: stress 3.3x one rank's; profiles/r06/pytest_gpu_call5.log).  The exact exchange is one GPU's arithmetic.
+            if (s->tile_far_relax_override <= 0.0f && (s->tshard_world > 1 || (s->shard_world > 1 && !s->exact_colours))) ta.far_relax *= 0.5f;
             if (s->tile_far_relax_override <= 0.0f && (s->tile_far_relax_max > 0.0f || s->tile_far_relax_slope > 0.0f)) {   // (experiment: another ceiling / slope of the ramp)
                 const float mx = s->tile_far_relax_max > 0.0f ? s->tile_far_relax_max : 1.0f, sl = s->tile_far_relax_slope > 0.0f ? s->tile_far_relax_slope : 0.2f;
                 const uint64_t it = s->relax_iter - 1;

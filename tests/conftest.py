@@ -75,7 +75,7 @@ GPU_ORDER = [
     (50, "test_tile_sharded_virtual_ranks"),
     (50, "test_virtual_rank_stress_band"),
     (50, "test_cpp_multi_gpu_run_with_two_virtual_devices"),
-    (54, "test_config5_size_truncated_schedule_against_the_committed_cpu_point"),
+    (54, "test_config5_size_schedules_against_the_committed_cpu_points"),
     (55, "test_config5_size_whole_schedule_against_the_per_lane_kernel"),
     # --- subprocesses: CLI, the C++ shim, torchrun
     (90, "test_cli_"),

@@ -580,7 +580,7 @@ def test_synthetic_million_node_properties(oa, orc):
 
 
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
-TILE_CURVE = {5: 9130.0, 10: 8.59, 15: 6.55}
+TILE_CURVE = {5: 3270.0, 10: 12.3, 15: 9.39}   # round 6 (far pulls ramp 0.2 .. 1.0; rounds 3-5, 0.1 .. 0.5: 9130 / 8.59 / 6.55)
 
 
 def _gpu_curve(oa, orc, g, og, p, X0, Y0, snap_iters, pairs, eval_seed):
@@ -679,7 +679,7 @@ def test_tile_kernel_against_the_reference_rule_at_config4(oa, orc):
             # detected (five runs of this test in round 3: 9065..9165, 8.54..8.66, 6.53..6.57)
             assert 0.75 * TILE_CURVE[it] <= tile[k] <= 1.25 * TILE_CURVE[it], msg
         else:
-            assert tile[k] <= 3.0 * cpu_mean[k], msg                     # the first iteration: measured 0.85x the reference's
+            assert tile[k] <= 4.0 * cpu_mean[k], msg                     # the first iteration: measured 2.5x the reference's (rounds 3-5: 0.85x)
 
 
 _CONFIG5 = {}
@@ -729,97 +729,99 @@ def test_config5_size_properties(oa, tmp_path):
     assert lay.size() == 2 * g.n_nodes and np.isfinite(lay.X).all() and np.isfinite(lay.Y).all()
 
 
-def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
-    """BASELINE config 5 size, the WHOLE 30-iteration schedule (1.4e11 terms): the tile kernel against the per-lane kernel
-    — the reference's rule term by term, within 4 % of the CPU restatement at config 4 — from the same initial layout,
-    one evaluator.  Sampled stress after iteration 30 two-sided within 10 %, after iteration 20 not more than 10 % behind
-    and not more than 20 % ahead."""
-    from odgi_amd import _lib
-    g, (X0, Y0) = _config5_graph(oa)
-    curves, ms = {}, {}
-    for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES)):
-        p = _params(oa, g, flags=flags)
-        etas = oa.path_linear_sgd_layout_schedule(p)
-        out = []
-        with oa.LayoutSession(g, p) as s:
-            s.upload(X0, Y0)
-            assert s.tile_info()["tiled"] == (name == "tile")
-            w0 = s.download_words()
-            for it in range(p.iter_max):
-                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
-                s.sync()
-                if it + 1 in (10, 20, 30):
-                    X, Y = s.download_f64(flush=it + 1 == 30)
-                    assert np.isfinite(X).all() and np.isfinite(Y).all()
-                    out.append(oa.path_stress(g, X, Y, 2_000_000, seed=1))
-            ms[name] = s.kernel_time()[0] + sum(s.aux_time())
-            assert s.outbox_overflow() == 0
-            w1 = s.download_words()    # 1.4e11 terms later: coordinate checksums conserved, every node end moved
+def _near_exact(oa, g, X, Y):
+    """The near pairs' part of the expected sampled stress, without sampling error (pgsgd_path_stress_near, zmax = 4: 99.9 % of
+    the figure at these sizes).  The SAMPLED evaluator is a mean of squared relative errors whose top hundred pairs carry a third
+    of a 2e6-pair sample at 1e7 nodes: on ONE layout its value moves by -10 ... +25 % with its own seed (profiles/r06/NOTES.md
+    section 1), which rounds 4-5 read as a +10 % gap between the kernels.  Two runs of one kernel differ by 0.05 % in this figure."""
+    return oa.path_stress_near(g, X, Y, zmax=4)["near"]
+
+
+def _config5_run(oa, g, X0, Y0, flags, iter_max, min_term_updates, sample_at, checks=True):
+    """One layout of the 1e7-node graph: sampled stress after the iterations in sample_at, the exact near-pair stress of
+    the final layout, milliseconds of kernels."""
+    p = _params(oa, g, flags=flags, iter_max=iter_max, min_term_updates=min_term_updates)
+    etas = oa.path_linear_sgd_layout_schedule(p)
+    out = []
+    with oa.LayoutSession(g, p) as s:
+        s.upload(X0, Y0)
+        tiled = s.tile_info()["tiled"]
+        w0 = s.download_words() if checks else None
+        for it in range(p.iter_max):
+            s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+            s.sync()
+            if it + 1 in sample_at:
+                X, Y = s.download_f64(flush=it + 1 == p.iter_max)
+                assert np.isfinite(X).all() and np.isfinite(Y).all()
+                out.append(oa.path_stress(g, X, Y, 2_000_000, seed=1))
+        ms = s.kernel_time()[0] + sum(s.aux_time())
+        assert s.outbox_overflow() == 0
+        if checks:   # coordinate checksums conserved, every node end moved
+            w1 = s.download_words()
             _FRAME_DOUBLINGS[0] = s.frame_status()[1]
             assert _words_conserved(w0, w1) and np.count_nonzero(w0 != w1) > 19_000_000
-        curves[name] = out
-    print(f"config 5 size, whole schedule: stress after iterations 10/20/30 tile {curves['tile']} ({ms['tile']:.0f} ms of kernels), "
-          f"per-lane {curves['per_lane']} ({ms['per_lane']:.0f} ms)")
-    # measured over three runs of this test: iteration 20: tile 2.01 / 2.08 / 2.06, per-lane 2.12 / 2.14 / 2.33 (the tile kernel is
-    # ahead through the cooling transition, and the per-lane kernel's own runs differ by 9 % there); iteration 30: tile 0.1812
-    # (round 2's order) / 0.1732 / 0.1725, per-lane 0.1637 / 0.1635 / 0.1661.
-    # Round 4, five sampler seeds (tools/gpu_cfg5_ab.py, profiles/r04/cfg5_ab_*.jsonl): tile 0.1732 / 0.1818 / 0.1796 / 0.1787 /
-    # 0.1777 (mean 0.1782), per-lane 0.1657 / 0.1602 / 0.1601 / 0.1599 (mean 0.1615): the tile kernel ends 10 % above the
-    # per-lane kernel at this size (at 1e6 nodes, eight seeds: 0.2518 +- 0.0014 against 0.2550 +- 0.0006 — no gap), and the
-    # gap is none of the far pulls' relaxation (r = 0.25 / 1.0: 0.1737 / 0.1719), their staleness (snapshot pass per
-    # iteration: 0.1724), the fixed-point quantum (4 quanta per bp instead of 1: 0.1775), or concurrent moves of one node end
-    # (locks: 0.1790); it sits in pairs fewer than 30 steps apart.  Open (DESIGN.md "what comes next"); the band states it.
-    assert 0.80 * curves["per_lane"][1] <= curves["tile"][1] <= 1.1 * curves["per_lane"][1], curves
-    assert 0.95 * curves["per_lane"][2] <= curves["tile"][2] <= 1.15 * curves["per_lane"][2], curves
-    assert curves["tile"][0] <= 1.1 * curves["per_lane"][0]   # before cooling the tile kernel is ahead (DESIGN 4a)
+    return dict(tiled=tiled, sampled=out, near=_near_exact(oa, g, X, Y), ms=ms, p=p)
 
 
-def test_config5_size_truncated_schedule_against_the_committed_cpu_point(oa):
-    """Oracle evidence at BASELINE config 5's size.  The CPU restatement cannot run the whole schedule at 1e7 nodes (1.4e11
-    terms: hours on 256 threads), so it ran a truncated one — `-x 15 -G 2`: 15 iterations of 2*S terms, the shortest schedule
-    the product runs the tile kernel on — once per initial layout (tools/make_config5_cpu_point.py, committed as
-    tests/golden/config5_cpu_point.json: 1.4e10 terms, 17 minutes per run on this container's 8 cores).  Both GPU kernels
-    run the same schedule from the same initial layout (seed 42) and are scored with the same evaluator (2e6 pairs, seed 1):
-    final stress two-sided against the CPU runs."""
-    import json
+def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
+    """BASELINE config 5 size, the WHOLE 30-iteration schedule (1.4e11 terms): the tile kernel against the per-lane kernel
+    — the reference's rule term by term — from the same initial layout, scored by the evaluator WITHOUT sampling error
+    (every pair of steps at most four apart, all end choices, weighted as the sampler draws them: _near_exact): the tile
+    kernel's final layout within 3 % of the per-lane kernel's, two-sided.  Measured (profiles/r06/gap_near_exact_1e7_whole.jsonl,
+    three sampler seeds): per-lane 0.16170 / 0.16175 / 0.16178, tile 0.16368 / 0.16312 / 0.16305 = +0.8 ... +1.2 %.
+    (Rounds 4-5 compared 2e6-pair SAMPLES, seed 1 — 0.183 against 0.167, 'a 10 % gap' — and looked for its cause for two
+    rounds: the same two layouts under evaluator seeds 1..8 give tile / per-lane = 1.10 0.85 0.95 0.96 1.01 1.02 1.10 0.97,
+    profiles/r06/evaluator_seed_sweep_1e7_whole.jsonl.  The sampled figures are still printed, with a band as wide as that.)"""
     from odgi_amd import _lib
-    with open(os.path.join(GOLDEN, "config5_cpu_point.json")) as f:
-        ref = json.load(f)
+    g, (X0, Y0) = _config5_graph(oa)
+    r = {name: _config5_run(oa, g, X0, Y0, flags, 30, 10 * g.n_steps, (10, 20, 30)) for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES))}
+    assert r["tile"]["tiled"] and not r["per_lane"]["tiled"]
+    print(f"config 5 size, whole schedule: exact near-pair stress tile {r['tile']['near']:.5f} ({r['tile']['ms']:.0f} ms of kernels), per-lane {r['per_lane']['near']:.5f} "
+          f"({r['per_lane']['ms']:.0f} ms), ratio {r['tile']['near'] / r['per_lane']['near']:.4f}; sampled (2e6 pairs, seed 1) after iterations 10/20/30: tile {r['tile']['sampled']}, per-lane {r['per_lane']['sampled']}")
+    assert 0.97 * r["per_lane"]["near"] <= r["tile"]["near"] <= 1.03 * r["per_lane"]["near"], (r["tile"]["near"], r["per_lane"]["near"])
+    t, l = r["tile"]["sampled"], r["per_lane"]["sampled"]
+    assert 0.75 * l[2] <= t[2] <= 1.3 * l[2], (t, l)     # the sampled evaluator's own scatter on one layout
+    assert 0.80 * l[1] <= t[1] <= 1.1 * l[1], (t, l)     # through the cooling transition the tile kernel is ahead (2.0-2.1 against 2.1-2.3)
+    assert t[0] <= 1.1 * l[0]                            # before cooling the tile kernel is ahead (DESIGN 4.5)
+
+
+def _cpu_point(name):
+    import json
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("point", ["config5_cpu_point.json", "config5_cpu_point_x30.json"])
+def test_config5_size_schedules_against_the_committed_cpu_points(oa, point):
+    """Oracle evidence at BASELINE config 5's size.  The CPU restatement ran the schedules it can finish at 1e7 nodes —
+    `-x 15 -G 2` (1.4e10 terms, the shortest schedule the product runs the tile kernel on; 17 minutes per run on this
+    container's 8 cores) and `-x 30 -G 2` (2.8e10 terms, 40 minutes) — from the initial layout the GPU starts from
+    (tools/make_config5_cpu_point.py; tests/golden/config5_cpu_point*.json), and its final layouts were scored by the
+    ORACLE's exact near-pair evaluator (orc_path_stress_near; tests/test_host_logic.py checks it against the product's).
+    Both GPU kernels run the same schedule from the same layout: exact near-pair stress of the final layout two-sided
+    within 5 % of the CPU runs' (measured: see the assertion), sampled stress (2e6 pairs, seed 1: the figure rounds 4-5
+    compared) printed."""
+    from odgi_amd import _lib
+    ref = _cpu_point(point)
     g, (X0, Y0) = _config5_graph(oa)
     assert ref["graph"] == {"nodes": g.n_nodes, "paths": g.n_paths, "steps": g.n_steps, "seed": 42}
     assert ref["runs"][0]["init_seed"] == 42 and ref["eval_pairs"] == 2_000_000 and ref["eval_seed"] == 1
+    cpu_near = [r["near_exact"]["near"] for r in ref["runs"] if "near_exact" in r]
     cpu_final = [r["stress_final"] for r in ref["runs"]]
-    cpu_at = np.array([r["stress_at"] for r in ref["runs"]])
-    res = {}
-    for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES)):
-        p = _params(oa, g, flags=flags, iter_max=ref["params"]["iter_max"], min_term_updates=ref["params"]["min_term_updates"])
-        assert p.theta == ref["params"]["theta"] and p.cooling_start == ref["params"]["cooling_start"]
-        etas = oa.path_linear_sgd_layout_schedule(p)
-        out = []
-        with oa.LayoutSession(g, p) as s:
-            s.upload(X0, Y0)
-            assert s.tile_info()["tiled"] == (name == "tile")
-            for it in range(p.iter_max):
-                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
-                s.sync()
-                if it + 1 in ref["snap_iters"]:
-                    X, Y = s.download_f64(flush=it + 1 == p.iter_max)
-                    out.append(oa.path_stress(g, X, Y, ref["eval_pairs"], seed=ref["eval_seed"]))
-            assert s.outbox_overflow() == 0
-        res[name] = out
-    print(f"config 5 size, -x 15 -G 2: stress after iterations {ref['snap_iters']}: tile {res['tile']}, per-lane {res['per_lane']}, "
-          f"CPU restatement {cpu_at.tolist()} (final {cpu_final}, {ref['threads']} threads)")
-    c = float(np.mean(cpu_final))
-    # Measured (profiles/r05/pytest_config5_truncated.log): CPU restatement 1.27e5 / 7.99 / 0.1148 after iterations 5 / 10 / 15,
-    # per-lane kernel 1.23e5 / 7.73 / 0.1129 — the reference's rule term by term follows the restatement within 2-4 % all the
-    # way at this size too — and the tile kernel 7.9e6 / 26.3 / 0.1324: its own transient (far pulls capped, DESIGN 4.5; on a
-    # schedule of 2*S terms per iteration there is a fifth of the local terms to absorb them) and a final layout 15 % above
-    # the restatement's.  That is the open 1e7-node gap of the next test (+10 % against the per-lane kernel over the whole
-    # schedule), now measured against the oracle: the per-lane kernel gets +-8 %, the tile kernel -10 % ... +25 % — a band that
-    # STATES the gap, not one that hides it (PGSGD_FLAG_NO_TILES / `--gpu-no-tiles` is the reference-quality plan at this size).
-    assert 0.92 * c <= res["per_lane"][-1] <= 1.08 * c, (res["per_lane"], cpu_final)
-    assert 0.90 * c <= res["tile"][-1] <= 1.25 * c, (res["tile"], cpu_final)
-    assert 0.5 * cpu_at[:, 1].mean() <= res["per_lane"][1] <= 2.0 * cpu_at[:, 1].mean()   # the transient of the reference's rule (iteration 10)
+    assert cpu_near, "the committed CPU point has no exact near-pair figure"
+    c = float(np.mean(cpu_near))
+    res = {name: _config5_run(oa, g, X0, Y0, flags, ref["params"]["iter_max"], ref["params"]["min_term_updates"], ref["snap_iters"], checks=False)
+           for name, flags in (("tile", 0), ("per_lane", _lib.FLAG_NO_TILES))}
+    assert res["tile"]["p"].theta == ref["params"]["theta"] and res["tile"]["p"].cooling_start == ref["params"]["cooling_start"]
+    assert res["tile"]["tiled"] and not res["per_lane"]["tiled"]
+    print(f"config 5 size, -x {ref['params']['iter_max']} -G 2: exact near-pair stress CPU restatement {cpu_near} ({ref['threads']} threads), tile {res['tile']['near']:.5f} "
+          f"({res['tile']['near'] / c:.4f}x), per-lane {res['per_lane']['near']:.5f} ({res['per_lane']['near'] / c:.4f}x); sampled after iterations {ref['snap_iters']}: "
+          f"tile {res['tile']['sampled']}, per-lane {res['per_lane']['sampled']}, CPU final {cpu_final}")
+    # Measured (profiles/r06/NOTES.md section 1): see the table there; the band is +-5 % for both kernels
+    assert 0.95 * c <= res["per_lane"]["near"] <= 1.05 * c, (res["per_lane"]["near"], cpu_near)
+    assert 0.95 * c <= res["tile"]["near"] <= 1.05 * c, (res["tile"]["near"], cpu_near)
+    cs = float(np.mean(cpu_final))
+    assert 0.75 * cs <= res["per_lane"]["sampled"][-1] <= 1.3 * cs and 0.75 * cs <= res["tile"]["sampled"][-1] <= 1.3 * cs   # (the sampled evaluator's own scatter)
 
 
 def _words_conserved(w0, w1):
@@ -1104,7 +1106,7 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     kw = dict(min_term_updates=3 * g.n_steps)
     p = _params(oa, g, **kw)
     etas = oa.path_linear_sgd_layout_schedule(p)
-    res = {}
+    res, sampled = {}, {}
     for G in (1, 2, 4, 8):
         for rep in range(3):
             X0, Y0 = oa.initial_layout(g, "d", seed=7 + rep)
@@ -1139,17 +1141,20 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
             for e in engines:
                 e.close()
             assert np.isfinite(X).all() and np.isfinite(Y).all()
-            res.setdefault(G, []).append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
+            res.setdefault(G, []).append(_near_exact(oa, g, X, Y))   # (no sampling error: _near_exact)
+            sampled.setdefault(G, []).append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
     means = {G: float(np.mean(v)) for G, v in res.items()}
-    print(f"virtual ranks sharded by {mode}: mean stress {means}, runs {res}")
-    # measured (three seeds each; the means of three runs scatter by ~2 % of themselves): round 3 by tile +5.9 / +9.8 / +16.4 %, by
-    # region +3.6 / +5.4 / +5.3 %; round 4 by tile +4.8 / +9.2 / +14.5 %, by region +3.2 / +4.5 / +4.9 %.  Bands = measured + 3 sigma,
-    # two-sided: a merge that made layouts BETTER than one device's would be as suspect as one that made them worse.
+    print(f"virtual ranks sharded by {mode}: mean exact near-pair stress {means}, runs {res}; sampled (1e6 pairs, seed 1) {sampled}")
+    # Measured in round 6 with the evaluator that has no sampling error (three seeds each; one rank's three runs differ by 1.4 %
+    # of their mean, a G-rank mean by less): by tile +2.7 / +5.2 / +11.2 %, by region with the merge rule +0.9 / +1.3 / +2.3 %,
+    # exact exchange +0.10 / +0.14 / +0.11 % (profiles/r06/pytest_gpu_call6.log).  Rounds 3-5 read the SAMPLED evaluator
+    # (1e6 pairs, one seed): by tile +5.9 / +9.8 / +16.4 %, by region +3.6 / +5.4 / +5.3 % — its own scatter on top.  Bands = measured
+    # + a margin, two-sided: a merge that made layouts BETTER than one device's would be as suspect as one that made them worse.
     # With the exact exchange the ranks compute what one GPU computes (bit for bit when the launches are sequential programs:
     # test_region_shard_with_the_exact_exchange_is_one_gpu_bit_for_bit): only the run-to-run scatter of a Hogwild launch is left.
-    band = {"tiles": {2: 1.11, 4: 1.16, 8: 1.22}, "regions": {2: 1.10, 4: 1.11, 8: 1.11}, "regions-exact": {2: 1.04, 4: 1.04, 8: 1.04}}[mode]
+    band = {"tiles": {2: 1.06, 4: 1.09, 8: 1.16}, "regions": {2: 1.03, 4: 1.04, 8: 1.05}, "regions-exact": {2: 1.01, 4: 1.01, 8: 1.01}}[mode]
     for G in (2, 4, 8):
-        assert (0.96 if mode == "regions-exact" else 0.97) * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
+        assert 0.99 * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
 
 
 @pytest.mark.parametrize("G", [2, 3, 8])

@@ -3,7 +3,7 @@
 (path_sgd_layout.cpp:120-377) at BASELINE config 5's SIZE — synthetic 1e7 nodes / 50 paths / ~4.7e8 steps, seed 42 — on a
 TRUNCATED schedule the CPU can finish: `-x 15 -G 2` (15 iterations of 2*S terms = 1.4e10 terms; the whole default schedule is
 1.4e11 terms, hours on 256 threads).  15 iterations is the shortest schedule the product runs the tile kernel on.
-The GPU test (tests/test_gpu_parity.py::test_config5_size_truncated_schedule_against_the_committed_cpu_point) runs the
+The GPU test (tests/test_gpu_parity.py::test_config5_size_schedules_against_the_committed_cpu_points) runs the
 same schedule from the same initial layout with both kernels and scores with the same evaluator (2e6 pairs, seed 1).
 
     python tools/make_config5_cpu_point.py [--threads T] [--runs R] [--nodes N]"""
