@@ -107,6 +107,7 @@ def main():
         eng.flush()   # the warm-up's last far pulls are delivered outside the window (the next launch would deliver them first otherwise)
     eng.session.kernel_time(reset=True)
     counts0 = eng.session.launch_counts()
+    terms_on_device0 = eng.session.terms_executed() if hasattr(eng.session, "terms_executed") else 0
     fence()
     per_iter = []          # (iteration, update-kernel ms, launches, snapshot ms, drain ms) — host bookkeeping after each
     k_prev = (0.0, 0, 0.0, 0.0)   # step's own sync (the product's run loop syncs every iteration for delta_max too)
@@ -129,6 +130,7 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches = eng.session.kernel_time()
     snapshot_ms, drain_ms = eng.session.aux_time()
+    terms_on_device = eng.session.terms_executed() - terms_on_device0 if hasattr(eng.session, "terms_executed") else None
     n_kernels, n_copies = (a - b for a, b in zip(eng.session.launch_counts(), counts0))
 
     total_terms = float(p.min_term_updates) * args.steps
@@ -152,12 +154,15 @@ def main():
         "dtype": "f32 (f64 sampler, q32 coords)",
         "data": "synthetic",
         "config": {"workload": f"synthetic linearised pangenome N={g.n_nodes} S={g.n_steps} P={g.n_paths} seed 42 "
-                               f"(BASELINE configs[3]); {p.min_term_updates} terms per iteration, iter_max {iters}, "
+                               f"({'BASELINE configs[3]' if (g.n_nodes, g.n_paths) == (1_000_000, 50) else 'BASELINE configs[4] size' if (g.n_nodes, g.n_paths) == (10_000_000, 50) else 'not a BASELINE configuration'}); {p.min_term_updates} terms per iteration, iter_max {iters}, "
                                f"theta {p.theta}, timed iterations {args.warmup}..{args.warmup + args.steps - 1}",
                    "streams_per_gpu": int(p.n_streams),
                    # everything a step puts on the stream, and the launches of the dominant kernel among them
                    "kernel_launches_per_step": n_kernels / args.steps, "memset_and_copy_ops_per_step": n_copies / args.steps,
                    "update_kernel_launches_per_step": launches / args.steps,
+                   # `value` divides the terms the schedule ASKS for by the time; what this rank's tile launches EXECUTED in the timed
+                   # window, counted by the kernel's waves on the device (0 / None: per-lane kernel, whose lanes loop over their share)
+                   "terms_requested_this_rank": drv.my_terms() * args.steps, "terms_executed_on_device_this_rank": terms_on_device,
                    "parallelism": f"{getattr(eng, 'shard_mode', 'terms') if drv.engine_sharded else 'terms'}-sharded x{world}, graph replicated, "
                                   + ("2 integer delta all-reduces per eta step (one per region colour; the ranks hold one GPU's coordinates bit for bit)"
                                      if drv.engine_sharded and getattr(eng, "shard_mode", "") == "regions-exact" and drv.exchanging
@@ -176,7 +181,14 @@ def main():
     rf = out["roofline"]
     step_terms = drv.my_terms()
     all_ms = (kernel_ms + snapshot_ms + drain_ms) / args.steps
-    rf["aux_kernels_ms_per_step"] = {"snapshot_kernel": snapshot_ms / args.steps, "far_drain_kernel": drain_ms / args.steps}
+    beside_on, beside_ms = eng.session.drain_beside() if hasattr(eng.session, "drain_beside") else (False, 0.0)
+    rf["aux_kernels_ms_per_step"] = {"snapshot_kernel": snapshot_ms / args.steps,
+                                     # on the launch stream: far_drain_kernel (+ far_combine_kernel) in front of the next launch — or, for a session that
+                                     # drains BESIDE its launches, only far_combine_kernel; that session's far_drain_kernel runs on a second stream
+                                     "far_drain_kernel" if not beside_on else "far_combine_kernel": drain_ms / args.steps}
+    if beside_on:
+        rf["aux_kernels_ms_per_step"]["far_drain_kernel_beside_the_launches"] = beside_ms / args.steps
+        rf["drain_beside_the_next_launch"] = True
     rf["frac_all_kernels"] = BYTES_PER_TERM * step_terms / (all_ms / 1e3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0
     rf["frac_wall"] = BYTES_PER_TERM * step_terms / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
     first_cooling = p.first_cooling_iteration()
@@ -193,7 +205,8 @@ def main():
     rf["whole_schedule"] = bool(args.warmup + args.steps >= iters and args.warmup <= 2)
     out["config"]["kernel_plan"] = ("per-lane kernel" if not info["tiled"] else
                                     "per-lane kernel until cooling, tile kernel after" if info["warm_per_lane"] else
-                                    "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)")
+                                    "tile kernel (snapshot_kernel -> sgd_tile_kernel -> far_drain_kernel per region colour)"
+                                    + (": the drain on a second stream beside the other colour's launch, far_combine_kernel in front of the same colour's next" if eng.session.drain_beside()[0] else ""))
     if info["tiled"]:
         out["config"]["tile_plan"] = {"region_nodes": info["region_nodes"], "tile_steps": info["tile_steps"], "windows": info["n_work_items"],
                                       "parts_per_window": info["parts"], "work_items_launched": info["n_launch_items"],

@@ -117,6 +117,9 @@ typedef struct pgsgd_graph_view {
                                            /* (more than 2 % of a sample of steps jump over 128 ranks) and would therefore miss the tile kernel is laid out */
                                            /* under ranks ordered by (component, mean path position) when that order at least halves the jumps              */
                                            /* (pgsgd_graph_path_order); the coordinates come back under the caller's ranks.  Not with snapshots (-u)        */
+#define PGSGD_FLAG_SYNC_DRAIN    0x20000u /* tile kernel: deliver every launch's far pulls in front of the very next launch.  By default a session of a  */
+                                         /* schedule as long as the reference's (iter_max >= 30) sums them on a second stream BESIDE the next     */
+                                         /* launch and delivers them a launch later (+3.5 % throughput, same layout).               */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -259,6 +262,11 @@ int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction, double* la
 /* Tile kernel: terms that went for their window ends' locks so far (conflict resolution on shared node coordinates while
  * the learning rate is in the projection regime), and terms among them that found an end taken and did nothing. */
 int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost);
+/* whether the session sums its launches' far pulls on a second stream beside the next launch (PGSGD_FLAG_SYNC_DRAIN: never), and
+ * far_drain_kernel's time there (ms, HIP events) — off the launch stream's critical path */
+int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* drain_ms);
+/* terms the session's tile launches have executed, counted on the device (cumulative; 0 without tiles) */
+int pgsgd_session_terms_executed(pgsgd_session* s, uint64_t* terms);
 /* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
  * direct atomic adds instead (0 in normal operation; the pool is sized from the tile table). */
 int64_t pgsgd_session_outbox_overflow(pgsgd_session* s);

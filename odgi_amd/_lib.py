@@ -83,6 +83,7 @@ FLAG_EXACT_MATH = 0x2000
 FLAG_NO_PARTNER_PAIRS = 0x4000
 FLAG_LOCK_WINDOW_ENDS = 0x8000
 FLAG_NO_RELABEL = 0x10000
+FLAG_SYNC_DRAIN = 0x20000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
@@ -129,6 +130,8 @@ SIGNATURES = [
     ("pgsgd_tile_parts_for", u32, [u64, u64, u64]),
     ("pgsgd_tile_split_items", C.c_int64, [P(u32), P(u32), P(u32), u64, u32, u32, P(u32), P(u32), P(u32), P(u32), u64]),
     ("pgsgd_session_tile_conflicts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
+    ("pgsgd_session_terms_executed", C.c_int, [C.c_void_p, P(u64)]),
+    ("pgsgd_session_drain_beside", C.c_int, [C.c_void_p, P(C.c_int), P(f64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),

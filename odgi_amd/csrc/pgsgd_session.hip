@@ -108,6 +108,28 @@ struct pgsgd_session {
     uint32_t ob_slices = 1;               // workgroups that share a (bucket, part)'s message stream (far_drain_kernel); > 1: d_ob_partial
     uint64_t* d_ob_partial = nullptr;     // [ob_slices][2N] the slices' sums, added to the coordinates by far_combine_kernel
     unsigned long long* d_ob_spill = nullptr;
+    // The drain BESIDE the next launch.  A session of a schedule as long as the reference's default (iter_max >= 30),
+    // unsharded, keeps one outbox per region colour: colour c's launch writes outbox c; right after it far_drain_kernel sums
+    // outbox c into d_pend[c] on the DRAIN stream — beside the next launch, which is the other colour's and writes the other
+    // outbox — and far_combine_kernel adds d_pend[c] to the coordinates right before colour c's NEXT launch.  A launch's far pulls
+    // then arrive one launch later than with the drain in front of the very next launch: measured free on the default schedule,
+    // costly on short ones (profiles/r06/NOTES.md section 3), hence the gate; PGSGD_FLAG_SYNC_DRAIN turns it off.
+    bool async_drain = false;             // the rule says so for this session's schedule (create; set_shard turns it off)
+    pgsgd::Outbox ob1{};                  // colour 1's outbox (colour 0's is `ob`): own pool, fill, next, spill
+    uint64_t* d_pend[2] = {nullptr, nullptr};   // [ob_slices][2N] the sums of colour c's last drain
+    bool pend_waiting[2] = {false, false};      // ... not in the coordinates yet
+    // Before cooling the far pulls are what forms the layout's global structure: those of a WARM launch reach the coordinates right
+    // before the very next launch, whatever its colour — the launch stream waits for their drain, nothing runs beside it.  (All
+    // launches late: the transient at config 4 is 65 instead of 12 after iteration 10 and a graph with window-less tiles, whose
+    // every move is a message, ends at 2.2 instead of 0.2: profiles/r06/pytest_gpu_call9.log.)
+    bool pulls_urgent[2] = {false, false};
+    bool queues_dirty = false;                  // a tile launch has run since the work queues and far-pull counters were last zeroed
+    int pend_order = 0;                         // the colour whose sums have waited longer (a flush delivers it first)
+    hipStream_t drain_stream = nullptr;
+    hipEvent_t ev_launch[2] = {nullptr, nullptr}, ev_drain[2] = {nullptr, nullptr};
+    struct DrainEv { hipEvent_t a, b; };
+    std::vector<DrainEv> free_drain_events, pending_drain_events;   // far_drain_kernel's duration on the drain stream, collected when complete
+    double drain_beside_ms = 0;           // ... summed (HIP events on the drain stream): NOT on the launch stream's critical path
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     std::vector<pgsgd::WorkItem> h_items; // host copy of the work items, colour 0 first (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
@@ -188,6 +210,20 @@ static int collect_events(pgsgd_session* s) {
         s->free_events.push_back(ev);
     }
     s->pending_events.clear();
+    // drains beside a launch run on their own stream and may still be running when the launch stream is idle: take the finished ones
+    size_t kept = 0;
+    for (auto& de : s->pending_drain_events) {
+        if (hipEventQuery(de.b) == hipSuccess) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, de.a, de.b));
+            s->drain_beside_ms += ms;
+            s->free_drain_events.push_back(de);
+        } else {
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+            s->pending_drain_events[kept++] = de;
+        }
+    }
+    s->pending_drain_events.resize(kept);
     return PGSGD_OK;
 }
 
@@ -647,6 +683,7 @@ static double check_pairs_stress(const pgsgd_session* s, const float* X, const f
 
 static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts);
 static int drain_outbox(pgsgd_session* s, unsigned long long* far_next);
+static inline bool pulls_waiting(const pgsgd_session* s) { return s->ob_pending || s->pend_waiting[0] || s->pend_waiting[1]; }
 
 extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_params* p, pgsgd_session** out) {
     pgsgd::clear_error();
@@ -1004,8 +1041,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pgsgd::far_drain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(uint64_t) << 14)));
                 S_TRY(hipMalloc(&s->d_term0, (ht.tiles.size() + 1) * sizeof(uint64_t)));
-                S_TRY(hipMalloc(&s->d_clock, 10 * sizeof(unsigned long long)));  // [6..9]: TileArgs::tail_probe
-                S_TRY(hipMemset(s->d_clock, 0, 10 * sizeof(unsigned long long)));
+                S_TRY(hipMalloc(&s->d_clock, 12 * sizeof(unsigned long long)));  // [6..9]: TileArgs::tail_probe; [10]: TileArgs::term_count
+                S_TRY(hipMemset(s->d_clock, 0, 12 * sizeof(unsigned long long)));
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
@@ -1122,6 +1159,14 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         S_TRY(hipStreamSynchronize(s->stream));
     }
     timer.lap("tables, streams");
+    // The drain beside the next launch (pgsgd_session::async_drain): schedules as long as the reference's default.  Measured with the
+    // evaluator that has no sampling error (profiles/r06/NOTES.md section 3): free at `-x 30`, costly on short schedules.
+    // And graphs whose outbox buckets one drain workgroup holds (up to 2.1e6 nodes): beyond that a bucket is read by 2^(shift - 14)
+    // workgroups of 128 KiB of LDS each, which find no room on a CU beside the tile kernel's five — the drain then waits for the
+    // launch it was meant to run beside and delays the next (measured at 1e7 nodes: 4.92e10 against 5.11e10 terms/s, stress +0.7 %).
+    s->async_drain = s->tiled && p->iter_max >= 30 && !(p->flags & PGSGD_FLAG_SYNC_DRAIN) && s->fmt == pgsgd::kFmtQ32 && s->ob.shift == s->ob_part_shift
+                     && s->n_nonlocal_tiles == 0;   // (a window-less tile's every move is a message: none of them may wait a launch)
+    if (const char* e = pgsgd::debug_env("PGSGD_ASYNC_DRAIN")) s->async_drain = s->tiled && s->fmt == pgsgd::kFmtQ32 && atoi(e) != 0;   // experiment / parity knob
     if (s->tiled && p->min_term_updates) {  // the message pool for iterations of the default length (grown later if a call asks for more)
         rc = ensure_outbox(s, p->min_term_updates, 1);
         if (rc) return fail(rc);
@@ -1161,6 +1206,21 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->ob.pool) (void)hipFree(s->ob.pool);
     if (s->ob.next) (void)hipFree(s->ob.next);
     if (s->ob.fill) (void)hipFree(s->ob.fill);
+    if (s->drain_stream) (void)hipStreamSynchronize(s->drain_stream);
+    if (s->ob1.pool) (void)hipFree(s->ob1.pool);
+    if (s->ob1.fill) (void)hipFree(s->ob1.fill);
+    if (s->drain_stream) {   // (ob1.next / ob1.spill are the session's own only when the second outbox was built)
+        if (s->ob1.next) (void)hipFree(s->ob1.next);
+        if (s->ob1.spill) (void)hipFree(s->ob1.spill);
+    }
+    for (int c = 0; c < 2; ++c) {
+        if (s->d_pend[c]) (void)hipFree(s->d_pend[c]);
+        if (s->ev_launch[c]) (void)hipEventDestroy(s->ev_launch[c]);
+        if (s->ev_drain[c]) (void)hipEventDestroy(s->ev_drain[c]);
+    }
+    for (auto& de : s->free_drain_events) { (void)hipEventDestroy(de.a); (void)hipEventDestroy(de.b); }
+    for (auto& de : s->pending_drain_events) { (void)hipEventDestroy(de.a); (void)hipEventDestroy(de.b); }
+    if (s->drain_stream) (void)hipStreamDestroy(s->drain_stream);
     if (s->d_ob_chunk0) (void)hipFree(s->d_ob_chunk0);
     if (s->d_ob_cap) (void)hipFree(s->d_ob_cap);
     if (s->d_ob_overflow) (void)hipFree(s->d_ob_overflow);
@@ -1200,7 +1260,7 @@ extern "C" int pgsgd_session_upload_coords(pgsgd_session* s, const float* X, con
     pgsgd::clear_error();
     if (!s || !X || !Y) return PGSGD_E_INVALID;
     HIP_TRY(hipSetDevice(s->device));
-    if (s->ob_pending) {  // far pulls of an earlier layout must not reach the new one (their drain also resets the counters)
+    if (pulls_waiting(s)) {  // far pulls of an earlier layout must not reach the new one (their drain also resets the counters)
         const int rc = pgsgd_session_flush(s);
         if (rc) return rc;
     }
@@ -1438,6 +1498,10 @@ extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t
     // WINDOWS (n_items: the session's unsplit work items per colour), not the parts a one-GPU session cuts them into.
     if (by_region < 0) by_region = !(s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000) ? 0 : s->fmt == pgsgd::kFmtQ32 ? 2 : 1;
     if (by_region == 2 && (!s->tiled || s->fmt != pgsgd::kFmtQ32)) { set_error("the exact exchange needs a tiled session with fixed-point coordinates"); return PGSGD_E_UNSUPPORTED; }
+    if (world > 1 || by_region == 2) {  // a sharded session exchanges after every launch: its far pulls are delivered in front of the next one
+        if (pulls_waiting(s)) { const int rc = pgsgd_session_flush(s); if (rc) return rc; }
+        s->async_drain = false;
+    }
     s->shard_rank = by_region ? rank : 0;
     s->shard_world = by_region ? world : 1;
     s->tshard_rank = by_region ? 0 : rank;
@@ -1531,13 +1595,16 @@ extern "C" int pgsgd_session_split_info(const pgsgd_session* s, uint32_t* apply_
 static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     const uint64_t per_call = n_terms / std::max<uint32_t>(1, n_parts * s->tile_substeps * s->tshard_world * s->shard_world) + 1;
     if (s->ob.pool && per_call <= s->ob_budget_terms) return PGSGD_OK;
-    if (s->ob_pending) {  // the pool is about to be replaced: deliver what the last launch left in it first
+    if (pulls_waiting(s)) {  // the pool is about to be replaced: deliver what the last launch left in it first
         const int rc = pgsgd_session_flush(s);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->drain_stream) HIP_TRY(hipStreamSynchronize(s->drain_stream));
     if (s->ob.pool) { (void)hipFree(s->ob.pool); s->ob.pool = nullptr; }
     if (s->ob.fill) { (void)hipFree(s->ob.fill); s->ob.fill = nullptr; }
+    if (s->ob1.pool) { (void)hipFree(s->ob1.pool); s->ob1.pool = nullptr; }
+    if (s->ob1.fill) { (void)hipFree(s->ob1.fill); s->ob1.fill = nullptr; }
     const uint32_t B = s->ob.n_buckets;
     double frac = 1.3 * s->ob_msgs_per_term;  // every partner far, and slack for buckets that draw more than their share
     uint64_t open_chunks = (uint64_t)pgsgd::kObGroup * (s->tile_grid + 4);  // every resident workgroup may hold one partly filled group of chunks per bucket
@@ -1566,6 +1633,32 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     }
     HIP_TRY(hipMalloc(&s->ob.fill, total * sizeof(uint32_t)));
     HIP_TRY(hipMemset(s->ob.fill, 0, total * sizeof(uint32_t)));
+    if (s->async_drain) {  // one pool per region colour: colour c's launch fills its pool while the other colour's is drained
+        e = hipMalloc(&s->ob1.pool, total * pgsgd::kObChunk * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            set_error("second outbox pool of %.1f GB: %s", (double)total * pgsgd::kObChunk * 8 / 1e9, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP;
+        }
+        HIP_TRY(hipMalloc(&s->ob1.fill, total * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->ob1.fill, 0, total * sizeof(uint32_t)));
+    }
+    if (s->async_drain && !s->drain_stream) {
+        const size_t n_ends = 2 * (size_t)s->n_nodes;
+        HIP_TRY(hipMalloc(&s->ob1.spill, n_ends * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(s->ob1.spill, 0, n_ends * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&s->ob1.next, B * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->ob1.next, 0, B * sizeof(uint32_t)));
+        for (int c = 0; c < 2; ++c) {
+            HIP_TRY(hipMalloc(&s->d_pend[c], (size_t)s->ob_slices * n_ends * sizeof(uint64_t)));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_launch[c], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_drain[c], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&s->drain_stream, hipStreamNonBlocking));
+    }
+    if (s->ob_slices > 1 && !s->d_ob_partial) {  // (with the pool, where a failure is the create path's to report — not on the iteration path)
+        hipError_t e2 = hipMalloc(&s->d_ob_partial, (size_t)s->ob_slices * 2 * s->n_nodes * sizeof(uint64_t));
+        if (e2 != hipSuccess) { set_error("drain slices' sums (%u x %.1f MB): %s", s->ob_slices, 16.0 * s->n_nodes / 1e6, hipGetErrorString(e2)); return e2 == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
+    }
     if (!s->d_ob_chunk0) {
         HIP_TRY(hipMalloc(&s->d_ob_overflow, sizeof(unsigned long long)));
         HIP_TRY(hipMemset(s->d_ob_overflow, 0, sizeof(unsigned long long)));
@@ -1582,6 +1675,11 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
     HIP_TRY(hipMemcpy(s->d_ob_cap, cap.data(), B * sizeof(uint32_t), hipMemcpyHostToDevice));
     s->ob.chunk0 = s->d_ob_chunk0;
     s->ob.cap = s->d_ob_cap;
+    if (s->async_drain) {  // colour 1's outbox: the shared description with its own pool, chunk counters and spill words
+        pgsgd::Outbox o = s->ob;
+        o.pool = s->ob1.pool; o.fill = s->ob1.fill; o.next = s->ob1.next; o.spill = s->ob1.spill;
+        s->ob1 = o;
+    }
     s->ob_budget_terms = per_call;
     s->ob_total_chunks = total;
     if (s->params.progress)
@@ -1594,25 +1692,82 @@ static int ensure_outbox(pgsgd_session* s, uint64_t n_terms, uint32_t n_parts) {
 // node ends; then the chunk counters, the work queues and `far_next` — the far-pull counter the next launch writes —
 // start from zero.
 static int drain_outbox(pgsgd_session* s, unsigned long long* far_next) {
-    if (!s->ob_pending) return PGSGD_OK;
+    if (!s->ob_pending) {
+        if (s->queues_dirty && far_next) {  // (the launches since the last reset drained beside each other: pgsgd_session_flush delivered them, the counters are as they left them)
+            hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3(1), dim3(256), 0, s->stream, s->ob.next, 0u, s->d_queue, far_next);
+            s->n_kernels++;
+            HIP_TRY(hipGetLastError());
+            s->queues_dirty = false;
+        }
+        return PGSGD_OK;
+    }
     // (a bucket's parts run on one XCD: the grid is the buckets rounded up to a multiple of the 8 XCDs, times the parts)
     const uint64_t n_ends = 2 * s->n_nodes;
-    if (s->ob_slices > 1 && !s->d_ob_partial) HIP_TRY(hipMalloc(&s->d_ob_partial, (size_t)s->ob_slices * n_ends * sizeof(uint64_t)));
     hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(((((s->ob.n_buckets + pgsgd::kItemQueues - 1) / pgsgd::kItemQueues) * pgsgd::kItemQueues) << (s->ob.shift - s->ob_part_shift)) * s->ob_slices), dim3(1024),
-                       sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, n_ends, s->ob_part_shift, s->dc.frame_flag, s->ob_slices, s->d_ob_partial);
+                       sizeof(uint64_t) << s->ob_part_shift, s->stream, s->ob, s->d_coords, n_ends, s->ob_part_shift, s->dc.frame_flag, s->ob_slices, s->ob_slices > 1 ? s->d_ob_partial : nullptr);
     s->n_kernels++;
     HIP_TRY(hipGetLastError());
-    if (s->ob_slices > 1) {
+    if (s->ob_slices > 1) {   // the slices' sums reach the coordinates; the same kernel zeroes the chunk counters, the work queues and far_next
         hipLaunchKernelGGL(pgsgd::far_combine_kernel, dim3((unsigned)std::min<uint64_t>((n_ends + 255) / 256, 2048)), dim3(256), 0, s->stream, s->d_coords, s->d_ob_partial, n_ends,
-                           s->ob_slices, s->dc.frame_flag);
-        s->n_kernels++;
-        HIP_TRY(hipGetLastError());
+                           s->ob_slices, s->dc.frame_flag, s->ob.next, s->ob.n_buckets, s->d_queue, s->d_queue + pgsgd::kItemQueues, s->d_queue + 2 * pgsgd::kItemQueues, far_next);
+    } else {
+        hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
+                           s->d_queue, far_next);
     }
-    hipLaunchKernelGGL(pgsgd::outbox_reset_kernel, dim3((s->ob.n_buckets + 255) / 256), dim3(256), 0, s->stream, s->ob.next, s->ob.n_buckets,
-                       s->d_queue, far_next);
     s->n_kernels++;
     HIP_TRY(hipGetLastError());
     s->ob_pending = false;
+    s->queues_dirty = false;
+    return PGSGD_OK;
+}
+
+// ---- the drain beside the next launch (pgsgd_session::async_drain) ----
+// Right after colour c's tile launch (already enqueued on the launch stream): far_drain_kernel sums the launch's messages into
+// d_pend[c] on the DRAIN stream, beside whatever the launch stream does next — the other colour's launch, which writes the other
+// outbox and the coordinates; the drain touches neither.
+static int enqueue_drain(pgsgd_session* s, int colour) {
+    HIP_TRY(hipEventRecord(s->ev_launch[colour], s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->drain_stream, s->ev_launch[colour], 0));
+    pgsgd_session::DrainEv de;
+    if (!s->free_drain_events.empty()) {
+        de = s->free_drain_events.back();
+        s->free_drain_events.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&de.a));
+        HIP_TRY(hipEventCreate(&de.b));
+    }
+    const pgsgd::Outbox& ob = colour ? s->ob1 : s->ob;
+    const uint64_t n_ends = 2 * s->n_nodes;
+    HIP_TRY(hipEventRecord(de.a, s->drain_stream));
+    hipLaunchKernelGGL(pgsgd::far_drain_kernel, dim3(((((ob.n_buckets + pgsgd::kItemQueues - 1) / pgsgd::kItemQueues) * pgsgd::kItemQueues) << (ob.shift - s->ob_part_shift)) * s->ob_slices), dim3(1024),
+                       sizeof(uint64_t) << s->ob_part_shift, s->drain_stream, ob, s->d_coords, n_ends, s->ob_part_shift, s->dc.frame_flag, s->ob_slices, s->d_pend[colour]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(de.b, s->drain_stream));
+    HIP_TRY(hipEventRecord(s->ev_drain[colour], s->drain_stream));
+    s->pending_drain_events.push_back(de);
+    s->n_kernels++;
+    if (!s->pend_waiting[1 - colour]) s->pend_order = colour;
+    s->pend_waiting[colour] = true;
+    return PGSGD_OK;
+}
+
+// The far pulls colour c's last launch collected reach the coordinates (launch stream; waits for their drain): right before colour
+// c's next launch — with for_launch the same kernel zeroes that launch's work queues and the far-pull counter it writes — and for
+// whoever needs the coordinates complete (pgsgd_session_flush).
+static int deliver_pulls(pgsgd_session* s, int colour, bool for_launch, unsigned long long* far_next) {
+    const bool waiting = s->pend_waiting[colour];
+    if (!waiting && !for_launch) return PGSGD_OK;
+    if (waiting) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_drain[colour], 0));
+    const uint64_t n_ends = 2 * s->n_nodes;
+    const pgsgd::Outbox& ob = colour ? s->ob1 : s->ob;
+    hipLaunchKernelGGL(pgsgd::far_combine_kernel, dim3(waiting ? (unsigned)std::min<uint64_t>((n_ends + 255) / 256, 2048) : 1u), dim3(256), 0, s->stream, s->d_coords,
+                       waiting ? s->d_pend[colour] : nullptr, n_ends, s->ob_slices, s->dc.frame_flag, waiting ? ob.next : nullptr, ob.n_buckets,
+                       for_launch ? s->d_queue + colour * pgsgd::kItemQueues : nullptr, for_launch && colour == 0 ? s->d_queue + 2 * pgsgd::kItemQueues : nullptr, nullptr,
+                       for_launch ? far_next : nullptr);
+    HIP_TRY(hipGetLastError());
+    s->n_kernels++;
+    s->pend_waiting[colour] = false;
+    if (for_launch) s->queues_dirty = false;
     return PGSGD_OK;
 }
 
@@ -1623,6 +1778,19 @@ static int flush_for(pgsgd_session* s, int next_colour);
 extern "C" int pgsgd_session_flush(pgsgd_session* s) {
     pgsgd::clear_error();
     if (!s) return PGSGD_E_INVALID;
+    if (s->pend_waiting[0] || s->pend_waiting[1]) {  // a session whose drains run beside its launches: the sums of its last two launches wait
+        HIP_TRY(hipSetDevice(s->device));
+        pgsgd_session::EvSet ev;
+        int rc = take_events(s, &ev);
+        if (rc) return rc;
+        ev.n = 1;
+        HIP_TRY(hipEventRecord(ev.e[2], s->stream));
+        rc = deliver_pulls(s, s->pend_order, false, nullptr);
+        if (rc == PGSGD_OK) rc = deliver_pulls(s, 1 - s->pend_order, false, nullptr);
+        HIP_TRY(hipEventRecord(ev.e[3], s->stream));
+        s->pending_events.push_back(ev);
+        if (rc) return rc;
+    }
     // (the counter zeroed is the one the next launch — colour 0 unless it has no items — will write)
     return flush_for(s, s->n_items[0] ? 0 : 1);
 }
@@ -1655,7 +1823,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
     // (experiment knob PGSGD_TILE_UNTIL=k: the iterations from the k-th on, 0-based, run the per-lane kernel — does the 1e7-node
     // gap come from the late, refining iterations?  profiles/r05/NOTES.md section 7)
     const bool use_tiles = s->tiled && !(s->warm_per_lane && !cooling) && !(s->tile_until && s->relax_iter >= s->tile_until);
-    if (!use_tiles && s->ob_pending) {  // (the last tile launch's far pulls must not wait behind per-lane iterations)
+    if (!use_tiles && pulls_waiting(s)) {  // (the last tile launch's far pulls must not wait behind per-lane iterations)
         const int rc = pgsgd_session_flush(s);
         if (rc) return rc;
     }
@@ -1694,6 +1862,8 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
         const uint32_t tile_parts = exact ? 1u : n_parts;   // the parts the TILES are dealt out to
         int rc = ensure_outbox(s, n_terms, tile_parts);
         if (rc) return rc;
+        // the drain beside the next launch: whole iterations of an unsharded session only (pgsgd_session::async_drain)
+        const bool async = s->async_drain && s->drain_stream && !exact && n_parts == 1 && s->tile_substeps == 1 && s->shard_world == 1 && s->tshard_world == 1;
         if (s->term0_terms != n_terms) {  // every tile's exact share of this call's terms
             const uint64_t nt = s->n_tiles + 1;
             hipLaunchKernelGGL(pgsgd::tile_terms_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s->stream, s->d_tiles, s->n_tiles,
@@ -1763,13 +1933,14 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.lock_mu = s->tile_lock_mu;
             ta.pair_uniform = s->tile_pair_uniform;
             ta.clock_probe = s->d_clock;
+            ta.term_count = s->d_clock ? s->d_clock + 10 : nullptr;
             ta.tail_probe = nullptr;
             if (s->tile_tail && s->d_clock) {  // (debug only: two more memsets per launch)
                 ta.tail_probe = s->d_clock + 6;
                 HIP_TRY(hipMemsetAsync(s->d_clock + 6, 0, 4 * sizeof(unsigned long long), s->stream));
                 HIP_TRY(hipMemsetAsync(s->d_clock + 8, 0xff, sizeof(unsigned long long), s->stream));
             }
-            ta.ob = s->ob;
+            ta.ob = async && colour ? s->ob1 : s->ob;
             pgsgd::TileSampler ts;
             ts.zipf_tab = s->d_zipf_tab;
             ts.space = (uint32_t)std::min<uint64_t>(s->params.space, 0xffffffffull);
@@ -1785,7 +1956,17 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             // pulls (each an average of a dozen long-range pulls — noise at the scale of neighbouring nodes until the
             // next launch's local terms have worked on it; tools/cpu_transient.py).
             HIP_TRY(hipEventRecord(ev.e[2], s->stream));
-            rc = drain_outbox(s, s->d_far + 2 * colour + (launches & 1u));
+            if (async) {
+                // (a session whose drains run beside its launches: what THIS colour's last launch collected arrives now — its drain
+                // ran beside the other colour's launch — and the launch's queues and far-pull counter start from zero; what the
+                // launch before this one collected arrives now too if that was a warm launch)
+                if (s->ob_pending) { rc = drain_outbox(s, nullptr); if (rc) return rc; }   // (a launch from before the mode was on)
+                if (s->pend_waiting[1 - colour] && s->pulls_urgent[1 - colour]) { rc = deliver_pulls(s, 1 - colour, false, nullptr); if (rc) return rc; }
+                rc = deliver_pulls(s, colour, true, s->d_far + 2 * colour + (launches & 1u));
+            } else {
+                if (s->pend_waiting[0] || s->pend_waiting[1]) { rc = pgsgd_session_flush(s); if (rc) return rc; }   // (the mode was turned off: set_shard)
+                rc = drain_outbox(s, s->d_far + 2 * colour + (launches & 1u));
+            }
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.e[3], s->stream));
             // Partners outside a window are read from the snapshot pieces of the gather records.  A tile rewrites the pieces
@@ -1827,7 +2008,14 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipEventRecord(ev.e[1], s->stream));
-            s->ob_pending = true;
+            if (async) {
+                rc = enqueue_drain(s, colour);   // (drain stream: beside whatever this stream does next)
+                if (rc) return rc;
+                s->pulls_urgent[colour] = !a.cooling;
+            } else {
+                s->ob_pending = true;
+            }
+            s->queues_dirty = true;
             s->last_colour = colour;
             s->snap_stale = sharded;
             s->pending_events.push_back(ev);
@@ -1898,7 +2086,7 @@ extern "C" int pgsgd_session_reframe(pgsgd_session* s) {
     if (!s) return PGSGD_E_INVALID;
     if (s->fmt != pgsgd::kFmtQ32) return PGSGD_OK;
     HIP_TRY(hipSetDevice(s->device));
-    if (s->ob_pending) {  // messages in the outbox are steps in quanta of the frame they were computed in
+    if (pulls_waiting(s)) {  // messages in the outbox are steps in quanta of the frame they were computed in
         const int rc = pgsgd_session_flush(s);
         if (rc) return rc;
     }
@@ -1957,7 +2145,7 @@ extern "C" int pgsgd_session_kernel_time(pgsgd_session* s, double* total_ms, uin
     if (!s) return PGSGD_E_INVALID;
     if (total_ms) *total_ms = s->kernel_ms;
     if (launches) *launches = s->launches;
-    if (reset) { s->kernel_ms = 0; s->launches = 0; s->aux_ms[0] = s->aux_ms[1] = 0; }
+    if (reset) { s->kernel_ms = 0; s->launches = 0; s->aux_ms[0] = s->aux_ms[1] = 0; s->drain_beside_ms = 0; }
     return PGSGD_OK;
 }
 
@@ -2008,6 +2196,22 @@ extern "C" int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, 
     return PGSGD_OK;
 }
 
+// Terms the session's tile launches have EXECUTED, counted on the device (every wave adds the population count of the lanes
+// that finished a term, trip by trip) — the host's accounting (`terms += min_term_updates`, path_sgd_layout.cpp:133-137,370)
+// says what was asked for; this says what ran.  Cumulative since the session was created; 0 for a session without tiles.
+extern "C" int pgsgd_session_terms_executed(pgsgd_session* s, uint64_t* terms) {
+    pgsgd::clear_error();
+    if (!s || !terms) return PGSGD_E_INVALID;
+    *terms = 0;
+    if (!s->d_clock) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, s->d_clock + 10, sizeof v, hipMemcpyDeviceToHost));
+    *terms = v;
+    return PGSGD_OK;
+}
+
 // Debug knob PGSGD_TILE_TAIL: of the last windowed tile launch, the share of (workgroups x launch duration) that the
 // workgroups were alive for — a persistent workgroup lives until the launch has no work item left for it, so what is
 // missing is the launch's tail: slots idle while the last items finish.  0 when the knob is off.
@@ -2042,6 +2246,19 @@ extern "C" int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, dou
     if (!s) return PGSGD_E_INVALID;
     if (snapshot_ms) *snapshot_ms = s->aux_ms[0];
     if (drain_ms) *drain_ms = s->aux_ms[1];
+    return PGSGD_OK;
+}
+
+// A session whose drains run beside its launches (pgsgd_session::async_drain): *on = whether this one does, *drain_ms = far_drain_kernel's
+// time on the DRAIN stream (HIP events; finished drains only — synchronise first for all of them): NOT on the launch stream's critical
+// path.  What the launch stream pays for the far pulls (far_combine_kernel in front of a launch) is the drain_ms of pgsgd_session_aux_time.
+extern "C" int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* drain_ms) {
+    if (!s) return PGSGD_E_INVALID;
+    if (on) *on = s->async_drain && s->drain_stream ? 1 : 0;
+    if (drain_ms) {
+        if (s->drain_stream) { HIP_TRY(hipStreamSynchronize(s->drain_stream)); (void)collect_events(s); }
+        *drain_ms = s->drain_beside_ms;
+    }
     return PGSGD_OK;
 }
 

@@ -174,6 +174,7 @@ struct TileArgs {
     uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
     uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
+    unsigned long long* term_count;    // terms this session's tile launches have executed (cumulative; every wave adds what its lanes finished): pgsgd_session_terms_executed
     uint32_t tile_rotate;              // debug knob PGSGD_TILE_ROTATE: an item's tiles start at another one every iteration (which path has the last word on a window)
     Outbox ob;
 };
@@ -674,10 +675,12 @@ struct PendingTerm {
 // The hand-off of a window between consecutive parts (kItemHasNext) has no release/acquire fence: the words go out with
 // agent-scope atomic stores, `s_waitcnt vmcnt(0)` waits for their acknowledgement (on gfx9 the one counter covers stores — gfx10+
 // count them in vscnt), a relaxed flag follows, and the next part stages the window with agent-scope loads.  That is the memory
-// model of gfx942 / gfx950 (write-through L2 at agent scope, store acknowledged when visible to the agent) and of no other
+// model of gfx950 (and gfx942: write-through L2 at agent scope, store acknowledged when visible to the agent) and of no other
 // target: this file is built for those only, and the windowed instance must read coordinates with the agent-scope flavour.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "pgsgd_tiles.hpp: the fence-free window hand-off (kItemHasNext) is written for gfx950 / gfx942 only"
+// This file is built for gfx950 ONLY: besides the hand-off, far_drain_kernel accumulates a bucket in 128 KiB of a workgroup's LDS
+// (160 KB per CU on gfx950; gfx942 has 64 KB) and the tile kernel's LDS budget assumes five workgroups in those 160 KB.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pgsgd_tiles.hpp is written for gfx950 (MI355X): the fence-free window hand-off and the 128-KiB drain accumulators do not carry over"
 #endif
 template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
@@ -716,6 +719,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     }
     float dmax = 0.0f;
     uint32_t n_far = 0;
+    uint32_t n_done = 0;   // terms this wave's lanes have finished (wave-uniform: a ballot's population count per trip, scalar arithmetic)
     bool guard = false;  // a coordinate in the outer quarter of the fixed-point frame was seen (in_frame_guard)
     const uint64_t n_ends = 2 * (uint64_t)c.n_nodes;
     const uint32_t win_words = 4 * ta.region;
@@ -884,6 +888,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 bool msg_a = false, msg_b = false;
                 uint32_t end_a = 0, end_b = 0;
                 int32_t mqx = 0, mqy = 0;
+                n_done += (uint32_t)__popcll(__ballot(Qr.ka != kNoTerm));
                 if (Qr.ka != kNoTerm) {
                     const uint32_t flip_a = (Qr.flags >> 29) & 1u, flip_b = (Qr.flags >> 28) & 1u;  // the two end choices (:253,262)
                     const bool from_global = !(Qr.kb_off < t.n);
@@ -1077,6 +1082,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     }
     for (int off = 32; off > 0; off >>= 1) n_far += __shfl_xor(n_far, off);
     if ((threadIdx.x & 63) == 0 && n_far) atomicAdd(TILE_COLD(ta.far_count), (unsigned long long)n_far);
+    if ((threadIdx.x & 63) == 0 && n_done && TILE_COLD(ta.term_count)) atomicAdd(TILE_COLD(ta.term_count), (unsigned long long)n_done);
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(TILE_COLD(c.delta_max_bits), __float_as_uint(dmax));
     if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(TILE_COLD(c.frame_flag), 1u);
@@ -1108,7 +1114,9 @@ __global__ __launch_bounds__(256) void snapshot_kernel(const uint32_t* step_hand
 // everything: its instruction issue and LDS adds, not the memory, were what the drain waited for (profiles/r05/NOTES.md).
 // With one slice the workgroup moves the node ends itself (nothing else writes coordinates while the drain runs: a plain
 // read-modify-write); with several, each writes its sums to partial[slice][2N] — every word, zero where nothing arrived — and
-// far_combine_kernel adds them to the coordinates: exact 64-bit integer adds, the sum direct atomics would give.
+// far_combine_kernel adds them to the coordinates: exact 64-bit integer adds, the sum direct atomics would give.  `partial`
+// non-null with ONE slice: the drain runs on its own stream BESIDE the other colour's tile launch (which is writing coordinates:
+// the drain must not) and its sums wait in partial until the same colour's next launch (pgsgd_session.hip: enqueue_drain).
 __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* coords, uint64_t n_ends, uint32_t part_shift, unsigned int* frame_flag,
                                                          uint32_t slices, uint64_t* partial) {
     extern __shared__ uint64_t acc[];
@@ -1180,7 +1188,7 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
             sp = ob.spill[base + i];
             if (sp) ob.spill[base + i] = 0;
         }
-        if (slices > 1) {
+        if (partial) {
             partial[(uint64_t)slice * n_ends + base + i] = acc[i] + sp;
         } else if (acc[i] + sp != 0) {
             const uint64_t w = coords[base + i] + acc[i] + sp;
@@ -1191,8 +1199,23 @@ __global__ __launch_bounds__(1024) void far_drain_kernel(Outbox ob, uint64_t* co
     if (__ballot(guard) && (threadIdx.x & 63) == 0) atomicOr(frame_flag, 1u);
 }
 
-// coords += the slices' partial sums (far_drain_kernel with several slices)
-__global__ __launch_bounds__(256) void far_combine_kernel(uint64_t* coords, const uint64_t* partial, uint64_t n_ends, uint32_t slices, unsigned int* frame_flag) {
+// coords += the slices' partial sums (far_drain_kernel with several slices, or beside a launch); `partial` null: nothing to add.
+// Also what a tile launch needs zeroed right before it (a session whose drains run beside the launches has no drain in front of
+// the launch to do it): the chunk counters of the outbox whose sums these are, the work-item counters of the runs q_a, q_b, q_c
+// and the far-pull counter the launch writes (any of them null: left alone).
+__global__ __launch_bounds__(256) void far_combine_kernel(uint64_t* coords, const uint64_t* partial, uint64_t n_ends, uint32_t slices, unsigned int* frame_flag,
+                                                          uint32_t* next, uint32_t n_buckets, uint32_t* q_a, uint32_t* q_b, uint32_t* q_c, unsigned long long* far_next) {
+    if (blockIdx.x == 0) {   // (the drain whose sums these are is done with the chunk counters)
+        if (next)
+            for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) next[b] = 0;
+        if (threadIdx.x < kItemQueues) {
+            if (q_a) q_a[threadIdx.x] = 0;
+            if (q_b) q_b[threadIdx.x] = 0;
+            if (q_c) q_c[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 0 && far_next) *far_next = 0;
+    }
+    if (!partial) return;
     bool guard = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ends; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t d = 0;
@@ -1207,11 +1230,13 @@ __global__ __launch_bounds__(256) void far_combine_kernel(uint64_t* coords, cons
 }
 
 // the drain is done with the chunk counters; the next launch's work queues and far-pull counter start from zero
+// (queues / far_next null: a drain beside a launch resets its own outbox's chunk counters only — far_combine_kernel does the rest
+// right before the launch)
 __global__ void outbox_reset_kernel(uint32_t* next, uint32_t n_buckets, uint32_t* queues, unsigned long long* far_next) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_buckets) next[b] = 0;
-    if (b < 3 * kItemQueues) queues[b] = 0;
-    if (b == 0) *far_next = 0;
+    if (queues && b < 3 * kItemQueues) queues[b] = 0;
+    if (b == 0 && far_next) *far_next = 0;
 }
 
 // sampler-only replay of one tile's terms (parity hook): out[(q - first_term)*4 + {0..3}] = {ka, kb, off_a, off_b};

@@ -305,6 +305,19 @@ class LayoutSession:
         check(lib.pgsgd_session_tile_conflicts(self._h, C.byref(a), C.byref(b)), "tile_conflicts")
         return a.value, b.value
 
+    def drain_beside(self):
+        """(on, ms): whether the session sums its launches' far pulls on a second stream beside the next launch (schedules of
+        30 iterations and more, unsharded; PGSGD_FLAG_SYNC_DRAIN: never), and far_drain_kernel's time on that stream so far."""
+        on, ms = C.c_int(), C.c_double()
+        check(lib.pgsgd_session_drain_beside(self._h, C.byref(on), C.byref(ms)), "drain_beside")
+        return bool(on.value), ms.value
+
+    def terms_executed(self):
+        """Terms the session's tile launches have executed so far, counted on the device (0 for a session without tiles)."""
+        n = C.c_uint64()
+        check(lib.pgsgd_session_terms_executed(self._h, C.byref(n)), "terms_executed")
+        return int(n.value)
+
     def launch_counts(self):
         """(kernel launches, memsets + copies) the session's iterations have put on the stream."""
         k, c = C.c_uint64(), C.c_uint64()

@@ -205,6 +205,7 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
 
 
 TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN, TILE_NO_PAIRS, TILE_RELAX_R5 = 1, 2, 4, 8, 16, 32, 64, 128
+TILE_DRAIN_BESIDE = 0x8000   # per-colour outboxes, pulls delivered before the same colour's next launch (sessions of >= 30 iterations)
 TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN | TILE_NO_PAIRS   # the launch order, far-pull policy and per-lane coin of round 2
 TILE_ROUND3 = TILE_LANE_COIN | TILE_NO_PAIRS | TILE_RELAX_R5   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane, far pulls ramping to half a projection
 TILE_ROUND5 = TILE_RELAX_R5   # rounds 4-5: wave coin, partner pairs; far pulls ramping 0.1 .. 0.5 (round 6: 0.2 .. 1.0)

@@ -1316,6 +1316,10 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
  *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
  *   ORC_TILE_NO_PAIRS       every lane keeps its own uniform partner (rounds 2 and 3; PGSGD_FLAG_NO_PARTNER_PAIRS)
+ *   ORC_TILE_DRAIN_BESIDE   every region colour has its own outbox and a launch's far pulls are delivered right before the SAME colour's
+ *                           next launch — a launch later than by default — when theirs was a COOLING launch (a warm launch's arrive before
+ *                           the very next launch, as by default): what a session does whose drain runs on a second stream beside the
+ *                           other colour's launch (pgsgd_session::async_drain: schedules of 30 iterations and more)
  *   ORC_TILE_RELAX_R5       the far pulls' relaxation of rounds 3-5: 0.1 0.1 0.2 0.3 0.4 then half a projection (round 6: 0.2 ... 0.8 then one)
  * stop_after: run only the first stop_after iterations of the schedule (0 = all). */
 void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t seed_base,
@@ -1343,7 +1347,9 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                          double* last_delta_max, uint64_t* checksum, uint64_t* far_terms, uint32_t policy, uint64_t stop_after) {
     (void)n_tiles;
     const int drain_first = !(policy & ORC_TILE_DRAIN_AFTER), one_snapshot = !(policy & ORC_TILE_TWO_SNAPSHOTS);
-    int pending = 0;   /* a launch's far pulls wait in the outbox */
+    const int beside = (policy & ORC_TILE_DRAIN_BESIDE) != 0;
+    int pending[2] = {0, 0};   /* a launch's far pulls wait in the outbox (ORC_TILE_DRAIN_BESIDE: in its colour's) */
+    int urgent[2] = {0, 0};    /* ORC_TILE_DRAIN_BESIDE: ... and arrive before the very next launch when theirs was a warm one */
     if (last_delta_max) *last_delta_max = 0.0;
     const uint64_t n_ends = 2 * g->n_nodes;
     const float scale = (float)quanta_per_bp, inv_scale = (float)(1.0 / quanta_per_bp);
@@ -1365,7 +1371,7 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
     /* what a launch sees of node ends outside a window: their words when the iteration began (snapshot_kernel); what it
      * adds to them: collected (the outbox) and applied when the launch is over (far_drain_kernel) */
     uint64_t* snap = (uint64_t*)malloc(n_ends * sizeof(uint64_t));
-    uint64_t* outbox = (uint64_t*)calloc(n_ends, sizeof(uint64_t));
+    uint64_t* outboxes = (uint64_t*)calloc(2 * n_ends, sizeof(uint64_t));   /* (one per region colour; only ORC_TILE_DRAIN_BESIDE uses the second) */
     /* the snapshot words a partner outside the window is read from: a tile rewrites those of its OWN steps when its terms are
      * done (from the window), so a partner is seen as its tile last left it, this iteration or the one before; the words of
      * all steps are taken from the coordinates only when the run starts.  ORC_TILE_SNAPSHOT_PASS: a pass over all node
@@ -1394,7 +1400,14 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
             const uint64_t ib = colour ? n_first : 0, ie = colour ? n_items : n_first;
             if (ib == ie) continue;
             /* snapshot before every launch of a warm iteration, before the first launch of a cooling one */
-            if (pending) { for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; } pending = 0; }
+            /* what waits arrives now: the last launch's pulls, whatever its colour — or (ORC_TILE_DRAIN_BESIDE) this colour's last launch's */
+            for (int c = 0; c < 2; ++c)
+                if (pending[c] && (!beside || c == colour || urgent[c])) {
+                    uint64_t* ob = outboxes + (size_t)c * n_ends;
+                    for (uint64_t i = 0; i < n_ends; ++i) { W[i] += ob[i]; ob[i] = 0; }
+                    pending[c] = 0;
+                }
+            uint64_t* outbox = outboxes + (beside ? (size_t)colour * n_ends : 0);
             if (!snap_taken || (!cooling && !one_snapshot)) { memcpy(snap, W, n_ends * sizeof(uint64_t)); snap_taken = 1; }
             for (uint64_t it = ib; it < ie; ++it) {
                 const uint64_t wbase = 2 * (uint64_t)win0[it];
@@ -1465,7 +1478,8 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                     for (uint32_t i = 0; i < win_words; ++i)
                         if (wbase + i < n_ends) W[wbase + i] = win[i];
             }
-            if (drain_first) pending = 1;
+            urgent[colour] = !cooling;
+            if (drain_first) pending[beside ? colour : 0] = 1;
             else for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
         }
         for (int colour = 0; colour < 2; ++colour) {
@@ -1477,8 +1491,12 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
         if (iter + 1 < p->iter_max && (double)dmax <= p->delta) break;
         if (stop_after && iter + 1 >= stop_after) break;
     }
-    if (pending && !(policy & ORC_TILE_NO_FLUSH))
-        for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
+    if (!(policy & ORC_TILE_NO_FLUSH))
+        for (int c = 0; c < 2; ++c)
+            if (pending[c]) {
+                uint64_t* ob = outboxes + (size_t)c * n_ends;
+                for (uint64_t i = 0; i < n_ends; ++i) { W[i] += ob[i]; ob[i] = 0; }
+            }
     if (far_terms) *far_terms = far_total;
     if (checksum) {
         checksum[2] = checksum[3] = 0;
@@ -1488,5 +1506,5 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
         X[i] = (float)(x_off + (double)(uint32_t)W[i] * (double)inv_scale);
         Y[i] = (float)(y_off + (double)(uint32_t)(W[i] >> 32) * (double)inv_scale);
     }
-    free(W); free(zetas); free(etas); free(win); free(orig); free(snap); free(outbox); free(snapw);
+    free(W); free(zetas); free(etas); free(win); free(orig); free(snap); free(outboxes); free(snapw);
 }

@@ -94,6 +94,7 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 #define ORC_TILE_LANE_COIN 32u
 #define ORC_TILE_NO_PAIRS 64u
 #define ORC_TILE_RELAX_R5 128u
+#define ORC_TILE_DRAIN_BESIDE 0x8000u
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,
                          const uint32_t* tlanes, uint64_t steps_total, uint64_t n_items, uint64_t n_first, const uint32_t* tile_begin,

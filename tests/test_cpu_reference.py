@@ -48,6 +48,9 @@ def test_summaries_follow_from_the_runs_and_bands_are_sane():
                 assert again[f] == pytest.approx(d[f], rel=1e-12, abs=1e-15), (k, metric, f)
             lo, hi = cr.band(d)
             assert lo < d["median"] < hi and lo > 0, (k, metric, lo, hi)
+            # no vacuous side: the lower bound is never below 0.4 of the centre (the widest committed distribution, chr6.C4 -N h
+            # theta 0.5 K 0.75, has its lowest run at 0.53 of its median), the upper never above 1.6 of it
+            assert lo >= 0.4 * d["median"] and hi <= 1.6 * d["median"], (k, metric, lo, hi, d["median"])
             # the default band is never tighter than 10 % either way, and a distribution's own median lies inside it
             assert hi - d["median"] >= 0.0999 * d["median"] and d["median"] - lo >= 0.0999 * d["median"]
     # what the old tests did — ONE live run as the yardstick — would have failed the band of its own distribution in some
@@ -61,3 +64,27 @@ def test_a_missing_configuration_is_an_error_not_a_reroll(oa, graphs):
     with pytest.raises(KeyError):
         cr.entry("DRB1-3123", p)
     assert np.isfinite(cr.entry("DRB1-3123", oa.LayoutParams.defaults(graphs("DRB1-3123")))["stress"]["median"])
+
+
+def test_committed_yardsticks_were_rolled_with_todays_oracle():
+    """Every committed yardstick of the CPU restatement's Hogwild loop names the text of the oracle functions it follows from
+    (cpu_reference.hogwild_source_id: generator, sampler, schedule, the 2D and 1D loops).  A change to any of them leaves the
+    yardstick stale — and fails here, in the CPU suite, not on the GPU box whose statistical tests and smoke() read the files.
+    Every entry also says how many threads rolled it (the restatement's result moves with its thread count)."""
+    import json
+    import os
+    sid = cr.hogwild_source_id()
+    seen = 0
+    for name in cr.YARDSTICK_FILES:
+        path = os.path.join(cr.GOLDEN, name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        assert d.get("oracle_hogwild_source_id") == sid, f"{name} was rolled with oracle sources {d.get('oracle_hogwild_source_id')}, today's are {sid}: regenerate it ({d.get('generator')})"
+        seen += 1
+        if "entries" in d:
+            assert all(int(e.get("threads", 0)) >= 1 for e in d["entries"].values()), name
+        else:
+            assert int(d.get("threads", 0)) >= 1, name
+    assert seen >= 4

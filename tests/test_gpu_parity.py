@@ -561,6 +561,18 @@ def test_synthetic_million_node_properties(oa, orc):
     with oa.LayoutSession(g, _params(oa, g)) as s:
         info = s.tile_info()
         assert s.n_streams == 256 * 5 * 256          # five workgroups per CU: 123 outbox buckets, 30 KB of LDS
+        # What the full-width tile kernel EXECUTES is what the host accounts for (`terms += min_term_updates`, the figure the
+        # benchmark divides by time): every wave counts the lanes that finished a term, trip by trip, on the device
+        # (pgsgd_session_terms_executed) — two warm and two cooling iterations, i.e. both instances of the kernel, all
+        # 1280 workgroups, every window in its 13 parts.
+        pd = _params(oa, g)
+        etas_d = oa.path_linear_sgd_layout_schedule(pd)
+        s.upload(X0, Y0)
+        assert s.terms_executed() == 0
+        for k, cooling in enumerate((False, False, True, True)):
+            s.iteration(etas_d[k], cooling, pd.min_term_updates)
+            s.sync()
+            assert s.terms_executed() == (k + 1) * pd.min_term_updates, (k, s.terms_executed(), pd.min_term_updates)
     assert info["tiled"] and not info["warm_per_lane"] and info["n_nonlocal_tiles"] == 0
     assert (info["region_nodes"], info["tile_steps"], info["n_work_items"], info["parts"]) == (256, 224, 3907, 13), info
     assert 12 * 3907 < info["n_launch_items"] <= 13 * 3907 and info["xcd_runs"]    # ... in node order, one run per XCD
@@ -1404,7 +1416,8 @@ def _ragged_graph(oa):
     return oa.Graph.from_arrays(node_len, np.array(first, dtype=np.uint64), np.concatenate(handles))
 
 
-@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages", "synthetic-split", "DRB1-3123-split"])
+@pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages", "synthetic-split", "DRB1-3123-split",
+                                        "synthetic-drain-beside", "DRB1-3123-drain-beside", "synthetic-narrow-messages-drain-beside"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
@@ -1414,8 +1427,13 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     outbox message into 6 bits each: most far updates are then too wide for a message and take the spill words, which
     the drain adds with the messages — the same sums.  `-split`: every window's tiles as three consecutive work items, a later one
     waiting for the one before it (what sessions with launches of few rounds do, WorkItem in pgsgd_tiles.hpp); the mirror follows
-    the same item list."""
-    split = 1
+    the same item list.  `-drain-beside`: the session sums every launch's far pulls on a second stream beside the NEXT launch and
+    delivers them before the same colour's next launch (what sessions of 30 iterations and more do; forced here on six); the mirror
+    keeps one outbox per colour and delivers in that order (ORC_TILE_DRAIN_BESIDE)."""
+    split, policy = 1, 0
+    if graph_name.endswith("-drain-beside"):
+        monkeypatch.setenv("PGSGD_ASYNC_DRAIN", "1")
+        graph_name, policy = graph_name[:-13], orc.TILE_DRAIN_BESIDE
     if graph_name.endswith("-split"):
         monkeypatch.setenv("PGSGD_TILE_SPLIT", "3")
         graph_name, split = graph_name[:-6], 3
@@ -1438,6 +1456,7 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     with oa.LayoutSession(g, p) as s:
         info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
         assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64 and not info["fast_math"]
+        assert s.drain_beside()[0] == bool(policy)
         assert (info["n_nonlocal_tiles"] == 0) == (graph_name != "DRB1-3123")
         assert len(items["local"]) == info["n_launch_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
         assert info["parts"] == split and (len(items["local"]) > info["n_work_items"]) == (split > 1)
@@ -1465,9 +1484,12 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         assert s.outbox_overflow() == 0      # every far update went through the outbox, as the mirror assumes
         assert s.frame_status()[1] == 0      # and the fixed-point frame stayed as it was chosen
     args = (og, orc.params_from(p), p.seed, tiles, items, info["region_nodes"], X0, Y0, x_off, y_off, q)
-    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(*args)
-    Xn, Yn, _, _, _ = orc.tile_layout_q32(*args, policy=orc.TILE_NO_FLUSH)
+    Xo, Yo, dmax_o, ck, far = orc.tile_layout_q32(*args, policy=policy)
+    Xn, Yn, _, _, _ = orc.tile_layout_q32(*args, policy=policy | orc.TILE_NO_FLUSH)
     assert far > 0 and not np.array_equal(w0, w1)
+    if policy:   # the order of delivery is part of the result: the default order gives another layout
+        Xd, Yd, _, _, _ = orc.tile_layout_q32(*args)
+        assert not (np.array_equal(Xd, Xo) and np.array_equal(Yd, Yo))
     assert np.array_equal(Xs, Xn) and np.array_equal(Ys, Yn) and not (np.array_equal(Xs, Xg) and np.array_equal(Ys, Yg))
     assert np.array_equal(Xg, Xo) and np.array_equal(Yg, Yo)
     assert dmax_g == dmax_o

@@ -22,6 +22,7 @@ CURVE_FROM = int(os.environ.get("GAP_CURVE_FROM", str(ITER_MAX - 10)))
 g = oa.Graph.synthetic(N, 50, seed=42)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
 results = []
+ms_of = {}
 set_before = []
 for v_in in sys.argv[4:]:
     for k in set_before:
@@ -43,6 +44,8 @@ for v_in in sys.argv[4:]:
     elif name.startswith("until"):
         os.environ["PGSGD_TILE_UNTIL"] = name[5:]
         set_before.append("PGSGD_TILE_UNTIL")
+    elif name == "sync":      # tile kernel, every launch's far pulls delivered in front of the very next launch (PGSGD_FLAG_SYNC_DRAIN)
+        flags = _lib.FLAG_SYNC_DRAIN
     elif name == "nocap":
         flags = _lib.FLAG_NO_FAR_CAP
     elif name.startswith("lanes"):
@@ -56,6 +59,7 @@ for v_in in sys.argv[4:]:
     with oa.LayoutSession(g, p) as s:
         s.upload(X0, Y0)
         info = s.tile_info()
+        info["drain_beside"] = s.drain_beside()[0]
         for it in range(p.iter_max):
             s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
             s.sync()
@@ -63,7 +67,7 @@ for v_in in sys.argv[4:]:
                 X, Y = s.download_f64(flush=True)
                 curve[it + 1] = oa.path_stress(g, X, Y, 2_000_000, seed=1)
         ms = s.kernel_time()[0] + sum(s.aux_time())
-    cl = stress_classes.classes(g, X, Y)
+    cl = stress_classes.classes(g, X, Y) if not os.environ.get("GAP_NO_CLASSES") else {"total": 0.0, "pairs": 0, "by": {}, "tail": {}, "node_segments": {}}
     nr = oa.path_stress_near(g, X, Y, zmax=4, mod_step=224, mod_rank=256)   # no sampling error: what the layouts really differ by
     cl["near_exact"] = dict(near=nr["near"], by_z=nr["num"].sum(axis=(1, 2)).tolist(), by_z_flips=nr["num"].tolist(), zero_mass=nr["zero_mass"],
                             hist_step=nr["hist_step"].tolist(), hist_rank=nr["hist_rank"].tolist())
@@ -74,17 +78,20 @@ for v_in in sys.argv[4:]:
         if es <= 3:
             ev[f"2e7@{es}"] = oa.path_stress(g, X, Y, 20_000_000, seed=es)
     cl["sampled_evaluator_by_seed"] = ev
-    rec = dict(exp="gap_classes", nodes=N, iter_max=ITER_MAX, terms_per_step=TPS, variant=v_in, tiled=bool(info["tiled"]), parts=info.get("parts"),
+    rec = dict(exp="gap_classes", nodes=N, iter_max=ITER_MAX, terms_per_step=TPS, variant=v_in, tiled=bool(info["tiled"]), parts=info.get("parts"), drain_beside=info["drain_beside"],
                stress_curve=curve, stress_final=curve[p.iter_max], near_exact=cl["near_exact"]["near"], kernel_ms=ms, wall_s=time.time() - t0, classes=cl)
     print(json.dumps(rec), flush=True)
     results.append((v_in, cl))
+    ms_of[v_in] = ms
 for name, cl in results:
     ne = cl["near_exact"]
     hs, hr = np.array(ne["hist_step"]), np.array(ne["hist_rank"])
     if ne and cl.get("sampled_evaluator_by_seed"):
         print(f"{name:40s} sampled evaluator by seed: " + " ".join(f"{k}={v:.4f}" for k, v in cl["sampled_evaluator_by_seed"].items()), flush=True)
-    print(f"{name:40s} near_exact {ne['near']:.5f} by z {np.round(ne['by_z'], 5).tolist()}  step%224: first8 {hs[:8].sum() / hs.sum():.4f} last8 {hs[-8:].sum() / hs.sum():.4f} (uniform {8 / 224:.4f})"
+    print(f"{name:40s} kernel_ms {ms_of[name]:.0f} near_exact {ne['near']:.5f} by z {np.round(ne['by_z'], 5).tolist()}  step%224: first8 {hs[:8].sum() / hs.sum():.4f} last8 {hs[-8:].sum() / hs.sum():.4f} (uniform {8 / 224:.4f})"
           f"  rank%256: first8 {hr[:8].sum() / hr.sum():.4f} last8 {hr[-8:].sum() / hr.sum():.4f} (uniform {8 / 256:.4f})", flush=True)
 for name, cl in results[1:]:
+    if os.environ.get("GAP_NO_CLASSES"):
+        break
     print(f"--- {results[0][0]} vs {name}", flush=True)
     print(stress_classes.diff_table(results[0][1], cl, (results[0][0][:12], name[:12])), flush=True)

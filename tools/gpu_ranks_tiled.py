@@ -47,7 +47,9 @@ for rep in range(reps):
         for e in engines: e.sync()
         ms, n = engines[0].session.kernel_time()
         X, Y = engines[0].result()
+        aux = engines[0].session.aux_time()
         print(json.dumps(dict(exp="ranks_tiled", shard=mode, rep=rep, G=G, exchanges_per_iteration=blocks, stress=oa.path_stress(g, X, Y, 2_000_000, seed=1),
+                              near_exact=oa.path_stress_near(g, X, Y, zmax=4)["near"], rank0_snapshot_ms=aux[0], rank0_drain_ms=aux[1],
                               path_distance=oa.path_distance(g, X, Y)[0], rank0_kernel_ms=ms, rank0_launches=n,
                               rank0_terms_per_s=1e3 * p.min_term_updates * p.iter_max / G / ms)), flush=True)
         for e in engines: e.close()

@@ -18,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 SNAP_ITERS = [1, 5, 10, 15, 20, 30]
 EVAL_PAIRS = 2_000_000
@@ -39,7 +40,7 @@ def main():
     p = oa.LayoutParams.defaults(g)
     out = {"graph": {"nodes": g.n_nodes, "paths": g.n_paths, "steps": g.n_steps, "seed": 42},
            "params": {"iter_max": p.iter_max, "min_term_updates": p.min_term_updates, "theta": p.theta},
-           "snap_iters": SNAP_ITERS, "eval_pairs": EVAL_PAIRS, "eval_seed": EVAL_SEED, "threads": args.threads, "runs": []}
+           "oracle_hogwild_source_id": __import__("cpu_reference").hogwild_source_id(), "snap_iters": SNAP_ITERS, "eval_pairs": EVAL_PAIRS, "eval_seed": EVAL_SEED, "threads": args.threads, "runs": []}
     if os.path.exists(args.out):
         with open(args.out) as f:
             old = json.load(f)

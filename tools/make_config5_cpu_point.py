@@ -23,6 +23,12 @@ ITER_MAX = 15
 TERMS_PER_STEP = 2
 
 
+def _hogwild_id():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_reference as cr
+    return cr.hogwild_source_id()
+
+
 def main():
     global ITER_MAX, TERMS_PER_STEP, SNAP_ITERS
     ap = argparse.ArgumentParser()
@@ -44,7 +50,7 @@ def main():
     p = oa.LayoutParams.defaults(g, iter_max=ITER_MAX, min_term_updates=TERMS_PER_STEP * g.n_steps)
     out = {"generator": "tools/make_config5_cpu_point.py", "graph": {"nodes": g.n_nodes, "paths": g.n_paths, "steps": g.n_steps, "seed": 42},
            "params": {"iter_max": p.iter_max, "min_term_updates": p.min_term_updates, "theta": p.theta, "cooling_start": p.cooling_start},
-           "snap_iters": SNAP_ITERS, "eval_pairs": EVAL_PAIRS, "eval_seed": EVAL_SEED, "threads": args.threads, "runs": []}
+           "oracle_hogwild_source_id": _hogwild_id(), "snap_iters": SNAP_ITERS, "eval_pairs": EVAL_PAIRS, "eval_seed": EVAL_SEED, "threads": args.threads, "runs": []}
     if os.path.exists(args.out):
         with open(args.out) as f:
             old = json.load(f)

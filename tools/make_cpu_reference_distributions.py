@@ -62,6 +62,10 @@ def main():
               "what": "sampled path stress (1e6 pairs, evaluator seed 0x5eed) and `odgi stats -s` path distance per node of "
                       "the CPU restatement's Hogwild layouts (oracle/pgsgd_oracle.c: orc_layout_hogwild)",
               "eval_pairs": cr.EVAL_PAIRS, "host": {"cpus": os.cpu_count()}, "entries": {}}
+    # entries rolled with other oracle sources are stale: a file that mixes ids is refused rather than stamped over
+    if db.get("oracle_hogwild_source_id", cr.hogwild_source_id()) != cr.hogwild_source_id():
+        raise SystemExit(f"{cr.PATH} was rolled with oracle sources {db['oracle_hogwild_source_id']}, today's are {cr.hogwild_source_id()}: delete it and roll every entry again")
+    db["oracle_hogwild_source_id"] = cr.hogwild_source_id()
     graphs = {}
     for name, gf, pf, init, seeds, threads, fast in configs:
         if name not in graphs:
