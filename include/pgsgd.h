@@ -60,6 +60,9 @@ const char* pgsgd_last_error(void);
  *   step_pos     <- XPPath::positions: 0-based bp offset of the step start in its path
  *                                                                (xp.cpp:607-617, 393-397)
  * nr_iv (rank of a step in its path) is implicit: rank = k - path_first[step_path[k]].
+ * step_path and step_pos MAY BE NULL (both follow from the other three): the session then uploads 4 bytes per step instead of
+ * 12 and builds the positions on the device (a segmented prefix sum over node_len[step_handle >> 1]; the reference's GPU route
+ * flattens its paths on the device too, src/cuda/layout.cu:371-410); host code that needs them (the quality figures) walks the paths.
  */
 typedef struct pgsgd_graph_view {
     uint64_t n_nodes;
@@ -67,9 +70,9 @@ typedef struct pgsgd_graph_view {
     uint64_t n_paths;
     const uint32_t* node_len;    /* [n_nodes]   */
     const uint64_t* path_first;  /* [n_paths+1] */
-    const uint32_t* step_path;   /* [n_steps]   */
+    const uint32_t* step_path;   /* [n_steps] or NULL */
     const uint32_t* step_handle; /* [n_steps]   */
-    const uint64_t* step_pos;    /* [n_steps]   */
+    const uint64_t* step_pos;    /* [n_steps] or NULL */
 } pgsgd_graph_view;
 
 /* ---- parameters: the argument list of path_linear_sgd_layout_gpu -------------------------- */
@@ -262,6 +265,8 @@ int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction, double* la
 /* Tile kernel: terms that went for their window ends' locks so far (conflict resolution on shared node coordinates while
  * the learning rate is in the projection regime), and terms among them that found an end taken and did nothing. */
 int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost);
+/* parity hook: step records [first, first + count) as the session built them: {handle, node length, position low, position high} */
+int pgsgd_session_read_step_records(pgsgd_session* s, uint64_t first, uint64_t count, uint32_t* out);
 /* whether the session sums its launches' far pulls on a second stream beside the next launch (PGSGD_FLAG_SYNC_DRAIN: never), and
  * far_drain_kernel's time there (ms, HIP events) — off the launch stream's critical path */
 int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* drain_ms);
@@ -384,6 +389,11 @@ int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph** out);
 int pgsgd_graph_from_og(const char* path, int n_threads, pgsgd_graph** out);
 /* The reference's input dispatch (utils.cpp:110-134): names ending in "gfa" are GFA, the rest .og. */
 int pgsgd_graph_load(const char* path, int n_threads, pgsgd_graph** out);
+/* ... with PGSGD_LOAD_NO_STEP_INDEX: step_path and step_pos are not built (GFA) or dropped after the walk (.og): the views carry NULL */
+#define PGSGD_LOAD_NO_STEP_INDEX 1u
+int pgsgd_graph_load_flags(const char* path, int n_threads, uint32_t flags, pgsgd_graph** out);
+/* frees step_path and step_pos of a loaded graph; views taken afterwards carry NULL for them */
+int pgsgd_graph_drop_step_index(pgsgd_graph* g);
 /* Seeded synthetic "linearised pangenome" (BASELINE.json configs 4/5). */
 int pgsgd_graph_synthetic(uint64_t n_nodes, uint64_t n_paths, uint64_t seed, pgsgd_graph** out);
 void pgsgd_graph_free(pgsgd_graph* g);

@@ -131,6 +131,7 @@ SIGNATURES = [
     ("pgsgd_tile_split_items", C.c_int64, [P(u32), P(u32), P(u32), u64, u32, u32, P(u32), P(u32), P(u32), P(u32), u64]),
     ("pgsgd_session_tile_conflicts", C.c_int, [C.c_void_p, P(u64), P(u64)]),
     ("pgsgd_session_terms_executed", C.c_int, [C.c_void_p, P(u64)]),
+    ("pgsgd_session_read_step_records", C.c_int, [C.c_void_p, u64, u64, P(u32)]),
     ("pgsgd_session_drain_beside", C.c_int, [C.c_void_p, P(C.c_int), P(f64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
@@ -156,6 +157,8 @@ SIGNATURES = [
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_from_og", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_load", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
+    ("pgsgd_graph_load_flags", C.c_int, [C.c_char_p, C.c_int, C.c_uint32, P(C.c_void_p)]),
+    ("pgsgd_graph_drop_step_index", C.c_int, [C.c_void_p]),
     ("pgsgd_graph_synthetic", C.c_int, [u64, u64, u64, P(C.c_void_p)]),
     ("pgsgd_graph_free", None, [C.c_void_p]),
     ("pgsgd_graph_get_view", C.c_int, [C.c_void_p, P(GraphView)]),

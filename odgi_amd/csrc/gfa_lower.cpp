@@ -343,9 +343,12 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         g->path_first[P] = k;
     }
     const uint64_t S = g->path_first[P];
-    g->step_path.resize(S);
+    // PGSGD_LOAD_NO_STEP_INDEX (pgsgd_graph_load_flags): step_path and step_pos are not built — 12 of the index's 16 bytes per step —
+    // the session builds the positions on the device from the handles, host code that needs them walks the paths (pgsgd::StepIndex)
+    const bool index = !(pgsgd::load_flags() & PGSGD_LOAD_NO_STEP_INDEX);
+    if (index) g->step_path.resize(S);
     g->step_handle.resize(S);
-    g->step_pos.resize(S);
+    if (index) g->step_pos.resize(S);
     for_each_chunk([&](Chunk& c) {
         uint64_t k = c.first, bp = 0;
         const std::string& name = g->path_names[c.path];
@@ -363,7 +366,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
                 c.msg = "path '" + name + "' visits missing node '" + std::string(p, te - 1) + "'";
                 return false;
             }
-            g->step_path[k] = (uint32_t)c.path;
+            if (index) g->step_path[k] = (uint32_t)c.path;
             g->step_handle[k] = (uint32_t)(2 * (id - 1) + (orient == '-' ? 1 : 0));
             bp += g->node_len[id - 1];
             ++k;
@@ -377,7 +380,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
             uint64_t id = 0;
             while (p < c.e && (unsigned)(*p - '0') < 10u && p - t < 18) id = id * 10 + (uint64_t)(*p++ - '0');
             if (p > t && p < c.e && (*p == '+' || *p == '-') && (p + 1 == c.e || p[1] == ',') && id >= 1 && id <= N) {
-                g->step_path[k] = (uint32_t)c.path;
+                if (index) g->step_path[k] = (uint32_t)c.path;
                 g->step_handle[k] = (uint32_t)(2 * (id - 1) + (*p == '-' ? 1 : 0));
                 bp += g->node_len[id - 1];
                 ++k;
@@ -405,7 +408,7 @@ extern "C" int pgsgd_graph_from_gfa(const char* path, int n_threads, pgsgd_graph
         uint64_t pos = 0;
         for (uint64_t ci = first_chunk[i]; ci < first_chunk[i + 1]; ++ci) { chunks[ci].pos0 = pos; pos += chunks[ci].bp; }
     }
-    for_each_chunk([&](Chunk& c) {
+    if (index) for_each_chunk([&](Chunk& c) {
         uint64_t pos = c.pos0;
         for (uint64_t k = c.first; k < c.first + c.steps; ++k) {
             g->step_pos[k] = pos;
@@ -539,10 +542,32 @@ extern "C" int pgsgd_graph_get_view(const pgsgd_graph* g, pgsgd_graph_view* v) {
     v->n_paths = g->n_paths();
     v->node_len = g->node_len.data();
     v->path_first = g->path_first.data();
-    v->step_path = g->step_path.data();
+    v->step_path = g->step_path.size() ? g->step_path.data() : nullptr;   // (NULL: not built, or dropped — pgsgd_graph_drop_step_index)
     v->step_handle = g->step_handle.data();
-    v->step_pos = g->step_pos.data();
+    v->step_pos = g->step_pos.size() ? g->step_pos.data() : nullptr;
     return PGSGD_OK;
+}
+
+// The two arrays that follow from the others (step_path from path_first; step_pos from step_handle and node_len): freed, the views
+// handed out from now on carry NULL for them.  The session then uploads 4 bytes per step instead of 12 and builds the positions on
+// the device.
+extern "C" int pgsgd_graph_drop_step_index(pgsgd_graph* g) {
+    if (!g) return PGSGD_E_INVALID;
+    pgsgd::raw_vector<uint32_t>().swap(g->step_path);
+    pgsgd::raw_vector<uint64_t>().swap(g->step_pos);
+    return PGSGD_OK;
+}
+
+namespace pgsgd {
+static thread_local uint32_t t_load_flags = 0;
+uint32_t load_flags() { return t_load_flags; }
+}  // namespace pgsgd
+extern "C" int pgsgd_graph_load_flags(const char* path, int n_threads, uint32_t flags, pgsgd_graph** out) {
+    pgsgd::t_load_flags = flags;
+    const int rc = pgsgd_graph_load(path, n_threads, out);
+    pgsgd::t_load_flags = 0;
+    if (rc == PGSGD_OK && (flags & PGSGD_LOAD_NO_STEP_INDEX)) (void)pgsgd_graph_drop_step_index(*out);   // (.og: the walk built them)
+    return rc;
 }
 
 extern "C" uint64_t pgsgd_graph_edge_count(const pgsgd_graph* g) { return g ? g->edges.size() / 2 : 0; }

@@ -173,7 +173,9 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     // utils.cpp:110-134: names ending in "gfa" are built from GFA, anything else (and "-" = stdin) is .og
     const std::string infile = a.get("idx");
     pgsgd_graph* graph = nullptr;
-    int rc = pgsgd_graph_load(infile.c_str(), (int)num_threads, &graph);
+    // step_path / step_pos are not built on the host: the session builds the positions on the device from the handles (4 bytes per
+    // step over PCIe instead of 12); `--stress` walks the paths for its own figures (pgsgd::StepIndex)
+    int rc = pgsgd_graph_load_flags(infile.c_str(), (int)num_threads, PGSGD_LOAD_NO_STEP_INDEX, &graph);
     if (rc == PGSGD_E_NOTOPTIMIZED) {
         fprintf(stderr, "[odgi::layout] error: the graph is not optimized. Please run 'odgi sort' using -O, --optimize.\n");
         return 1;

@@ -49,7 +49,9 @@ int pgsgd_validate_view(const pgsgd_graph_view* g) {
     if (!g) { set_error("graph view is NULL"); return PGSGD_E_INVALID; }
     if (g->n_nodes == 0 || g->n_nodes > 0x7fffffffull) { set_error("n_nodes %llu out of range [1, 2^31)", (unsigned long long)g->n_nodes); return PGSGD_E_INVALID; }
     if (g->n_paths >= 0xffffffffull) { set_error("too many paths"); return PGSGD_E_INVALID; }
-    if (!g->node_len || !g->path_first || (g->n_steps && (!g->step_path || !g->step_handle || !g->step_pos))) {
+    // (step_path and step_pos may be NULL: both follow from path_first, step_handle and node_len — the session builds the positions on
+    // the device, host code that needs them walks the paths)
+    if (!g->node_len || !g->path_first || (g->n_steps && !g->step_handle)) {
         set_error("graph view has NULL arrays");
         return PGSGD_E_INVALID;
     }
@@ -239,7 +241,8 @@ double step_rank_disorder(const pgsgd_graph_view* g, const uint32_t* new_rank_of
     uint64_t seen = 0, far = 0;
     for (uint64_t i = 0; i < K; ++i) {
         const uint64_t k = (uint64_t)(((unsigned __int128)i * (S - 1)) / K);
-        if (g->step_path[k] != g->step_path[k + 1]) continue;
+        // k and k + 1 on one path: k + 1 is not a path's first step
+        if (std::binary_search(g->path_first, g->path_first + g->n_paths + 1, k + 1)) continue;
         uint32_t a = g->step_handle[k] >> 1, b = g->step_handle[k + 1] >> 1;
         if (new_rank_of_old) { a = new_rank_of_old[a]; b = new_rank_of_old[b]; }
         ++seen;
@@ -266,13 +269,17 @@ extern "C" int pgsgd_graph_path_order(const pgsgd_graph_view* g, uint32_t* new_r
     };
     std::vector<double> sum(N, 0.0);
     std::vector<uint32_t> cnt(N, 0);
-    for (uint64_t k = 0; k < S; ++k) {
-        const uint32_t n = g->step_handle[k] >> 1;
-        sum[n] += (double)g->step_pos[k];
-        cnt[n]++;
-        if (k + 1 < S && g->step_path[k] == g->step_path[k + 1]) {
-            const uint32_t a = find(n), b = find(g->step_handle[k + 1] >> 1);
-            if (a != b) parent[a < b ? b : a] = a < b ? a : b;   // the smaller rank is the component's name
+    for (uint64_t p = 0; p < g->n_paths; ++p) {   // (path by path: positions and "same path" need neither step_pos nor step_path)
+        uint64_t pos = 0;
+        for (uint64_t k = g->path_first[p]; k < g->path_first[p + 1]; ++k) {
+            const uint32_t n = g->step_handle[k] >> 1;
+            sum[n] += (double)pos;
+            pos += g->node_len[n];
+            cnt[n]++;
+            if (k + 1 < g->path_first[p + 1]) {
+                const uint32_t a = find(n), b = find(g->step_handle[k + 1] >> 1);
+                if (a != b) parent[a < b ? b : a] = a < b ? a : b;   // the smaller rank is the component's name
+            }
         }
     }
     struct Key { uint32_t comp; double pos; uint32_t old; };

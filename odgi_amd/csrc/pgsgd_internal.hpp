@@ -121,3 +121,30 @@ struct pgsgd_graph {
 };
 
 int pgsgd_validate_view(const pgsgd_graph_view* g);
+
+namespace pgsgd {
+uint32_t load_flags();   // of the pgsgd_graph_load_flags call in progress on this thread (gfa_lower.cpp)
+// step_pos / step_path of a view for host code that reads them at random steps (the quality figures): the view's arrays, or — when
+// the view carries none (pgsgd_graph_view::step_pos / step_path may be NULL) — built here by one walk over the paths (xp.cpp:607-617).
+struct StepIndex {
+    const uint64_t* pos;
+    const uint32_t* path;
+    std::vector<uint64_t> own_pos;
+    std::vector<uint32_t> own_path;
+    explicit StepIndex(const pgsgd_graph_view* g) : pos(g->step_pos), path(g->step_path) {
+        if (pos && path) return;
+        if (!pos) own_pos.resize(g->n_steps);
+        if (!path) own_path.resize(g->n_steps);
+        for (uint64_t p = 0; p < g->n_paths; ++p) {
+            uint64_t bp = 0;
+            for (uint64_t k = g->path_first[p]; k < g->path_first[p + 1]; ++k) {
+                if (!pos) own_pos[k] = bp;
+                if (!path) own_path[k] = (uint32_t)p;
+                bp += g->node_len[g->step_handle[k] >> 1];
+            }
+        }
+        if (!pos) pos = own_pos.data();
+        if (!path) path = own_path.data();
+    }
+};
+}  // namespace pgsgd

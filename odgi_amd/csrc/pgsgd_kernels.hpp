@@ -1122,6 +1122,103 @@ __global__ void build_step_records(const uint32_t* step_handle, const uint64_t* 
     }
 }
 
+// ---- step positions on the device (the reference's GPU route flattens paths in parallel, src/cuda/layout.cu:371-410) ----
+// step_pos[k] = bp offset of step k inside its path (xp.cpp:607-617) = an exclusive prefix sum of node_len[step_handle >> 1] that
+// starts again at every path.  A caller that hands over no step_pos (pgsgd_graph_view::step_pos == NULL) uploads 4 bytes per step
+// instead of 12; the session builds the positions from the handles: (1) sums of tiles of kPosTile steps, (2) their exclusive scan,
+// (3) the prefix of every step over ALL steps, (4) minus the prefix at its path's first step.
+constexpr uint32_t kPosItems = 16, kPosBlock = 256, kPosTile = kPosItems * kPosBlock;
+__global__ __launch_bounds__(kPosBlock) void step_len_tile_sums(const uint32_t* step_handle, const uint32_t* node_len, uint64_t n_steps, uint64_t n_tiles, uint64_t* tile_sum) {
+    __shared__ uint64_t part[kPosBlock / 64];
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t k0 = t * kPosTile + (uint64_t)threadIdx.x * kPosItems;
+        uint64_t sum = 0;
+        for (uint32_t i = 0; i < kPosItems; ++i)
+            if (k0 + i < n_steps) sum += node_len[step_handle[k0 + i] >> 1];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t tot = 0;
+            for (uint32_t w = 0; w < kPosBlock / 64; ++w) tot += part[w];
+            tile_sum[t] = tot;
+        }
+        __syncthreads();
+    }
+}
+// exclusive scan of the tile sums in place: one workgroup, chunks of 1024 (1.1e5 tiles at 4.7e8 steps)
+__global__ __launch_bounds__(1024) void scan_tile_sums(uint64_t* tile_sum, uint64_t n_tiles) {
+    __shared__ uint64_t buf[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_tiles; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tile_sum[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+            const uint64_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sum[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kPosBlock) void step_prefix_kernel(const uint32_t* step_handle, const uint32_t* node_len, uint64_t n_steps, uint64_t n_tiles, const uint64_t* tile_off,
+                                                                uint64_t* prefix) {
+    __shared__ uint64_t part[kPosBlock];
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t k0 = t * kPosTile + (uint64_t)threadIdx.x * kPosItems;
+        uint32_t len[kPosItems];
+        uint64_t sum = 0;
+        for (uint32_t i = 0; i < kPosItems; ++i) {
+            len[i] = k0 + i < n_steps ? node_len[step_handle[k0 + i] >> 1] : 0u;
+            sum += len[i];
+        }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < kPosBlock; off <<= 1) {
+            const uint64_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint64_t pos = tile_off[t] + part[threadIdx.x] - sum;
+        for (uint32_t i = 0; i < kPosItems; ++i) {
+            if (k0 + i < n_steps) prefix[k0 + i] = pos;
+            pos += len[i];
+        }
+        __syncthreads();
+    }
+}
+// the path of step k: the last p with path_first[p] <= k (empty paths share their first step with the next path)
+__device__ __forceinline__ uint32_t path_of_step(const uint64_t* path_first, uint32_t n_paths, uint64_t k) {
+    uint32_t lo = 0, hi = n_paths;   // path_first[lo] <= k < path_first[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (path_first[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ void path_base_kernel(const uint64_t* prefix, const uint64_t* path_first, uint32_t n_paths, uint64_t n_steps, uint64_t* base) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_paths) base[p] = path_first[p] < n_steps ? prefix[path_first[p]] : 0;
+}
+__global__ void step_pos_rebase_kernel(uint64_t* prefix, uint64_t n_steps, const uint64_t* path_first, uint32_t n_paths, const uint64_t* base) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_steps; k += (uint64_t)gridDim.x * blockDim.x)
+        prefix[k] -= base[path_of_step(path_first, n_paths, k)];
+}
+// out[i] = values[index[i]] (the few positions the host needs back: the last step of every path, the layout check's pairs)
+__global__ void gather_u64_kernel(const uint64_t* values, const uint64_t* index, uint64_t n, uint64_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = values[index[i]];
+}
+
 __device__ __forceinline__ uint32_t quantize(float v, double off, float scale) {
     double q = rint(((double)v - off) * (double)scale);
     q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);

@@ -645,7 +645,8 @@ static int build_launch_items(pgsgd_session* s) {
 // (profiles/r01/init_modes_tile_vs_per_lane.jsonl, shuffled_graphs.jsonl).  So upload measures the stress of
 // the initial layout on these pairs, and when it is not small the iterations before cooling — where long
 // moves happen (mu = 1 for every distance) — run the per-lane kernel.
-static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
+template <class FetchPos>
+static int sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g, FetchPos&& fetch_pos) {
     pgsgd::Xoshiro256Plus rng;
     rng.seed(0x5eedc0de);
     s->check_pairs.clear();
@@ -654,20 +655,29 @@ static void sample_check_pairs(pgsgd_session* s, const pgsgd_graph_view* g) {
     uint64_t total_bp = 0;
     for (uint64_t i = 0; i < g->n_nodes; ++i) total_bp += g->node_len[i];
     const double d_min = 8.0 * 2.0 * (double)s->region * ((double)total_bp / (double)g->n_nodes);
-    for (int tries = 0; tries < 65536 && s->check_pairs.size() < 16384; ++tries) {
+    // candidates first (the draws do not depend on the positions), their positions in one go (they may live on the device only)
+    std::vector<uint64_t> idx, pos;
+    for (int tries = 0; tries < 65536; ++tries) {
         const uint64_t ka = pgsgd::uniform_below(rng, g->n_steps);
-        const uint32_t path = g->step_path[ka];
+        const uint64_t path = g->step_path ? g->step_path[ka] : (uint64_t)(std::upper_bound(g->path_first, g->path_first + g->n_paths + 1, ka) - g->path_first) - 1;
         const uint64_t b = g->path_first[path], cnt = g->path_first[path + 1] - b;
         if (cnt < 2) continue;
         const uint64_t kb = b + pgsgd::uniform_below(rng, cnt);
-        const uint64_t pa = g->step_pos[ka], pb = g->step_pos[kb];
+        idx.push_back(ka);
+        idx.push_back(kb);
+    }
+    const int rc = fetch_pos(idx, pos);
+    if (rc) return rc;
+    for (size_t j = 0; j + 1 < idx.size() && s->check_pairs.size() < 16384; j += 2) {
+        const uint64_t pa = pos[j], pb = pos[j + 1];
         if ((double)(pa > pb ? pa - pb : pb - pa) < d_min) continue;
         pgsgd_session::CheckPair cp;
-        cp.end_a = g->step_handle[ka];  // the end a step starts at: 2 * rank + is_reverse
-        cp.end_b = g->step_handle[kb];
+        cp.end_a = g->step_handle[idx[j]];  // the end a step starts at: 2 * rank + is_reverse
+        cp.end_b = g->step_handle[idx[j + 1]];
         cp.d = (float)(pa > pb ? pa - pb : pb - pa);
         s->check_pairs.push_back(cp);
     }
+    return PGSGD_OK;
 }
 
 static double check_pairs_stress(const pgsgd_session* s, const float* X, const float* Y) {
@@ -717,12 +727,9 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     s->upd = (p->flags & PGSGD_FLAG_HOGWILD_STORES) ? pgsgd::kUpdStore : pgsgd::kUpdAtomic;
     for (uint64_t i = 0; i < g->n_paths; ++i) {
         const uint64_t e = g->path_first[i + 1];
-        if (e > g->path_first[i]) {
-            const uint64_t last = e - 1;
-            if ((g->step_handle[last] >> 1) >= g->n_nodes) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
-            s->max_path_bp = std::max(s->max_path_bp, g->step_pos[last] + g->node_len[g->step_handle[last] >> 1]);
-        }
+        if (e > g->path_first[i] && (g->step_handle[e - 1] >> 1) >= g->n_nodes) { set_error("a step names a node rank outside the graph"); delete s; return PGSGD_E_INVALID; }
     }
+    std::vector<uint64_t> path_end_bp(g->n_paths, 0);   // bp length of every path (filled once the step positions are there)
     auto fail = [&](int code) {
         pgsgd_session_destroy(s);
         return code;
@@ -763,6 +770,71 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         (void)hipFree(d_counts);
         (void)hipFree(d_bad);
         if (h_bad) { set_error("a step names a node rank outside the graph"); return fail(PGSGD_E_INVALID); }
+    }
+    // Step positions (xp.cpp:607-617): the caller's array — or, when the view carries none (pgsgd_graph_view::step_pos == NULL: 4 bytes
+    // per step over PCIe instead of 12, and no walk over the paths on the host), built here from the handles (pgsgd_kernels.hpp:
+    // step_prefix_kernel).  The host needs a few of them back: every path's last step (its bp length) and the layout check's pairs.
+    uint64_t* d_pos = nullptr;
+    uint32_t* d_len = nullptr;
+    struct PosGuard { uint64_t*& p; uint32_t*& l; ~PosGuard() { if (p) (void)hipFree(p); if (l) (void)hipFree(l); } } pos_guard{d_pos, d_len};
+    S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
+    S_TRY(hipMemcpyAsync(d_len, g->node_len, g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    S_TRY(hipMalloc(&d_pos, std::max<uint64_t>(1, g->n_steps) * sizeof(uint64_t)));
+    if (g->step_pos) {
+        S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    } else if (g->n_steps) {
+        const uint64_t n_tiles = (g->n_steps + pgsgd::kPosTile - 1) / pgsgd::kPosTile;
+        uint64_t *d_tile = nullptr, *d_first = nullptr, *d_pbase = nullptr;
+        S_TRY(hipMalloc(&d_tile, n_tiles * sizeof(uint64_t)));
+        S_TRY(hipMalloc(&d_first, (g->n_paths + 1) * sizeof(uint64_t)));
+        S_TRY(hipMalloc(&d_pbase, std::max<uint64_t>(1, g->n_paths) * sizeof(uint64_t)));
+        S_TRY(hipMemcpyAsync(d_first, g->path_first, (g->n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+        const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, 256 * 16);
+        hipLaunchKernelGGL(pgsgd::step_len_tile_sums, dim3(grid), dim3(pgsgd::kPosBlock), 0, s->stream, d_handle, d_len, g->n_steps, n_tiles, d_tile);
+        hipLaunchKernelGGL(pgsgd::scan_tile_sums, dim3(1), dim3(1024), 0, s->stream, d_tile, n_tiles);
+        hipLaunchKernelGGL(pgsgd::step_prefix_kernel, dim3(grid), dim3(pgsgd::kPosBlock), 0, s->stream, d_handle, d_len, g->n_steps, n_tiles, d_tile, d_pos);
+        hipLaunchKernelGGL(pgsgd::path_base_kernel, dim3((unsigned)((g->n_paths + 255) / 256)), dim3(256), 0, s->stream, d_pos, d_first, (uint32_t)g->n_paths, g->n_steps, d_pbase);
+        hipLaunchKernelGGL(pgsgd::step_pos_rebase_kernel, dim3((unsigned)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 16)), dim3(256), 0, s->stream, d_pos, g->n_steps, d_first,
+                           (uint32_t)g->n_paths, d_pbase);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        (void)hipFree(d_tile); (void)hipFree(d_first); (void)hipFree(d_pbase);
+        if (e != hipSuccess) { set_error("step positions on the device: %s", hipGetErrorString(e)); return fail(e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP); }
+        timer.lap("step positions (device)");
+    }
+    // positions of chosen steps, on the host: out[i] = step_pos[idx[i]]
+    auto fetch_pos = [&](const std::vector<uint64_t>& idx, std::vector<uint64_t>& out) -> int {
+        out.resize(idx.size());
+        if (idx.empty()) return PGSGD_OK;
+        if (g->step_pos) { for (size_t i = 0; i < idx.size(); ++i) out[i] = g->step_pos[idx[i]]; return PGSGD_OK; }
+        uint64_t *d_idx = nullptr, *d_out = nullptr;
+        hipError_t e = hipMalloc(&d_idx, idx.size() * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc(&d_out, idx.size() * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pgsgd::gather_u64_kernel, dim3((unsigned)((idx.size() + 255) / 256)), dim3(256), 0, s->stream, d_pos, d_idx, (uint64_t)idx.size(), d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, idx.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (d_idx) (void)hipFree(d_idx);
+        if (d_out) (void)hipFree(d_out);
+        if (e != hipSuccess) { set_error("reading step positions back: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PGSGD_E_NOMEM : PGSGD_E_HIP; }
+        return PGSGD_OK;
+    };
+    {
+        std::vector<uint64_t> last_idx, last_pos;
+        std::vector<uint64_t> of_path;
+        for (uint64_t i = 0; i < g->n_paths; ++i)
+            if (g->path_first[i + 1] > g->path_first[i]) { last_idx.push_back(g->path_first[i + 1] - 1); of_path.push_back(i); }
+        rc = fetch_pos(last_idx, last_pos);
+        if (rc) return fail(rc);
+        for (size_t j = 0; j < last_idx.size(); ++j) {
+            path_end_bp[of_path[j]] = last_pos[j] + g->node_len[g->step_handle[last_idx[j]] >> 1];
+            s->max_path_bp = std::max(s->max_path_bp, path_end_bp[of_path[j]]);
+        }
+    }
+    {
         // Outbox buckets: power-of-two ranges of node ends, at most 256 of them (a workgroup stages a 64-byte line per
         // bucket in LDS).  One drain workgroup accumulates up to 2^14 ends (128 KiB of LDS); wider buckets, from
         // ~2.1e6 nodes on, are read by 2^(shift - 14) workgroups each (a second bucketing pass is the fix).
@@ -935,8 +1007,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         bool short_paths = true, paths_32 = true;  // (the fast instance keeps positions as 32-bit words: every path shorter than 2^32 bp)
         for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
             if (g->path_first[q + 1] > g->path_first[q]) {
-                const uint64_t last = g->path_first[q + 1] - 1;
-                const uint64_t path_end = g->step_pos[last] + g->node_len[g->step_handle[last] >> 1];
+                const uint64_t path_end = path_end_bp[q];
                 short_paths = path_end < (1ull << 52);
                 paths_32 = paths_32 && path_end < (1ull << 32);
             }
@@ -1007,7 +1078,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             // (a randomly numbered graph ends at stress 3e4, profiles/r01/shuffled_graphs.jsonl): per-lane kernel.
             s->tiled = force || 10 * ht.n_nonlocal <= ht.tiles.size();
             if (s->tiled) {
-                sample_check_pairs(s, g);
+                rc = sample_check_pairs(s, g, fetch_pos);
+                if (rc) return fail(rc);
                 s->tile_steps_total = ht.steps_total;
                 {   // a launch sends at most one message per term of a tile with a window, two per term of a window-less tile
                     double bound = 0;
@@ -1054,14 +1126,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     timer.lap("stream, occupancy, tile upload");
     // step records: upload the SoA arrays, pack on the device, drop the staging copies
     {
-        uint32_t* d_len = nullptr;
-        uint64_t* d_pos = nullptr;
         S_TRY(hipMalloc(&s->d_recs, g->n_steps * sizeof(uint4)));
         if (s->tiled) S_TRY(hipMalloc(&s->d_recs2, pgsgd::recs2_pieces(g->n_steps) * sizeof(uint4)));
-        S_TRY(hipMalloc(&d_pos, g->n_steps * sizeof(uint64_t)));
-        S_TRY(hipMalloc(&d_len, g->n_nodes * sizeof(uint32_t)));
-        S_TRY(hipMemcpyAsync(d_pos, g->step_pos, g->n_steps * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
-        S_TRY(hipMemcpyAsync(d_len, g->node_len, g->n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         const int grid = (int)std::min<uint64_t>((g->n_steps + 255) / 256, 256 * 8);
         unsigned int* d_bad = nullptr;
         unsigned int h_bad = 0;
@@ -1074,13 +1140,13 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         S_TRY(hipStreamSynchronize(s->stream));
         (void)hipFree(d_bad);
         if (h_bad) {
-            (void)hipFree(d_pos);
-            (void)hipFree(d_len);
             set_error("a step names a node rank outside the graph");
             return fail(PGSGD_E_INVALID);
         }
         (void)hipFree(d_pos);
+        d_pos = nullptr;
         (void)hipFree(d_len);
+        d_len = nullptr;
     }
     if (s->tiled) {  // the snapshot pass reads the handles (4 bytes per step), not the records: the session keeps them
         s->d_step_handle = d_handle;
@@ -2249,6 +2315,17 @@ extern "C" int pgsgd_session_aux_time(pgsgd_session* s, double* snapshot_ms, dou
     return PGSGD_OK;
 }
 
+// Parity hook: the session's step records [first, first + count) as it built them — {handle, node length, position low, position high}
+// per step — whether the positions came with the view or were built on the device (pgsgd_graph_view::step_pos == NULL).
+extern "C" int pgsgd_session_read_step_records(pgsgd_session* s, uint64_t first, uint64_t count, uint32_t* out) {
+    pgsgd::clear_error();
+    if (!s || !out || first > s->n_steps || count > s->n_steps - first) return PGSGD_E_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (count) HIP_TRY(hipMemcpy(out, s->d_recs + first, count * sizeof(uint4), hipMemcpyDeviceToHost));
+    return PGSGD_OK;
+}
+
 // A session whose drains run beside its launches (pgsgd_session::async_drain): *on = whether this one does, *drain_ms = far_drain_kernel's
 // time on the DRAIN stream (HIP events; finished drains only — synchronise first for all of them): NOT on the launch stream's critical
 // path.  What the launch stream pays for the far pulls (far_combine_kernel in front of a launch) is the drain_ms of pgsgd_session_aux_time.
@@ -2573,7 +2650,12 @@ extern "C" int pgsgd_sort_params_defaults(const pgsgd_graph_view* g, pgsgd_param
     for (uint64_t i = 0; i < g->n_paths; ++i) {
         const uint64_t b = g->path_first[i], e = g->path_first[i + 1];
         max_steps = std::max(max_steps, e - b);
-        if (e > b) max_bp = std::max(max_bp, g->step_pos[e - 1] + g->node_len[g->step_handle[e - 1] >> 1]);
+        if (e > b && g->step_pos) max_bp = std::max(max_bp, g->step_pos[e - 1] + g->node_len[g->step_handle[e - 1] >> 1]);
+        if (e > b && !g->step_pos) {   // (a view without step positions: the path's length by a walk)
+            uint64_t bp = 0;
+            for (uint64_t k = b; k < e; ++k) bp += g->node_len[g->step_handle[k] >> 1];
+            max_bp = std::max(max_bp, bp);
+        }
     }
     p->iter_max = 100;                                                    // :313
     p->min_term_updates = (uint64_t)(1.0 * (double)g->n_steps);           // :383

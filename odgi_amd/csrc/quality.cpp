@@ -31,10 +31,11 @@ extern "C" int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, con
     rng.seed(seed);
     double acc = 0.0;
     uint64_t cnt = 0;
+    const pgsgd::StepIndex ix(g);
     for (uint64_t n = 0; n < n_pairs; ++n) {
         // the SGD sampler in its non-cooling mode: half Zipf partners, half uniform partners
         const uint64_t k = pgsgd::uniform_below(rng, g->n_steps);
-        const uint64_t p = g->step_path[k];
+        const uint64_t p = ix.path[k];
         const uint64_t pstart = g->path_first[p], c = g->path_first[p + 1] - pstart;
         if (c == 1) continue;
         const uint64_t s_rank = k - pstart;
@@ -50,7 +51,7 @@ extern "C" int pgsgd_path_stress(const pgsgd_graph_view* g, const double* X, con
         }
         const uint64_t kb = pstart + b_rank;
         const uint32_t ha = g->step_handle[k], hb = g->step_handle[kb];
-        uint64_t pa = g->step_pos[k], pb = g->step_pos[kb];
+        uint64_t pa = ix.pos[k], pb = ix.pos[kb];
         uint32_t oa = ha & 1u, ob = hb & 1u;
         if (pgsgd::coin(rng)) { pa += g->node_len[ha >> 1]; oa ^= 1u; }
         if (pgsgd::coin(rng)) { pb += g->node_len[hb >> 1]; ob ^= 1u; }
@@ -97,6 +98,7 @@ extern "C" int pgsgd_path_stress_near(const pgsgd_graph_view* g, const double* X
     std::vector<double> t_zero(T, 0.0);
     for (uint32_t t = 0; t < T; ++t) { if (hist_step) t_hs[t].assign(mod_step, 0.0); if (hist_rank) t_hr[t].assign(mod_rank, 0.0); }
     const double inv_steps = 1.0 / (double)g->n_steps;
+    const pgsgd::StepIndex ix(g);
     auto work = [&](uint32_t t) {
         for (uint64_t p = 0; p < g->n_paths; ++p) {
             const uint64_t b = g->path_first[p], c = g->path_first[p + 1] - b;
@@ -105,13 +107,13 @@ extern "C" int pgsgd_path_stress_near(const pgsgd_graph_view* g, const double* X
             for (uint64_t s = lo; s < hi; ++s) {
                 const uint64_t k = b + s;
                 const uint32_t ha = g->step_handle[k];
-                const double la = (double)g->node_len[ha >> 1], pa0 = (double)g->step_pos[k];
+                const double la = (double)g->node_len[ha >> 1], pa0 = (double)ix.pos[k];
                 // k as the first step, jumping forward: direction coin 1/2, or certain at the path's first step
                 const double fwd_a = (s == 0 ? 1.0 : s == c - 1 ? 0.0 : 0.5) / H[std::min<uint64_t>(max_steps, c - s - 1)];
                 for (uint32_t z = 1; z <= zmax && s + z < c; ++z) {
                     const uint64_t kb = k + z, sb = s + z;
                     const uint32_t hb = g->step_handle[kb];
-                    const double lb = (double)g->node_len[hb >> 1], pb0 = (double)g->step_pos[kb];
+                    const double lb = (double)g->node_len[hb >> 1], pb0 = (double)ix.pos[kb];
                     const double back_b = (sb == c - 1 ? 1.0 : 0.5) / H[std::min<uint64_t>(max_steps, sb)];   // kb as the first step, jumping back
                     const double w = inv_steps * 0.5 * zw[z] * (fwd_a + back_b) * 0.25;
                     for (uint32_t f = 0; f < 4; ++f) {
@@ -259,9 +261,10 @@ extern "C" int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uin
     rng.seed(seed);
     double acc = 0.0;
     uint64_t cnt = 0;
+    const pgsgd::StepIndex ix(g);
     for (uint64_t n = 0; n < n_pairs; ++n) {
         const uint64_t k = pgsgd::uniform_below(rng, g->n_steps);
-        const uint64_t p = g->step_path[k];
+        const uint64_t p = ix.path[k];
         const uint64_t pstart = g->path_first[p], c = g->path_first[p + 1] - pstart;
         if (c == 1) continue;
         const uint64_t s_rank = k - pstart;
@@ -276,7 +279,7 @@ extern "C" int pgsgd_sort_stress(const pgsgd_graph_view* g, const double* X, uin
             b_rank = pgsgd::uniform_below(rng, c);
         }
         const uint64_t kb = pstart + b_rank;
-        const double d = std::fabs((double)g->step_pos[k] - (double)g->step_pos[kb]);
+        const double d = std::fabs((double)ix.pos[k] - (double)ix.pos[kb]);
         if (d == 0) continue;
         const double e = (std::fabs(X[g->step_handle[k] >> 1] - X[g->step_handle[kb] >> 1]) - d) / d;
         acc += e * e;

@@ -54,6 +54,26 @@ class Graph:
         return g
 
     @classmethod
+    def load_lean(cls, path, threads=1):
+        """Graph.load without step_path / step_pos (PGSGD_LOAD_NO_STEP_INDEX): the session builds the positions on the device."""
+        g = cls()
+        h = C.c_void_p()
+        check(lib.pgsgd_graph_load_flags(str(path).encode(), int(threads), 1, C.byref(h)), f"load_lean({path})")
+        g._adopt(h)
+        return g
+
+    def drop_step_index(self):
+        """Free step_path and step_pos (they follow from path_first, step_handle and node_len); the view carries NULL for them:
+        sessions upload 4 bytes per step instead of 12 and build the positions on the device, host metrics walk the paths."""
+        if self._handle:
+            check(lib.pgsgd_graph_drop_step_index(self._handle), "drop_step_index")
+            check(lib.pgsgd_graph_get_view(self._handle, C.byref(self.view)), "get_view")
+        else:
+            self.view.step_path = None
+            self.view.step_pos = None
+        return self
+
+    @classmethod
     def synthetic(cls, n_nodes, n_paths, seed=42):
         g = cls()
         h = C.c_void_p()
@@ -116,9 +136,9 @@ class Graph:
 
     node_len = property(lambda s: s._arr(s.view.node_len, s.n_nodes, np.uint32))
     path_first = property(lambda s: s._arr(s.view.path_first, s.n_paths + 1, np.uint64))
-    step_path = property(lambda s: s._arr(s.view.step_path, s.n_steps, np.uint32))
+    step_path = property(lambda s: s._arr(s.view.step_path, s.n_steps, np.uint32) if s.view.step_path else None)
     step_handle = property(lambda s: s._arr(s.view.step_handle, s.n_steps, np.uint32))
-    step_pos = property(lambda s: s._arr(s.view.step_pos, s.n_steps, np.uint64))
+    step_pos = property(lambda s: s._arr(s.view.step_pos, s.n_steps, np.uint64) if s.view.step_pos else None)
 
     def path_step_counts(self):
         return np.diff(self.path_first.astype(np.int64))

@@ -305,6 +305,14 @@ class LayoutSession:
         check(lib.pgsgd_session_tile_conflicts(self._h, C.byref(a), C.byref(b)), "tile_conflicts")
         return a.value, b.value
 
+    def step_records(self, first=0, count=None):
+        """The session's step records [first, first + count) as a (count, 4) uint32 array {handle, node length, position low,
+        position high} — built from the view's positions, or on the device when the view carries none (parity hook)."""
+        count = self.graph.n_steps - first if count is None else count
+        out = np.zeros((count, 4), dtype=np.uint32)
+        check(lib.pgsgd_session_read_step_records(self._h, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_uint32))), "step_records")
+        return out
+
     def drain_beside(self):
         """(on, ms): whether the session sums its launches' far pulls on a second stream beside the next launch (schedules of
         30 iterations and more, unsharded; PGSGD_FLAG_SYNC_DRAIN: never), and far_drain_kernel's time on that stream so far."""

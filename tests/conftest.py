@@ -53,6 +53,7 @@ GPU_ORDER = [
     (6, "test_fixed_point_frame"),
     (7, "test_tile_kernel_fast_math"),
     (8, "test_single_step_and_ragged_paths"),
+    (8, "test_step_positions_built_on_the_device"),
     (30, "test_two_pass_iterations_of_small_lane_bound_graphs"),   # bit-exact parts + a GPU-vs-GPU band
     # --- deterministic properties: accounting, checksums, conservation, kernel plans (BASELINE configs 4 and 5 by size)
     (20, "test_synthetic_million_node_properties"),

@@ -591,6 +591,47 @@ def test_synthetic_million_node_properties(oa, orc):
         eng.close()
 
 
+def test_step_positions_built_on_the_device(oa, monkeypatch):
+    """A view without step_pos / step_path (include/pgsgd.h: both may be NULL): the session uploads the handles alone and builds the
+    positions on the device (a prefix sum over node_len[step_handle >> 1] that starts again at every path, pgsgd_kernels.hpp:
+    step_prefix_kernel; the reference's GPU route flattens its paths on the device too, src/cuda/layout.cu:371-410).  The step records
+    of such a session are, bit for bit, those of a session that was handed the positions — on a graph of ragged paths (some of one
+    step, some empty) and on 7e6 steps — and a sequential run (one workgroup, one lane per tile) gives the same coordinates."""
+    rs = np.random.RandomState(5)
+    n_nodes = 5000
+    node_len = rs.randint(1, 5000, n_nodes).astype(np.uint32)
+    counts = np.r_[rs.randint(0, 3, 40), rs.randint(1, 9000, 25), [0, 1, 0]]
+    first = np.r_[0, np.cumsum(counts)].astype(np.uint64)
+    handles = rs.randint(0, 2 * n_nodes, int(first[-1])).astype(np.uint32)
+    ragged = oa.Graph.from_arrays(node_len, first, handles)
+    for full in (ragged, oa.Graph.synthetic(300_000, 24, seed=7)):
+        lean = oa.Graph.from_arrays(full.node_len, full.path_first, full.step_handle)
+        lean.drop_step_index()
+        assert lean.step_pos is None
+        with oa.LayoutSession(full, _params(oa, full)) as a, oa.LayoutSession(lean, _params(oa, lean)) as b:
+            ra, rb = a.step_records(), b.step_records()
+            assert a.tile_info() == b.tile_info()
+        assert np.array_equal(ra, rb)
+        assert np.array_equal(ra[:, 2].astype(np.uint64) | (ra[:, 3].astype(np.uint64) << np.uint64(32)), full.step_pos) and np.array_equal(ra[:, 0], full.step_handle)
+    for k, v in {"PGSGD_TILE_FORCE": "1", "PGSGD_TILE_REGION": "64", "PGSGD_TILE_BLOCK": "64", "PGSGD_TILE_GRID": "1", "PGSGD_TILE_LANES": "1"}.items():
+        monkeypatch.setenv(k, v)
+    full = oa.Graph.synthetic(3000, 4, seed=3)
+    lean = oa.Graph.synthetic(3000, 4, seed=3).drop_step_index()
+    X0, Y0 = oa.initial_layout(full, "d", seed=5)
+    out = []
+    for gr in (full, lean):
+        p = _params(oa, gr, iter_max=4, min_term_updates=2 * gr.n_steps)
+        etas = oa.path_linear_sgd_layout_schedule(p)
+        with oa.LayoutSession(gr, p) as s:
+            assert s.tile_info()["tiled"]
+            s.upload(X0, Y0)
+            for it in range(p.iter_max):
+                s.iteration(etas[it], it >= p.first_cooling_iteration(), p.min_term_updates)
+                s.sync()
+            out.append(s.download_words())
+    assert np.array_equal(out[0], out[1])
+
+
 # the tile kernel's own transient at config 4, as measured in round 3 (profiles/r03/pytest_gpu_*.log): mean of three seeds
 TILE_CURVE = {5: 3270.0, 10: 12.3, 15: 9.39}   # round 6 (far pulls ramp 0.2 .. 1.0; rounds 3-5, 0.1 .. 0.5: 9130 / 8.59 / 6.55)
 

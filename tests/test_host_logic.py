@@ -607,3 +607,46 @@ def test_tile_windows_cut_into_parts_keep_order_and_dependencies(oa):
                 want[b:e] += 1
             assert np.array_equal(covered, want)
     assert lib.pgsgd_tile_split_items(None, None, None, 0, 0, 2, None, None, None, None, 0) < 0
+
+
+def test_views_without_step_positions_and_the_exact_evaluator(oa, orc, tmp_path):
+    """step_path and step_pos of a view may be NULL (include/pgsgd.h): both follow from path_first, step_handle and node_len.  A graph
+    loaded without them (PGSGD_LOAD_NO_STEP_INDEX, what `odgi layout` does) or stripped of them gives the same defaults, the same
+    node order by path position and the same quality figures as the full view; and the product's exact near-pair evaluator
+    (pgsgd_path_stress_near: unordered pairs) equals the oracle's (orc_path_stress_near: the sampler's draws) — two formulations of
+    one sum — on layouts of two graphs.  Host only."""
+    import ctypes as C
+    from odgi_amd import _lib
+    gfa = os.path.join(GOLDEN, "DRB1-3123.gfa")
+    g, lean = oa.Graph.from_gfa(gfa, threads=3), oa.Graph.load_lean(gfa, threads=3)
+    assert lean.step_pos is None and lean.step_path is None and g.step_pos is not None
+    for f in ("node_len", "path_first", "step_handle"):
+        assert np.array_equal(getattr(g, f), getattr(lean, f)), f
+    stripped = oa.Graph.synthetic(20_000, 6, seed=9)
+    full = oa.Graph.synthetic(20_000, 6, seed=9)
+    stripped.drop_step_index()
+    assert stripped.step_pos is None and stripped.step_path is None
+    for a, b in ((g, lean), (full, stripped)):
+        pa, pb = oa.LayoutParams.defaults(a), oa.LayoutParams.defaults(b)
+        assert (pa.iter_max, pa.min_term_updates, pa.space, pa.eta_max) == (pb.iter_max, pb.min_term_updates, pb.space, pb.eta_max)
+        X0, Y0 = oa.initial_layout(a, "d", seed=4)
+        rs = np.random.RandomState(2)
+        X, Y = X0.astype(np.float64) + 3 * rs.randn(len(X0)), Y0.astype(np.float64) + 3 * rs.randn(len(X0))
+        assert oa.path_stress(a, X, Y, 200_000, seed=3) == oa.path_stress(b, X, Y, 200_000, seed=3)
+        assert oa.path_distance(a, X, Y) == oa.path_distance(b, X, Y)
+        na, nb = oa.path_stress_near(a, X, Y, zmax=4, threads=2, mod_step=7, mod_rank=5), oa.path_stress_near(b, X, Y, zmax=4, threads=3)
+        assert np.allclose(na["num"], nb["num"], rtol=1e-12) and abs(na["near"] - nb["near"]) <= 1e-12 * na["near"]
+        assert np.isclose(na["hist_step"].sum(), na["num"].sum(), rtol=1e-12) and np.isclose(na["hist_rank"].sum(), na["num"].sum(), rtol=1e-12)
+        no = orc.path_stress_near(orc.Graph.from_product(a), X, Y, zmax=4, threads=2)
+        assert np.allclose(na["num"], no["num"], rtol=1e-11) and np.allclose(na["mass"], no["mass"], rtol=1e-11) and abs(na["zero_mass"] - no["zero_mass"]) < 1e-13
+        # and it is a part of what the sampled evaluator estimates, growing with the reach (on a CONVERGED layout four steps of
+        # reach carry 99.9 % of the figure; on this perturbed initial layout the pairs further apart still carry a share)
+        n64 = oa.path_stress_near(a, X, Y, zmax=64, threads=2)["near"]
+        assert na["near"] < n64 < 1.15 * oa.path_stress(a, X, Y, 4_000_000, seed=5)
+        order = []
+        for gr in (a, b):
+            new = np.zeros(gr.n_nodes, dtype=np.uint32)
+            d0, d1 = C.c_double(), C.c_double()
+            assert _lib.lib.pgsgd_graph_path_order(C.byref(gr.view), new.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(d0), C.byref(d1)) == 0
+            order.append((new, d0.value, d1.value))
+        assert np.array_equal(order[0][0], order[1][0]) and order[0][1:] == order[1][1:]
