@@ -216,9 +216,9 @@ def main():
     rf["shader_clock_mhz"] = clock_mhz
     # HBM traffic per launch: NOT measured in this run — the memory-side request counters of the L2 (TCC_EA0_RDREQ by size
     # class, TCC_EA0_WRREQ) from the committed rocprofv3 PMC passes of this same command, with the request sizes calibrated on
-    # kernels of known traffic (tools/profile_cal.sh -> profiles/r05/pmc_traffic_r05.json, pmc_calibration*.json), labelled so —
+    # kernels of known traffic (tools/profile_cal.sh -> profiles/r06/pmc_traffic_r06.json, pmc_calibration*.json), labelled so —
     # and labelled STALE when the library's sources have changed since the passes were taken (library_source_id)
-    prof = os.path.join(ROOT, "profiles", "r05", "pmc_traffic_r05.json")
+    prof = os.path.join(ROOT, "profiles", "r06", "pmc_traffic_r06.json")
     same_workload = world == 1 and args.nodes == 1_000_000 and args.paths == 50 and args.streams == 0 and not args.no_tiles and not args.flags
     if os.path.exists(prof) and same_workload:
         try:

@@ -28,8 +28,14 @@ extern "C" {
  * changed at each version).  5: pgsgd_stats grew by `relabeled` and `tiled` (56 -> 64 bytes: a caller built against the
  * older header would have its stack overwritten by the library's memset of the whole struct);
  * pgsgd_session_download_* deliver the far pulls still waiting before they read (pgsgd_session_peek_* read the words as
- * they are); pgsgd_tile_region_for is gone; pgsgd_session_set_shard(.., -1) chooses the exact exchange itself. */
-#define PGSGD_ABI_VERSION 5
+ * they are); pgsgd_tile_region_for is gone; pgsgd_session_set_shard(.., -1) chooses the exact exchange itself.
+ * 6: a tiled session of a schedule of 30 iterations and more delivers the far pulls of its COOLING launches a launch later (their
+ * drain runs on a second stream beside the next launch; PGSGD_FLAG_SYNC_DRAIN: as before) — pgsgd_session_peek_* may then lack
+ * the pulls of the last TWO launches; the far pulls of a launch amount to one projection, not half (tile kernel; final layouts of
+ * short schedules change); pgsgd_graph_view::step_path / step_pos may be NULL.  New entry points (nothing removed):
+ * pgsgd_path_stress_near, pgsgd_session_terms_executed, pgsgd_session_drain_beside, pgsgd_session_read_step_records,
+ * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index. */
+#define PGSGD_ABI_VERSION 6
 int pgsgd_abi_version(void);
 /* sizeof(pgsgd_graph_view), sizeof(pgsgd_params), sizeof(pgsgd_stats) as the LIBRARY was built (any pointer may be NULL) */
 void pgsgd_abi_struct_sizes(size_t* graph_view, size_t* params, size_t* stats);

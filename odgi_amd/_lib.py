@@ -47,7 +47,7 @@ class Stats(C.Structure):
                 ("frame_doublings", u32), ("apply_lanes", u32), ("relabeled", u32), ("tiled", u32)]
 
 
-ABI_VERSION = 5   # include/pgsgd.h: PGSGD_ABI_VERSION this binding was written against
+ABI_VERSION = 6   # include/pgsgd.h: PGSGD_ABI_VERSION this binding was written against
 
 
 def _check_abi():

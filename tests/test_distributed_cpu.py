@@ -258,14 +258,16 @@ def _exact_worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def test_two_rank_exact_exchange_equals_one_rank(tmp_path):
-    """DistributedLayout with an engine sharded by region and the exact exchange, world 2 over gloo: one launch per region
-    colour, one 64-bit integer all-reduce after each, tails decoded (max |Delta| as float bits), nothing exchanged at the
-    end — and both ranks end with exactly the words ONE rank owning everything computes."""
-    world, port = 2, 29617
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_exact_exchange_equals_one_rank(tmp_path, world):
+    """DistributedLayout with an engine sharded by region and the exact exchange, world 2 and world 4 over gloo: one launch per
+    region colour, one 64-bit integer all-reduce after each, tails decoded (max |Delta| as float bits), nothing exchanged at the
+    end — and every rank ends with exactly the words ONE rank owning everything computes."""
+    port = 29617 + world
     mp.spawn(_exact_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    w0, w1 = np.load(tmp_path / "words_0.npy"), np.load(tmp_path / "words_1.npy")
-    assert np.array_equal(w0, w1)
+    w0 = np.load(tmp_path / "words_0.npy")
+    for r in range(1, world):
+        assert np.array_equal(w0, np.load(tmp_path / f"words_{r}.npy")), r
     sys.path.insert(0, ROOT)
     import odgi_amd as oa
     from odgi_amd.distributed import DistributedLayout
@@ -283,6 +285,6 @@ def test_two_rank_exact_exchange_equals_one_rank(tmp_path):
             one.exchange_exact_end(buf, 1)
     assert np.array_equal(w0, one.words)
     # every rank saw every rank's max |Delta| (rank 1's is the larger by construction) and the far-pull counts of all ranks
-    d0, d1 = np.load(tmp_path / "dmax_0.npy"), np.load(tmp_path / "dmax_1.npy")
-    assert np.array_equal(d0, d1) and np.allclose(d0, np.float32(1.125) * etas[: p.iter_max].astype(np.float32), rtol=1e-6)
+    d0, d1 = np.load(tmp_path / "dmax_0.npy"), np.load(tmp_path / f"dmax_{world - 1}.npy")
+    assert np.array_equal(d0, d1) and np.allclose(d0, np.float32(1.0 + 0.125 * (world - 1)) * etas[: p.iter_max].astype(np.float32), rtol=1e-6)
     assert np.array_equal(np.load(tmp_path / "far_0.npy"), np.array(one.far_seen))
