@@ -244,6 +244,9 @@ def main():
     if args.stress and rank == 0:
         X, Y = eng.result()
         out["stress_sampled"] = oa.path_stress(g, X, Y, 2_000_000)
+        # the near pairs' exact contribution to that figure's expectation (no sampling error: two layouts of equal quality differ by
+        # up to +-25 % in the sampled figure at 1e7 nodes, profiles/r06/NOTES.md section 1)
+        out["stress_near_exact"] = oa.path_stress_near(g, np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64), zmax=4)["near"]
         out["stress_initial"] = oa.path_stress(g, X0, Y0, 2_000_000)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # CPU baseline: the oracle's Hogwild restatement of path_sgd_layout.cpp:165-377 (fp64, 1 ms
