@@ -253,6 +253,7 @@ def main():
         # controller), reference Release flags minus -march=native, on a time-bounded sample of the
         # same workload (same graph, same parameters, same initial layout).
         from oracle import oracle as orc
+        cpu_flags = orc.build_fast_native()   # the reference's Release flags incl. -march=native, compiled on the host that is timed
         og = orc.Graph.from_product(g)
         cores = os.cpu_count() or 1
         # the loop's shared coordinates are seq-cst atomic<double>s (path_sgd_layout.cpp:316-363): more threads than one
@@ -280,7 +281,7 @@ def main():
             "thread_scan": [{"threads": t, "value": r} for r, t, _ in scan], "host_threads": cores,
             "single_thread": {"value": st1["terms"] / st1["seconds"] if st1["seconds"] > 0 else 0.0, "cores": 1,
                               "sample": f"{st1['terms']} terms in {st1['seconds']:.1f} s, same loop, one thread (-t 1)"},
-            "cpu_model": cpu_model,
+            "cpu_model": cpu_model, "build_flags": cpu_flags,
         }
     eng.close()
     if dist.is_initialized():

@@ -104,8 +104,27 @@ def _load(name):
 _libs = {}
 
 
+FAST_FLAGS = "-Ofast -fPIC -std=c11 -funroll-all-loops -pipe"   # oracle/Makefile FAST: the reference's Release flags (CMakeLists.txt:85) minus -march=native
+_fast_name = ["liboracle_fast.so"]
+
+
+def build_fast_native():
+    """Compile the timed build of the oracle ON THIS HOST with the reference's full Release flags, -march=native included
+    (oracle/_build/liboracle_fast_native.so), and make it what lib(fast=True) loads.  bench.py's cpu_baseline calls this on the box
+    it times on; returns the flags used (the portable build's when gcc is missing or fails)."""
+    out = os.path.join(_BUILD, "liboracle_fast_native.so")
+    try:
+        os.makedirs(_BUILD, exist_ok=True)
+        subprocess.check_call(["gcc"] + FAST_FLAGS.split() + ["-march=native", "-shared", "-o", out, os.path.join(_HERE, "pgsgd_oracle.c"), "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _fast_name[0] = "liboracle_fast_native.so"
+        return FAST_FLAGS + " -march=native (built on this host)"
+    except Exception:  # noqa: BLE001
+        return FAST_FLAGS + " (portable build: no -march=native)"
+
+
 def lib(fast=False):
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+    name = _fast_name[0] if fast else "liboracle.so"
     if name not in _libs:
         _libs[name] = _load(name)
     return _libs[name]
