@@ -189,6 +189,7 @@ static int pick_device(int requested, int* out) {
     return PGSGD_OK;
 }
 
+static int collect_drain_events(pgsgd_session* s);
 static int collect_events(pgsgd_session* s) {
     for (auto& ev : s->pending_events) {
         float ms = 0;
@@ -210,7 +211,11 @@ static int collect_events(pgsgd_session* s) {
         s->free_events.push_back(ev);
     }
     s->pending_events.clear();
-    // drains beside a launch run on their own stream and may still be running when the launch stream is idle: take the finished ones
+    return collect_drain_events(s);
+}
+
+// drains beside a launch run on their own stream and may still be running when the launch stream is idle: take the finished ones
+static int collect_drain_events(pgsgd_session* s) {
     size_t kept = 0;
     for (auto& de : s->pending_drain_events) {
         if (hipEventQuery(de.b) == hipSuccess) {
@@ -2333,7 +2338,7 @@ extern "C" int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* dra
     if (!s) return PGSGD_E_INVALID;
     if (on) *on = s->async_drain && s->drain_stream ? 1 : 0;
     if (drain_ms) {
-        if (s->drain_stream) { HIP_TRY(hipStreamSynchronize(s->drain_stream)); (void)collect_events(s); }
+        if (s->drain_stream) { HIP_TRY(hipStreamSynchronize(s->drain_stream)); (void)collect_drain_events(s); }
         *drain_ms = s->drain_beside_ms;
     }
     return PGSGD_OK;
