@@ -29,8 +29,8 @@ extern "C" {
  * older header would have its stack overwritten by the library's memset of the whole struct);
  * pgsgd_session_download_* deliver the far pulls still waiting before they read (pgsgd_session_peek_* read the words as
  * they are); pgsgd_tile_region_for is gone; pgsgd_session_set_shard(.., -1) chooses the exact exchange itself.
- * 6: a tiled session of a schedule of 30 iterations and more delivers the far pulls of its COOLING launches a launch later (their
- * drain runs on a second stream beside the next launch; PGSGD_FLAG_SYNC_DRAIN: as before) — pgsgd_session_peek_* may then lack
+ * 6: a tiled session of a schedule of 30 iterations and more delivers the far pulls of its launches a launch later from the sixth
+ * iteration on (their drain runs on a second stream beside the next launch; PGSGD_FLAG_SYNC_DRAIN: as before) — pgsgd_session_peek_* may then lack
  * the pulls of the last TWO launches; the far pulls of a launch amount to one projection, not half (tile kernel; final layouts of
  * short schedules change); pgsgd_graph_view::step_path / step_pos may be NULL.  New entry points (nothing removed):
  * pgsgd_path_stress_near, pgsgd_session_terms_executed, pgsgd_session_drain_beside, pgsgd_session_read_step_records,
@@ -128,7 +128,7 @@ typedef struct pgsgd_graph_view {
                                            /* (pgsgd_graph_path_order); the coordinates come back under the caller's ranks.  Not with snapshots (-u)        */
 #define PGSGD_FLAG_SYNC_DRAIN    0x20000u /* tile kernel: deliver every launch's far pulls in front of the very next launch.  By default a session of a  */
                                          /* schedule as long as the reference's (iter_max >= 30) sums them on a second stream BESIDE the next     */
-                                         /* launch and delivers them a launch later (+3.5 % throughput, same layout).               */
+                                         /* launch and delivers them a launch later, from the sixth iteration on (+2.7 %, same layout). */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 

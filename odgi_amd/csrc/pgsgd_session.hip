@@ -118,11 +118,15 @@ struct pgsgd_session {
     pgsgd::Outbox ob1{};                  // colour 1's outbox (colour 0's is `ob`): own pool, fill, next, spill
     uint64_t* d_pend[2] = {nullptr, nullptr};   // [ob_slices][2N] the sums of colour c's last drain
     bool pend_waiting[2] = {false, false};      // ... not in the coordinates yet
-    // Before cooling the far pulls are what forms the layout's global structure: those of a WARM launch reach the coordinates right
-    // before the very next launch, whatever its colour — the launch stream waits for their drain, nothing runs beside it.  (All
-    // launches late: the transient at config 4 is 65 instead of 12 after iteration 10 and a graph with window-less tiles, whose
-    // every move is a message, ends at 2.2 instead of 0.2: profiles/r06/pytest_gpu_call9.log.)
+    // While the layout's global structure is still forming — the five iterations of the far pulls' ramp (kFarGentleIterations) — a
+    // launch's pulls reach the coordinates right before the very next launch, whatever its colour: the launch stream waits for their
+    // drain, nothing runs beside it.  Measured at config 4 (exact figure of the final layout / stress after iterations 10, 12, 14 /
+    // terms per s; profiles/r06/drain_beside_from_1e6.jsonl): never late 0.20548 / 91 86 90 / 7.09e10; late from iteration 15 (the
+    // cooling launches) 0.20528 / 91 86 90 / 7.13e10; from 10: 0.20531 / 91 165 169 / 7.21e10; **from 5: 0.20545 / 358 185 171 / 7.32e10**;
+    // from 1: 0.20583 / 3037 545 196; every launch: the transient's damage reaches the final layout of graphs with window-less tiles
+    // (2.2 instead of 0.2).  The reference's own stress at those points: 12 740.
     bool pulls_urgent[2] = {false, false};
+    uint64_t async_from = 0;                    // experiment knob PGSGD_ASYNC_FROM
     bool queues_dirty = false;                  // a tile launch has run since the work queues and far-pull counters were last zeroed
     int pend_order = 0;                         // the colour whose sums have waited longer (a flush delivers it first)
     hipStream_t drain_stream = nullptr;
@@ -1237,6 +1241,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
     // launch it was meant to run beside and delays the next (measured at 1e7 nodes: 4.92e10 against 5.11e10 terms/s, stress +0.7 %).
     s->async_drain = s->tiled && p->iter_max >= 30 && !(p->flags & PGSGD_FLAG_SYNC_DRAIN) && s->fmt == pgsgd::kFmtQ32 && s->ob.shift == s->ob_part_shift
                      && s->n_nonlocal_tiles == 0;   // (a window-less tile's every move is a message: none of them may wait a launch)
+    if (const char* e = pgsgd::debug_env("PGSGD_ASYNC_FROM")) s->async_from = (uint64_t)std::max(0L, atol(e));
     if (const char* e = pgsgd::debug_env("PGSGD_ASYNC_DRAIN")) s->async_drain = s->tiled && s->fmt == pgsgd::kFmtQ32 && atoi(e) != 0;   // experiment / parity knob
     if (s->tiled && p->min_term_updates) {  // the message pool for iterations of the default length (grown later if a call asks for more)
         rc = ensure_outbox(s, p->min_term_updates, 1);
@@ -2082,7 +2087,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             if (async) {
                 rc = enqueue_drain(s, colour);   // (drain stream: beside whatever this stream does next)
                 if (rc) return rc;
-                s->pulls_urgent[colour] = !a.cooling;
+                s->pulls_urgent[colour] = s->relax_iter <= (s->async_from ? s->async_from : pgsgd::kFarGentleIterations);   // (experiment knob PGSGD_ASYNC_FROM=k: late from iteration k on, 0-based)
             } else {
                 s->ob_pending = true;
             }

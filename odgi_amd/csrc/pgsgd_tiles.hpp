@@ -492,8 +492,9 @@ constexpr int kFarTwoSided = 0, kFarExclusive = 2;
 // error (pgsgd_path_stress_near; profiles/r06/NOTES.md section 1) at 1e7 nodes: on the default schedule the ramp and its ceiling
 // change nothing (tile kernel +1.2 % over the per-lane kernel with either), on a SHORT schedule (`-x 15 -G 2`) the slow ramp
 // to 0.5 costs +7.3 %, this one +0.4 % (constant 0.75 / 1.0: -1.4 / -0.6 %; ramp 0.1.. to 1.0: +5.2 %; 0.25: +18 %).
+constexpr uint64_t kFarGentleIterations = 5;   // the iterations of the ramp — and those whose far pulls always arrive before the very next launch (pgsgd_session.hip: pulls_urgent)
 __host__ __device__ inline float tile_far_relax(uint64_t iteration /* 0-based */) {
-    return iteration < 2 ? 0.2f : iteration < 5 ? 0.2f * (float)iteration : 1.0f;   // 0.2 0.2 0.4 0.6 0.8 1.0 ...
+    return iteration < 2 ? 0.2f : iteration < kFarGentleIterations ? 0.2f * (float)iteration : 1.0f;   // 0.2 0.2 0.4 0.6 0.8 1.0 ...
 }
 
 // What the tile kernel's sampler needs, trimmed: step indices and jump lengths fit 32 bits here (a tiled session has

@@ -1317,7 +1317,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
  *   ORC_TILE_NO_PAIRS       every lane keeps its own uniform partner (rounds 2 and 3; PGSGD_FLAG_NO_PARTNER_PAIRS)
  *   ORC_TILE_DRAIN_BESIDE   every region colour has its own outbox and a launch's far pulls are delivered right before the SAME colour's
- *                           next launch — a launch later than by default — when theirs was a COOLING launch (a warm launch's arrive before
+ *                           next launch — a launch later than by default — from the sixth iteration on (the first five's arrive before
  *                           the very next launch, as by default): what a session does whose drain runs on a second stream beside the
  *                           other colour's launch (pgsgd_session::async_drain: schedules of 30 iterations and more)
  *   ORC_TILE_RELAX_R5       the far pulls' relaxation of rounds 3-5: 0.1 0.1 0.2 0.3 0.4 then half a projection (round 6: 0.2 ... 0.8 then one)
@@ -1478,7 +1478,7 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                     for (uint32_t i = 0; i < win_words; ++i)
                         if (wbase + i < n_ends) W[wbase + i] = win[i];
             }
-            urgent[colour] = !cooling;
+            urgent[colour] = iter < 5;   /* (pgsgd_tiles.hpp: kFarGentleIterations) */
             if (drain_first) pending[beside ? colour : 0] = 1;
             else for (uint64_t i = 0; i < n_ends; ++i) { W[i] += outbox[i]; outbox[i] = 0; }
         }

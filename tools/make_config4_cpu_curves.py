@@ -55,6 +55,8 @@ def main():
         rec = {"init_seed": init_seed, "stress_initial": orc.path_stress_sampled(og, X0, Y0, EVAL_PAIRS, EVAL_SEED),
                "stress_at": curve, "stress_final": orc.path_stress_sampled(og, X, Y, EVAL_PAIRS, EVAL_SEED),
                "terms": st["terms"], "iterations": st["iterations"], "seconds": st["seconds"], "wall": time.time() - t}
+        ne = orc.path_stress_near(og, X, Y, zmax=4, threads=args.threads)   # the final layout's exact near-pair figure (round 6)
+        rec["near_exact"] = {"near": ne["near"], "by_z": ne["num"].sum(axis=(1, 2)).tolist(), "zero_mass": ne["zero_mass"], "zmax": 4}
         print(json.dumps(rec), flush=True)
         out["runs"].append(rec)
         with open(args.out, "w") as f:

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--runs", type=int, default=9)
     ap.add_argument("--only", default="")
     ap.add_argument("--threads-large", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--exact", default="", help="entries whose key contains this get runs scored with the exact near-pair evaluator (entry['near_exact'])")
     args = ap.parse_args()
     import numpy as np
     import odgi_amd as oa
@@ -100,6 +101,30 @@ def main():
             with open(cr.PATH + ".tmp", "w") as f:
                 json.dump(db, f, indent=1)
             os.replace(cr.PATH + ".tmp", cr.PATH)
+    # --exact SUBSTRING (round 6): for the matching 2D entries, `runs` MORE runs scored with the evaluator that has no sampling error
+    # (orc.path_stress_near, zmax 4) -> entry["near_exact"]; the sampled distributions above are left as they are
+    if args.exact:
+        for name, gf, pf, init, seeds, threads, fast in configs:
+            if name not in graphs:
+                g = gf()
+                graphs[name] = (g, orc.Graph.from_product(g))
+            g, og = graphs[name]
+            p = pf(g)
+            k = cr.key(name, p, init)
+            e = db["entries"].get(k)
+            if args.exact not in k or not e or e.get("near_exact", {}).get("n", 0) >= args.runs:
+                continue
+            vals = list(e.get("near_exact", {}).get("runs", []))
+            while len(vals) < args.runs:
+                seed = seeds[len(vals) % len(seeds)]
+                X0, Y0 = oa.initial_layout(g, init, seed=seed)
+                Xo, Yo, st = orc.layout_hogwild(og, orc.params_from(p), threads, X0, Y0, fast=fast)
+                vals.append(orc.path_stress_near(og, Xo, Yo, zmax=4, threads=threads)["near"])
+                print(f"{k}: exact run {len(vals)} seed {seed} near-pair figure {vals[-1]:.5f}", flush=True)
+                e["near_exact"] = cr.summarize(vals)
+                with open(cr.PATH + ".tmp", "w") as f:
+                    json.dump(db, f, indent=1)
+                os.replace(cr.PATH + ".tmp", cr.PATH)
     # 1D PG-SGD (`odgi sort -Y`, path_sgd.cpp): orc.sort_hogwild, scored with orc.sort_stress
     from odgi_amd.sort import sort_params_defaults
     sort_configs = [("1d:" + n, (lambda n=n: (fixture(n), None)), (lambda g: sort_params_defaults(g)), 300_000) for n in ("DRB1-3123", "DRB1-3123_unsorted", "chr6.C4")]
