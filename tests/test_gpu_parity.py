@@ -833,7 +833,7 @@ def _config5_run(oa, g, X0, Y0, flags, iter_max, min_term_updates, sample_at, ch
 
 def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
     """BASELINE config 5 size, the WHOLE 30-iteration schedule (1.4e11 terms): the tile kernel against the per-lane kernel
-    — the reference's rule term by term — from the same initial layout, scored by the evaluator WITHOUT sampling error
+    — the reference's rule term by term — AND the CPU oracle's committed run of the same schedule, from the same initial layout, scored by the evaluator WITHOUT sampling error
     (every pair of steps at most four apart, all end choices, weighted as the sampler draws them: _near_exact): the tile
     kernel's final layout within 3 % of the per-lane kernel's, two-sided.  Measured (profiles/r06/gap_near_exact_1e7_whole.jsonl,
     three sampler seeds): per-lane 0.16170 / 0.16175 / 0.16178, tile 0.16368 / 0.16312 / 0.16305 = +0.8 ... +1.2 %.
@@ -847,6 +847,15 @@ def test_config5_size_whole_schedule_against_the_per_lane_kernel(oa):
     print(f"config 5 size, whole schedule: exact near-pair stress tile {r['tile']['near']:.5f} ({r['tile']['ms']:.0f} ms of kernels), per-lane {r['per_lane']['near']:.5f} "
           f"({r['per_lane']['ms']:.0f} ms), ratio {r['tile']['near'] / r['per_lane']['near']:.4f}; sampled (2e6 pairs, seed 1) after iterations 10/20/30: tile {r['tile']['sampled']}, per-lane {r['per_lane']['sampled']}")
     assert 0.97 * r["per_lane"]["near"] <= r["tile"]["near"] <= 1.03 * r["per_lane"]["near"], (r["tile"]["near"], r["per_lane"]["near"])
+    # ... and against the ORACLE: the CPU restatement's run of the whole default schedule at this size (1.4e11 terms: 2 h 36 min on this
+    # container's 8 cores, rolled once in round 6; tests/golden/config5_cpu_point_whole.json), scored by the oracle's exact evaluator:
+    # 0.16049.  Both kernels within 4 % of it (measured: per-lane +0.8 %, tile +1.6 ... +2.1 %).
+    ref = _cpu_point("config5_cpu_point_whole.json")
+    assert ref["graph"] == {"nodes": g.n_nodes, "paths": g.n_paths, "steps": g.n_steps, "seed": 42} and ref["params"]["iter_max"] == 30
+    assert ref["params"]["min_term_updates"] == r["tile"]["p"].min_term_updates and ref["runs"][0]["init_seed"] == 42
+    c = float(np.mean([run["near_exact"]["near"] for run in ref["runs"]]))
+    print(f"   CPU restatement, same schedule and initial layout: {c:.5f} ({ref['threads']} threads); tile {r['tile']['near'] / c:.4f}x, per-lane {r['per_lane']['near'] / c:.4f}x")
+    assert 0.96 * c <= r["per_lane"]["near"] <= 1.04 * c and 0.96 * c <= r["tile"]["near"] <= 1.04 * c, (r["tile"]["near"], r["per_lane"]["near"], c)
     t, l = r["tile"]["sampled"], r["per_lane"]["sampled"]
     assert 0.75 * l[2] <= t[2] <= 1.3 * l[2], (t, l)     # the sampled evaluator's own scatter on one layout
     assert 0.80 * l[1] <= t[1] <= 1.1 * l[1], (t, l)     # through the cooling transition the tile kernel is ahead (2.0-2.1 against 2.1-2.3)
