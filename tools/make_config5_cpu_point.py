@@ -56,6 +56,8 @@ def main():
             old = json.load(f)
         if old.get("graph") == out["graph"] and old.get("params") == out["params"]:
             out["runs"] = old["runs"]
+            for run in out["runs"]:   # (runs rolled before the thread count was kept per run)
+                run.setdefault("threads", old.get("threads"))
     for r in range(len(out["runs"]), args.runs):
         init_seed = 42 + r
         X0, Y0 = oa.initial_layout(g, "d", seed=init_seed)
@@ -64,7 +66,7 @@ def main():
         rec = {"init_seed": init_seed, "stress_initial": orc.path_stress_sampled(og, X0, Y0, EVAL_PAIRS, EVAL_SEED),
                "stress_at": [orc.path_stress_sampled(og, sx[k], sy[k], EVAL_PAIRS, EVAL_SEED) for k in range(len(SNAP_ITERS))],
                "stress_final": orc.path_stress_sampled(og, X, Y, EVAL_PAIRS, EVAL_SEED),
-               "terms": st["terms"], "iterations": st["iterations"], "seconds": st["seconds"], "wall": time.time() - t}
+               "terms": st["terms"], "iterations": st["iterations"], "seconds": st["seconds"], "wall": time.time() - t, "threads": args.threads}
         ne = orc.path_stress_near(og, X, Y, zmax=4, threads=args.threads)   # no sampling error (oracle/pgsgd_oracle.c: orc_path_stress_near)
         rec["near_exact"] = {"near": ne["near"], "by_z": ne["num"].sum(axis=(1, 2)).tolist(), "zero_mass": ne["zero_mass"], "zmax": 4}
         if args.classes:
