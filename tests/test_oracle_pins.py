@@ -184,8 +184,9 @@ def test_reference_fixture_is_reproduced_two_sided(oa, orc, graphs, ographs):
     `-K` option's default of 0.5) the restatement reproduces the file — stress, `odgi stats -s`, the distribution of
     layout distance over path distance for adjacent steps and for Zipf-sampled pairs, the layout's extent — within the
     bands of tests/refstats.py, from three initial layouts, with the docs' `--threads 2`
-    (docs/rst/tutorials/sort_layout.rst:365).  With the default cooling phase the same restatement is 13 % better,
-    also asserted two-sided."""
+    (docs/rst/tutorials/sort_layout.rst:365; the command the reference keeps for this very file, scripts/GIFs_doc.sh:24, is
+    `odgi layout -i DRB1-3123_unsorted.og -o DRB1-3123_unsorted.og.lay -P --threads 2 -u ...`: the defaults of its day, two
+    threads).  With the default cooling phase the same restatement is 13 % better, also asserted two-sided."""
     import refstats
     g, og = graphs("DRB1-3123_unsorted"), ographs("DRB1-3123_unsorted")
     lay = oa.Layout.load(os.path.join(GOLDEN, "DRB1-3123_unsorted.og.lay"))
