@@ -291,6 +291,9 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
     // wait for a lane that is not running.  The poll sits at the top of the one loop instead: every lane still in it
     // reaches the loop's end before any starts the next pass, and the replacing lane finishes within its pass.)
     bool strayed = false;
+    // (read BEFORE the claim it does not depend on: the two LDS requests then travel together — one round trip of the rings'
+    // protocol less per call, whose cost is its chain of dependent LDS round trips, profiles/r06/NOTES.md section 9)
+    const uint32_t c0 = L.chunk0()[b];
     for (;;) {
         if (strayed && (__hip_atomic_load(L.line() + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
             __builtin_amdgcn_s_sleep(1);  // still being replaced (by a lane of another wave)
@@ -298,21 +301,21 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
         }
         const uint32_t lp = atomicAdd(L.line() + b, 1u);
         const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // first chunk of the group, lines claimed in the group
-        if (used < kObLinesPerGroup && chunk < kObOverflow) return (L.chunk0()[b] + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
+        if (used < kObLinesPerGroup && chunk < kObOverflow) return (c0 + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
         if (chunk == kObOverflow) {  // the bucket's share of the pool is used up (sticky; the count field is put back so that it cannot run over)
             atomicExch(L.line() + b, kObOverflow << kObUsedBits);
             return kObNoLine;
         }
         if (used == kObLinesPerGroup) {  // this lane replaces the full group and takes the new one's first line
             if (chunk != kObNone)
-                for (uint32_t k = 0; k < kObGroup; ++k) TILE_COLD(ta.ob.fill)[L.chunk0()[b] + chunk + k] = kObChunk;
+                for (uint32_t k = 0; k < kObGroup; ++k) TILE_COLD(ta.ob.fill)[c0 + chunk + k] = kObChunk;
             const uint32_t nc = atomicAdd(TILE_COLD(ta.ob.next) + b, kObGroup);
             if (nc + kObGroup > TILE_COLD(ta.ob.cap)[b]) {
                 atomicExch(L.line() + b, kObOverflow << kObUsedBits);
                 return kObNoLine;
             }
             atomicExch(L.line() + b, (nc << kObUsedBits) | 1u);
-            return (L.chunk0()[b] + nc) * kObLinesPerChunk;
+            return (c0 + nc) * kObLinesPerChunk;
         }
         strayed = true;  // the group is being replaced: every lane adds to the word at most once per replacement, so the 10-bit field holds
     }
@@ -330,6 +333,7 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
     // need of it), ordinary buckets with one atomic per lane
     static_assert(kObRings == 2, "the claim below is written for two hot rings");
     uint32_t slot = 0;
+    if (has && !hot) slot = atomicAdd(L.head() + b, 1u);   // (issued before the hot claim below is waited for: the two travel together)
     const uint64_t m0 = __ballot(hot && r == 0), m1 = __ballot(hot && r == 1);
     if (m0 | m1) {  // wave-uniform
         const uint32_t want = lane == 0 ? (uint32_t)__popcll(m0) : (uint32_t)__popcll(m1);
@@ -338,9 +342,8 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
         const uint32_t base0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), base1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
         const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));  // lanes below this one in the mask
         const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-        slot = r == 0 ? base0 + rank0 : base1 + rank1;
+        if (hot) slot = r == 0 ? base0 + rank0 : base1 + rank1;
     }
-    if (has && !hot) slot = atomicAdd(L.head() + b, 1u);
     const uint32_t lines_log2 = hot ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
     const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + ((slot >> kObLineLog2) & ((1u << lines_log2) - 1u));  // staged line of the slot
     const uint32_t round = slot >> (kObLineLog2 + lines_log2);
