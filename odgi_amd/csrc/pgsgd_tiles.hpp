@@ -787,19 +787,63 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         }
         const uint32_t n_item_tiles = wi.tile_end - wi.tile_begin;
         const uint32_t rot = TILE_COLD(ta.tile_rotate) && n_item_tiles ? (uint32_t)(((uint32_t)a.epoch * 0x9e3779b1u + wi.win0) % n_item_tiles) : 0u;
+        // What a tile needs before its first term — its record, its share of the terms, its path's extent, its step records — used to be
+        // fetched when the tile started: three dependent round trips to memory in front of every term loop, 4.0 us (warm) / 2.4 us (cooling)
+        // of a tile's 33 / 26 us with the workgroup's four waves idle (profiles/r06/NOTES.md section 10).  Now lane l of every wave
+        // fetches the numbers of the item's l-th tile when the item starts (64 tiles per batch), a tile reads its own with v_readlane,
+        // and the step records of the NEXT tile are requested when a tile starts.
+        // The same tiles in the same order with the same numbers: nothing about a term changes.
+        const uint32_t wlane = threadIdx.x & 63u;
+        uint32_t tb_t0 = 0, tb_nl = 0, tb_terms = 0, tb_pstart = 0, tb_cnt = 0;   // this lane's tile of the batch
+        auto tile_of = [&](uint32_t k) -> uint32_t { return wi.tile_begin + (k + rot >= n_item_tiles ? k + rot - n_item_tiles : k + rot); };
+        auto load_batch = [&](uint32_t first_k) {
+            const uint32_t k = first_k + wlane;
+            if (k < n_item_tiles) {
+                const uint32_t ti = tile_of(k);
+                const Tile t = TILE_COLD(ta.tiles)[ti];
+                const uint64_t* path_first = TILE_COLD(c.path_first);
+                const uint64_t* term0 = TILE_COLD(ta.term0);
+                tb_t0 = (uint32_t)t.t0;   // (a tiled session has fewer than 2^32 path steps)
+                tb_nl = t.n | ((t.lanes < blockDim.x ? t.lanes : blockDim.x) << 16);
+                tb_terms = (uint32_t)(term0[ti + 1] - term0[ti]);
+                tb_pstart = (uint32_t)path_first[t.path];
+                tb_cnt = (uint32_t)(path_first[t.path + 1] - path_first[t.path]);
+            }
+        };
+        auto runs = [&](uint32_t k) -> bool { return tile_of(k) % TILE_COLD(ta.n_sub) == TILE_COLD(ta.sub); };  // (multi-GPU by tile, sub-steps: block-uniform)
+        uint4 r_pref = make_uint4(0, 0, 0, 0);   // step record threadIdx.x of the tile `pref_k`, requested while the tile before it finished
+        uint32_t pref_k = kNoItem;
         for (uint32_t tk = 0; tk < n_item_tiles; ++tk) {
-            const uint32_t ti = wi.tile_begin + (tk + rot >= n_item_tiles ? tk + rot - n_item_tiles : tk + rot);
-            if (ti % TILE_COLD(ta.n_sub) != TILE_COLD(ta.sub)) continue;  // block-uniform
-            const Tile t = TILE_COLD(ta.tiles)[ti];
+            if ((tk & 63u) == 0) load_batch(tk);
+            const uint32_t ti = tile_of(tk);
+            if (!runs(tk)) continue;
+            const uint32_t bl = tk & 63u;
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tb_t0, (int)bl), nl = (uint32_t)__builtin_amdgcn_readlane((int)tb_nl, (int)bl);
+            struct { uint32_t n; } t;   // (the tile's step count, under the name the stages below use)
+            t.n = nl & 0xffffu;
+            const uint32_t lanes = nl >> 16;
             __syncthreads();  // previous tile's terms are done with trec; window staging is complete
-            for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = TILE_COLD(c.recs)[t.t0 + i];
+            if (pref_k == tk) {
+                if (threadIdx.x < t.n) trec[threadIdx.x] = r_pref;
+                for (uint32_t i = threadIdx.x + blockDim.x; i < t.n; i += blockDim.x) trec[i] = TILE_COLD(c.recs)[(uint64_t)t0 + i];
+            } else {
+                for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = TILE_COLD(c.recs)[(uint64_t)t0 + i];
+            }
             __syncthreads();
-            const uint64_t term_begin = TILE_COLD(ta.term0)[ti], term_end = TILE_COLD(ta.term0)[ti + 1];
-            const uint32_t t0 = (uint32_t)t.t0;
-            const uint64_t* path_first = TILE_COLD(c.path_first);
-            const uint32_t pstart = (uint32_t)path_first[t.path];
-            const uint32_t cnt = (uint32_t)(path_first[t.path + 1] - path_first[t.path]);
-            const uint32_t lanes = t.lanes < blockDim.x ? t.lanes : blockDim.x;
+            {   // the next tile's step records are on their way while this one runs its terms
+                uint32_t nk = tk + 1;
+                while (nk < n_item_tiles && (nk & 63u) != 0 && !runs(nk)) ++nk;
+                pref_k = kNoItem;
+                if (nk < n_item_tiles && (nk & 63u) != 0) {   // (a tile that opens a batch has its numbers fetched first)
+                    pref_k = nk;
+                    const uint32_t nt0 = (uint32_t)__builtin_amdgcn_readlane((int)tb_t0, (int)(nk & 63u));
+                    const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)tb_nl, (int)(nk & 63u)) & 0xffffu;
+                    if (threadIdx.x < nn) r_pref = TILE_COLD(c.recs)[(uint64_t)nt0 + threadIdx.x];
+                }
+            }
+            const uint32_t n_tile_terms = (uint32_t)__builtin_amdgcn_readlane((int)tb_terms, (int)bl);
+            const uint32_t pstart = (uint32_t)__builtin_amdgcn_readlane((int)tb_pstart, (int)bl);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)tb_cnt, (int)bl);
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
             const uint64_t seed_base = TILE_COLD(ta.seed_base);
@@ -813,7 +857,6 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // and cannot wait for a particular load while stores are pending: with a single consumption point per trip the
             // one full wait falls where everything outstanding is a trip old.)  A lane's stream yields its terms' draws in
             // term order.
-            const uint32_t n_tile_terms = (uint32_t)(term_end - term_begin);
             const uint32_t trips = (n_tile_terms + lanes - 1) / lanes;
             // Two sets of stage registers, used alternately: a trip WRITES one set and READS the other, so nothing that
             // is still in flight has to be copied between registers at the end of a trip (a copy is a use: it would wait
@@ -1030,7 +1073,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     const uint64_t w0 = LOCAL ? win[e0 - wbase] : load_word<COORD_LOAD>(c.coords, e0);
                     const uint64_t w1 = LOCAL ? win[(e0 ^ 1u) - wbase] : load_word<COORD_LOAD>(c.coords, e0 ^ 1u);
                     // (plain stores; write-through (sc1) and non-temporal ones measured the same: profiles/r03/bench_variants_call4.txt)
-                    recs2_out[recs2_snap_piece((uint64_t)t.t0 + i)] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+                    recs2_out[recs2_snap_piece((uint64_t)t0 + i)] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                 }
             }
         }
