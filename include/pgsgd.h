@@ -34,7 +34,7 @@ extern "C" {
  * the pulls of the last TWO launches; the far pulls of a launch amount to one projection, not half (tile kernel; final layouts of
  * short schedules change); pgsgd_graph_view::step_path / step_pos may be NULL.  New entry points (nothing removed):
  * pgsgd_path_stress_near, pgsgd_session_terms_executed, pgsgd_session_drain_beside, pgsgd_session_read_step_records,
- * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index. */
+ * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index, pgsgd_session_probe_words. */
 #define PGSGD_ABI_VERSION 6
 int pgsgd_abi_version(void);
 /* sizeof(pgsgd_graph_view), sizeof(pgsgd_params), sizeof(pgsgd_stats) as the LIBRARY was built (any pointer may be NULL) */
@@ -268,6 +268,9 @@ int pgsgd_session_shader_clock(pgsgd_session* s, double* mhz, double* launch_ms)
 /* Debug (PGSGD_DEBUG=1 PGSGD_TILE_TAIL=1): the share of (workgroups x duration) of the last windowed tile launch that its
  * persistent workgroups were alive for; the rest is the launch's tail.  Zeros when the knob is off. */
 int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction, double* launch_ms, uint32_t* workgroups);
+/* Profiling hook: the twelve raw words of the tile kernel's probes (shader clock, conflict counters, tail probe, device-side term
+ * count); with the kernel's profiling instance 5 the phases of a workgroup's time (tools/gpu_tile_phases.py).  Zeros without tiles. */
+int pgsgd_session_probe_words(pgsgd_session* s, uint64_t out[12]);
 /* Tile kernel: terms that went for their window ends' locks so far (conflict resolution on shared node coordinates while
  * the learning rate is in the projection regime), and terms among them that found an end taken and did nothing. */
 int pgsgd_session_tile_conflicts(pgsgd_session* s, uint64_t* locked, uint64_t* lost);

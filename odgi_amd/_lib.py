@@ -133,6 +133,7 @@ SIGNATURES = [
     ("pgsgd_session_terms_executed", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_read_step_records", C.c_int, [C.c_void_p, u64, u64, P(u32)]),
     ("pgsgd_session_drain_beside", C.c_int, [C.c_void_p, P(C.c_int), P(f64)]),
+    ("pgsgd_session_probe_words", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),
     ("pgsgd_session_exchange_mark", C.c_int, [C.c_void_p]),

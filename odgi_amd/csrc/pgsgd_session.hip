@@ -137,6 +137,7 @@ struct pgsgd_session {
     std::vector<pgsgd::Tile> h_tiles;     // host copy of the tile table (parity hooks)
     std::vector<pgsgd::WorkItem> h_items; // host copy of the work items, colour 0 first (parity hooks)
     pgsgd::Tile* d_tiles = nullptr;
+    uint4* d_tile_heads = nullptr;        // TileArgs::tile_heads
     pgsgd::WorkItem* d_items = nullptr;   // colour 0 items, then colour 1 items
     uint32_t n_items[2] = {0, 0};
     // the session's own windows with their tiles cut into tile_split consecutive parts (WorkItem::local: kItemHasNext,
@@ -1127,6 +1128,16 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
                 S_TRY(hipMalloc(&s->d_far, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemset(s->d_far, 0, 4 * sizeof(unsigned long long)));
                 S_TRY(hipMemcpy(s->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(pgsgd::Tile), hipMemcpyHostToDevice));
+                {   // what the kernel reads of a tile before its first term, in one 16-byte load (TileArgs::tile_heads)
+                    std::vector<uint4> heads(std::max<size_t>(1, ht.tiles.size()));
+                    for (size_t i = 0; i < ht.tiles.size(); ++i) {
+                        const pgsgd::Tile& t = ht.tiles[i];
+                        heads[i] = make_uint4((uint32_t)t.t0, (t.n & 0xffffu) | (std::min<uint32_t>(t.lanes, 0xffffu) << 16), (uint32_t)g->path_first[t.path],
+                                              (uint32_t)(g->path_first[t.path + 1] - g->path_first[t.path]));
+                    }
+                    S_TRY(hipMalloc(&s->d_tile_heads, heads.size() * sizeof(uint4)));
+                    S_TRY(hipMemcpy(s->d_tile_heads, heads.data(), heads.size() * sizeof(uint4), hipMemcpyHostToDevice));
+                }
                 S_TRY(hipMemcpy(s->d_items, all.data(), all.size() * sizeof(pgsgd::WorkItem), hipMemcpyHostToDevice));
             }
         }
@@ -1271,6 +1282,7 @@ extern "C" void pgsgd_session_destroy(pgsgd_session* s) {
     if (s->d_rng) (void)hipFree(s->d_rng);
     if (s->d_delta_max) (void)hipFree(s->d_delta_max);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
+    if (s->d_tile_heads) (void)hipFree(s->d_tile_heads);
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_items_split) (void)hipFree(s->d_items_split);
     if (s->d_item_done) (void)hipFree(s->d_item_done);
@@ -1969,6 +1981,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             const uint32_t launches = s->far_launches[colour]++;
             pgsgd::TileArgs ta;
             ta.tiles = s->d_tiles;
+            ta.tile_heads = s->d_tile_heads;
             const bool split = s->tile_split > 1;  // the session's own windows, in parts (build_launch_items)
             const uint32_t* n_items_now = split ? s->n_items_split : s->n_items;
             ta.items = (split ? s->d_items_split : s->d_items) + (colour ? n_items_now[0] : 0);
@@ -2014,7 +2027,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             if (s->tile_tail && s->d_clock) {  // (debug only: two more memsets per launch)
                 ta.tail_probe = s->d_clock + 6;
                 HIP_TRY(hipMemsetAsync(s->d_clock + 6, 0, 4 * sizeof(unsigned long long), s->stream));
-                HIP_TRY(hipMemsetAsync(s->d_clock + 8, 0xff, sizeof(unsigned long long), s->stream));
+                if (PGSGD_TILE_ABL != 5) HIP_TRY(hipMemsetAsync(s->d_clock + 8, 0xff, sizeof(unsigned long long), s->stream));   // (instance 5 sums phases in the four words)
             }
             ta.ob = async && colour ? s->ob1 : s->ob;
             pgsgd::TileSampler ts;
@@ -2308,6 +2321,20 @@ extern "C" int pgsgd_session_tile_tail(pgsgd_session* s, double* alive_fraction,
         if (launch_ms) *launch_ms = span / 1e5;
         if (workgroups) *workgroups = (uint32_t)v[3];
     }
+    return PGSGD_OK;
+}
+
+// Profiling hook: the twelve raw words behind pgsgd_session_shader_clock / _tile_conflicts / _tile_tail / _terms_executed.  With the
+// profiling instance 5 of the tile kernel (make -C odgi_amd/csrc ../lib/libpgsgd_x5.so; PGSGD_DEBUG=1 PGSGD_LIB=libpgsgd_x5.so
+// PGSGD_TILE_TAIL=1) words 4, 5 (cumulative) and 6..9 (the last launch) are the phases of a workgroup's time: tools/gpu_tile_phases.py.
+extern "C" int pgsgd_session_probe_words(pgsgd_session* s, uint64_t out[12]) {
+    pgsgd::clear_error();
+    if (!s || !out) return PGSGD_E_INVALID;
+    for (int i = 0; i < 12; ++i) out[i] = 0;
+    if (!s->d_clock) return PGSGD_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out, s->d_clock, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PGSGD_OK;
 }
 

@@ -138,6 +138,8 @@ constexpr int kTileWaves = kTileBlock / 64;
 
 struct TileArgs {
     const Tile* tiles;
+    const uint4* tile_heads;  // [n_tiles] what the kernel needs of a tile before its first term, one 16-byte load: {first flat step, steps | lanes << 16,
+                              // first flat step of its path, steps of its path} (a tiled session has fewer than 2^32 path steps)
     const WorkItem* items;
     const uint64_t* term0;  // [n_tiles + 1] first term of every tile for this call's term count (tile_terms_kernel)
     // Work items of a launch are pulled from up to kItemQueues runs.  By default there is one run (items by decreasing
@@ -702,6 +704,11 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b() + kTileWaves * kWqCap);
     for (uint32_t i = threadIdx.x; i < tile_lock_words(ta.region); i += blockDim.x) lockw[i] = 0;
     uint32_t n_locked = 0, n_lost = 0;
+    // profiling instance 5 (make libpgsgd_x5.so): where a workgroup's time goes, summed by its thread 0 in 100 MHz ticks —
+    // [0] taking an item .. its first tile, [1] a tile's start .. its term loop, [2] the term loop, [3] the loop's end .. the tile's end
+    // (snapshot pieces), [4] the item's last tile .. the item's end (queue flush, window write-back), [5] everything
+    uint64_t ph[6] = {0, 0, 0, 0, 0, 0};
+    const uint64_t ph_start = ABL == 5 ? wall_clock64() : 0;
     if (TILE_COLD(ta.ob.n_buckets) != ta.ob.n_buckets || TILE_COLD(c.n_nodes) != c.n_nodes) __builtin_trap();  // the argument segment is not laid out as TileKernelArgs says
     if (blockIdx.x == 0 && threadIdx.x == 0 && TILE_COLD(ta.clock_probe)) {  // (workgroups are persistent: workgroup 0 lives as long as the launch has work)
         unsigned long long* probe = TILE_COLD(ta.clock_probe);
@@ -746,20 +753,34 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         my_queue = xcc & (kItemQueues - 1u);
     }
+    // Taking an item used to be a chain of six dependent round trips in front of its first tile — the queue's returning atomic, the
+    // item's record (thread 0, for the window it waits for), the record again (everybody), the window's words, the tiles' numbers, the
+    // first tile's step records: 7.5 us of an item's ~150 (profiles/r06/NOTES.md section 10).  Now thread 0 passes the record on through
+    // LDS, the tiles' numbers travel with the window's words, and the first tile's step records follow as soon as those have arrived.
+    // (Measured and NOT taken: thread 0 taking the next item while the current one starts, so that record, numbers and step records are
+    // there when the item begins — 6 % SLOWER: an item held back by a busy workgroup is what the next part of its window waits for, and
+    // with two items per workgroup in flight the queue's distance between the parts of a window — 1 953 items, 1.5 rounds — is used up.)
+    __shared__ WorkItem s_wi;        // the current item's record
+    auto claim = [&]() -> uint32_t {   // (thread 0) the next item of this workgroup's runs
+        for (; queues_done < kItemQueues; ++queues_done) {  // a run that is used up stays used up: never asked again
+            const uint32_t q = (my_queue + queues_done) & (kItemQueues - 1u);
+            const uint32_t lo = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * q), hi = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * (q + 1u));
+            const uint32_t cand = lo + atomicAdd(TILE_COLD(ta.queue) + q, 1u) * TILE_COLD(ta.shard_world) + TILE_COLD(ta.shard_rank);
+            if (cand < hi) return cand;
+        }
+        return kNoItem;
+    };
+    uint32_t tb_first = kNoItem;   // the lanes hold the numbers of tiles tb_first .. tb_first + 63 of the current item (tb_* below)
+    uint32_t tb_t0 = 0, tb_nl = 0, tb_terms = 0, tb_pstart = 0, tb_cnt = 0;   // this lane's tile of the batch
+    uint4 r_pref = make_uint4(0, 0, 0, 0);   // step record threadIdx.x of tile pref_k of the current item, requested ahead
+    uint32_t pref_k = kNoItem;
     for (;;) {
+        uint64_t ph_t = ABL == 5 ? wall_clock64() : 0;
         if (threadIdx.x == 0) {
-            uint32_t it = kNoItem;
-            for (; queues_done < kItemQueues; ++queues_done) {  // a run that is used up stays used up: never asked again
-                const uint32_t q = (my_queue + queues_done) & (kItemQueues - 1u);
-                const uint32_t lo = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * q), hi = tile_kernarg<uint32_t>((uint32_t)__builtin_offsetof(TileKernelArgs, ta.chunk) + 4u * (q + 1u));
-                const uint32_t cand = lo + atomicAdd(TILE_COLD(ta.queue) + q, 1u) * TILE_COLD(ta.shard_world) + TILE_COLD(ta.shard_rank);
-                if (cand < hi) {
-                    it = cand;
-                    break;
-                }
-            }
+            const uint32_t it = claim();
+            if (it != kNoItem) s_wi = TILE_COLD(ta.items)[it];
             if (LOCAL && it != kNoItem) {  // a later part of a window waits until the part before it has written the window back
-                const uint32_t dep = TILE_COLD(ta.items)[it].local >> kItemDepShift;
+                const uint32_t dep = s_wi.local >> kItemDepShift;
                 if (dep) {
                     const uint32_t* flag = TILE_COLD(ta.item_done) + (dep - 1u);
                     const uint32_t stamp = TILE_COLD(ta.stamp);
@@ -778,47 +799,63 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         __syncthreads();
         const uint32_t item = s_item;
         if (item == kNoItem) break;
-        const WorkItem wi = TILE_COLD(ta.items)[item];
+        const WorkItem wi = s_wi;
         const uint32_t wbase = 2 * wi.win0;  // first coordinate word of the window
-        if (LOCAL) {
-            L.ring_b0 = wbase >> ta.ob.shift;  // the hot rings serve the window's bucket and the next one
-            for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
-                win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(LOCAL ? TILE_COLD(c.coords) : c.coords, wbase + i) : 0;
-        }
         const uint32_t n_item_tiles = wi.tile_end - wi.tile_begin;
         const uint32_t rot = TILE_COLD(ta.tile_rotate) && n_item_tiles ? (uint32_t)(((uint32_t)a.epoch * 0x9e3779b1u + wi.win0) % n_item_tiles) : 0u;
         // What a tile needs before its first term — its record, its share of the terms, its path's extent, its step records — used to be
         // fetched when the tile started: three dependent round trips to memory in front of every term loop, 4.0 us (warm) / 2.4 us (cooling)
         // of a tile's 33 / 26 us with the workgroup's four waves idle (profiles/r06/NOTES.md section 10).  Now lane l of every wave
-        // fetches the numbers of the item's l-th tile when the item starts (64 tiles per batch), a tile reads its own with v_readlane,
-        // and the step records of the NEXT tile are requested when a tile starts.
-        // The same tiles in the same order with the same numbers: nothing about a term changes.
+        // fetches the numbers of the item's l-th tile when the item starts (64 tiles per batch; one 16-byte head and two term counts per
+        // tile, beside the window's words), a tile reads its own with v_readlane, and the step records of the NEXT tile are requested
+        // when a tile starts.  The same tiles in the same order with the same numbers: nothing about a term changes.
         const uint32_t wlane = threadIdx.x & 63u;
-        uint32_t tb_t0 = 0, tb_nl = 0, tb_terms = 0, tb_pstart = 0, tb_cnt = 0;   // this lane's tile of the batch
         auto tile_of = [&](uint32_t k) -> uint32_t { return wi.tile_begin + (k + rot >= n_item_tiles ? k + rot - n_item_tiles : k + rot); };
         auto load_batch = [&](uint32_t first_k) {
             const uint32_t k = first_k + wlane;
             if (k < n_item_tiles) {
                 const uint32_t ti = tile_of(k);
-                const Tile t = TILE_COLD(ta.tiles)[ti];
-                const uint64_t* path_first = TILE_COLD(c.path_first);
+                const uint4 h = TILE_COLD(ta.tile_heads)[ti];
                 const uint64_t* term0 = TILE_COLD(ta.term0);
-                tb_t0 = (uint32_t)t.t0;   // (a tiled session has fewer than 2^32 path steps)
-                tb_nl = t.n | ((t.lanes < blockDim.x ? t.lanes : blockDim.x) << 16);
+                const uint32_t h_lanes = h.y >> 16;
+                tb_t0 = h.x;
+                tb_nl = (h.y & 0xffffu) | ((h_lanes < blockDim.x ? h_lanes : blockDim.x) << 16);
                 tb_terms = (uint32_t)(term0[ti + 1] - term0[ti]);
-                tb_pstart = (uint32_t)path_first[t.path];
-                tb_cnt = (uint32_t)(path_first[t.path + 1] - path_first[t.path]);
+                tb_pstart = h.z;
+                tb_cnt = h.w;
             }
         };
         auto runs = [&](uint32_t k) -> bool { return tile_of(k) % TILE_COLD(ta.n_sub) == TILE_COLD(ta.sub); };  // (multi-GPU by tile, sub-steps: block-uniform)
-        uint4 r_pref = make_uint4(0, 0, 0, 0);   // step record threadIdx.x of the tile `pref_k`, requested while the tile before it finished
-        uint32_t pref_k = kNoItem;
+        tb_first = kNoItem;
+        if (n_item_tiles) {   // the first batch's numbers travel with the window's words
+            tb_first = 0;
+            load_batch(0);
+        }
+        if (LOCAL) {
+            L.ring_b0 = wbase >> ta.ob.shift;  // the hot rings serve the window's bucket and the next one
+            for (uint32_t i = threadIdx.x; i < win_words; i += blockDim.x)
+                win[i] = (uint64_t)wbase + i < n_ends ? load_word<COORD_LOAD>(LOCAL ? TILE_COLD(c.coords) : c.coords, wbase + i) : 0;
+        }
+        pref_k = kNoItem;
+        if (n_item_tiles && runs(0)) {   // ... and the first tile's step records follow them
+            pref_k = 0;
+            const uint32_t nt0 = (uint32_t)__builtin_amdgcn_readlane((int)tb_t0, 0);
+            const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)tb_nl, 0) & 0xffffu;
+            if (threadIdx.x < nn) r_pref = TILE_COLD(c.recs)[(uint64_t)nt0 + threadIdx.x];
+        }
         for (uint32_t tk = 0; tk < n_item_tiles; ++tk) {
-            if ((tk & 63u) == 0) load_batch(tk);
             const uint32_t ti = tile_of(tk);
             if (!runs(tk)) continue;
+            if (tb_first != (tk & ~63u)) {   // the lanes hold another batch of the item's tiles
+                tb_first = tk & ~63u;
+                load_batch(tb_first);
+            }
+            if (ABL == 5) { const uint64_t now = wall_clock64(); ph[tk ? 3 : 0] += now - ph_t; ph_t = now; }
             const uint32_t bl = tk & 63u;
             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tb_t0, (int)bl), nl = (uint32_t)__builtin_amdgcn_readlane((int)tb_nl, (int)bl);
+            const uint32_t n_tile_terms = (uint32_t)__builtin_amdgcn_readlane((int)tb_terms, (int)bl);
+            const uint32_t pstart = (uint32_t)__builtin_amdgcn_readlane((int)tb_pstart, (int)bl);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)tb_cnt, (int)bl);
             struct { uint32_t n; } t;   // (the tile's step count, under the name the stages below use)
             t.n = nl & 0xffffu;
             const uint32_t lanes = nl >> 16;
@@ -830,10 +867,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 for (uint32_t i = threadIdx.x; i < t.n; i += blockDim.x) trec[i] = TILE_COLD(c.recs)[(uint64_t)t0 + i];
             }
             __syncthreads();
+            pref_k = kNoItem;
             {   // the next tile's step records are on their way while this one runs its terms
                 uint32_t nk = tk + 1;
                 while (nk < n_item_tiles && (nk & 63u) != 0 && !runs(nk)) ++nk;
-                pref_k = kNoItem;
                 if (nk < n_item_tiles && (nk & 63u) != 0) {   // (a tile that opens a batch has its numbers fetched first)
                     pref_k = nk;
                     const uint32_t nt0 = (uint32_t)__builtin_amdgcn_readlane((int)tb_t0, (int)(nk & 63u));
@@ -841,9 +878,6 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     if (threadIdx.x < nn) r_pref = TILE_COLD(c.recs)[(uint64_t)nt0 + threadIdx.x];
                 }
             }
-            const uint32_t n_tile_terms = (uint32_t)__builtin_amdgcn_readlane((int)tb_terms, (int)bl);
-            const uint32_t pstart = (uint32_t)__builtin_amdgcn_readlane((int)tb_pstart, (int)bl);
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)tb_cnt, (int)bl);
             const bool worker = threadIdx.x < lanes;
             Xoshiro256Plus rng;
             const uint64_t seed_base = TILE_COLD(ta.seed_base);
@@ -1043,6 +1077,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
                 }
             };
+            if (ABL == 5) { const uint64_t now = wall_clock64(); ph[1] += now - ph_t; ph_t = now; }
             for (uint32_t j = 0; j <= trips + 1; j += 2) {  // (a trip past the end finds nothing valid and does nothing)
                 if (!COOLING && j && !(j & 63u)) coin_cur = Xoshiro256Plus::splitmix64(coin_x);  // the wave's next 64 coins
                 // one trip: everything the previous trip requested is consumed FIRST (one wait, for loads that have been
@@ -1065,6 +1100,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // pieces are never written again (recs2_snap_piece).  Readers in other workgroups may see a record's old or new
             // words (each 8-byte word is written whole); the far pulls the drain delivers after the launch reach the
             // records when the tile runs again — the same staleness the per-iteration pass had (tools/cpu_transient.py).
+            if (ABL == 5) { const uint64_t now = wall_clock64(); ph[2] += now - ph_t; ph_t = now; }
             uint4* const recs2_out = TILE_COLD(ta.recs2_out);
             if (ABL != 2 && recs2_out && (TILE_COLD(ta.snap_every) <= 1u || ((uint32_t)a.epoch + ti) % TILE_COLD(ta.snap_every) == 0u)) {  // (experiment knob PGSGD_TILE_SNAP_EVERY: every k-th iteration, a k-th of the tiles each)
                 __syncthreads();
@@ -1088,17 +1124,18 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                     else TILE_COLD(c.coords)[wbase + i] = win[i];
                     guard |= in_frame_guard(win[i]);
                 }
+            // the hot rings move on with the window: write out what they hold and unbind them (while the window's words travel)
+            outbox_flush_rings(ta.ob, L, L.n_buckets, kObRings);
             // every thread's words are out before the flag goes up: the write-through stores have completed when the counter is
             // back at zero (a release fence at agent scope would also write back the XCD's whole L2: measured, 200 us per item)
-            if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // the hot rings move on with the window: write out what they hold and unbind them
-            outbox_flush_rings(ta.ob, L, L.n_buckets, kObRings);
             if (has_next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(TILE_COLD(ta.item_done) + item, TILE_COLD(ta.stamp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();  // s_item and the window are reused
+        if (ABL == 5) ph[4] += wall_clock64() - ph_t;   // (from the last tile's term loop on: its snapshot pieces are counted here, not in [3])
     }
     // write out the partly filled lines and close the chunks this workgroup still has open
     outbox_flush_rings(ta.ob, L, 0, L.n_buckets);
@@ -1115,11 +1152,18 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         for (int off = 32; off > 0; off >>= 1) { n_locked += __shfl_xor(n_locked, off); n_lost += __shfl_xor(n_lost, off); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(probe + 4, (unsigned long long)n_locked); atomicAdd(probe + 5, (unsigned long long)n_lost); }
     }
+    if (ABL == 5 && threadIdx.x == 0 && probe) {   // (the words of the conflict counters and, with PGSGD_TILE_TAIL=1, of the tail probe)
+        ph[5] = wall_clock64() - ph_start;
+        atomicAdd(probe + 4, (unsigned long long)ph[0]);
+        atomicAdd(probe + 5, (unsigned long long)ph[1]);
+        if (unsigned long long* tail = TILE_COLD(ta.tail_probe))
+            for (int k = 0; k < 4; ++k) atomicAdd(tail + k, (unsigned long long)ph[2 + k]);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && probe) {
         probe[2] = __builtin_readcyclecounter();
         probe[3] = wall_clock64();
     }
-    if (threadIdx.x == 0 && TILE_COLD(ta.tail_probe)) {
+    if (ABL != 5 && threadIdx.x == 0 && TILE_COLD(ta.tail_probe)) {
         unsigned long long* tail = TILE_COLD(ta.tail_probe);
         const uint64_t now = wall_clock64();
         atomicAdd(tail, (unsigned long long)(now - wg_start));

@@ -320,6 +320,12 @@ class LayoutSession:
         check(lib.pgsgd_session_drain_beside(self._h, C.byref(on), C.byref(ms)), "drain_beside")
         return bool(on.value), ms.value
 
+    def probe_words(self):
+        """Profiling hook: the twelve raw words of the tile kernel's probes (pgsgd_session_probe_words)."""
+        out = (C.c_uint64 * 12)()
+        check(lib.pgsgd_session_probe_words(self._h, out), "probe_words")
+        return [int(v) for v in out]
+
     def terms_executed(self):
         """Terms the session's tile launches have executed so far, counted on the device (0 for a session without tiles)."""
         n = C.c_uint64()
