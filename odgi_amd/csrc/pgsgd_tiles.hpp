@@ -1113,8 +1113,9 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                 }
             }
         }
-        // what still waits in the wave's queue goes to the rings while the hot ones are bound to this window
-        while (wq_n) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }  // (ABL 2: the tiles do not rewrite their snapshot pieces)
+        // (what still waits in the wave's queue stays there: a message finds its bucket's ring — hot or not — whenever it is pushed, so
+        // the queue carries over to the next item and a call of the rings' protocol per wave and item is saved; flushed when the
+        // workgroup is out of items.  ABL 2: the tiles do not rewrite their snapshot pieces.)
         __syncthreads();
         if (LOCAL) {  // the window's only writer since it was staged: plain, coalesced stores
             const bool has_next = (wi.local & kItemHasNext) != 0;  // ... unless the window's next part may be staged by another workgroup in this launch
@@ -1137,8 +1138,11 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
         __syncthreads();  // s_item and the window are reused
         if (ABL == 5) ph[4] += wall_clock64() - ph_t;   // (from the last tile's term loop on: its snapshot pieces are counted here, not in [3])
     }
-    // write out the partly filled lines and close the chunks this workgroup still has open
-    outbox_flush_rings(ta.ob, L, 0, L.n_buckets);
+    // what still waits in the waves' queues, then the partly filled lines (the hot rings' too: the last pushes may have used them);
+    // close the chunks this workgroup still has open
+    while (wq_n) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }
+    __syncthreads();
+    outbox_flush_rings(ta.ob, L, 0, L.n_buckets + kObRings);
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
         const uint32_t lp = L.line()[b], chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // lines written into the open group
         if (chunk < kObOverflow)
