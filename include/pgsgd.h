@@ -34,7 +34,8 @@ extern "C" {
  * the pulls of the last TWO launches; the far pulls of a launch amount to one projection, not half (tile kernel; final layouts of
  * short schedules change); pgsgd_graph_view::step_path / step_pos may be NULL.  New entry points (nothing removed):
  * pgsgd_path_stress_near, pgsgd_session_terms_executed, pgsgd_session_drain_beside, pgsgd_session_read_step_records,
- * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index, pgsgd_session_probe_words. */
+ * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index, pgsgd_session_probe_words, pgsgd_tile_quad_partner; the lanes of a tile share the
+ * uniform partners of a warm trip in quads (one 128-byte line of step records for four terms), not pairs. */
 #define PGSGD_ABI_VERSION 6
 int pgsgd_abi_version(void);
 /* sizeof(pgsgd_graph_view), sizeof(pgsgd_params), sizeof(pgsgd_stats) as the LIBRARY was built (any pointer may be NULL) */
@@ -115,9 +116,9 @@ typedef struct pgsgd_graph_view {
                                            /* and 32-bit positions: the instance the CPU oracle's mirror reproduces bit for bit (parity  */
                                            /* tests).  Chosen automatically when a path is 2^32 bp long or longer                        */
 #define PGSGD_FLAG_NO_PARTNER_PAIRS 0x4000u /* tile kernel: every lane keeps its own uniform partner (path_sgd_layout.cpp:235-237).  By default the */
-                                           /* lanes of a wave pair up in a warm iteration's uniform trips: the odd lane takes the step that shares */
-                                           /* a 64-byte unit with its even neighbour's partner (one memory request for two terms; every partner  */
-                                           /* is still uniform over the path).  A/B and parity                                                  */
+                                           /* lanes of a wave share partners in quads in a warm iteration's uniform trips: lane r of four takes    */
+                                           /* flat step lead ^ r of the 128-byte line of four step records its quad's first lane drew (one memory */
+                                           /* request for four terms; every partner is still uniform over the path).  A/B and parity             */
 #define PGSGD_FLAG_LOCK_WINDOW_ENDS 0x8000u /* tile kernel, option (measured: no effect on the layout, 3 % slower — profiles/r04/NOTES.md): conflict   */
                                            /* resolution on shared node coordinates.  While a term's learning rate is in the projection regime     */
                                            /* (mu >= 0.1) it takes a lock bit on each of its window ends (one LDS atomic OR per end; the lanes of a  */
@@ -332,6 +333,9 @@ int64_t pgsgd_tile_split_items(const uint32_t* tile_begin, const uint32_t* tile_
  * when that is a step of the path, its own draw otherwise. */
 int pgsgd_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip);
 uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank);
+/* ... and what sessions run since round 6: lane r (1..3) of four consecutive lanes takes flat step lead ^ r of the 128-byte line of
+ * four step records its quad's first lane drew, when that is a step of the path (lane 0 and a cut line: the own draw). */
+uint32_t pgsgd_tile_quad_partner(uint32_t lead_flat_step, uint32_t lane_in_quad, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank);
 /* How the session's per-lane launches run: 0 one pass (a lane samples a term and moves its ends), 1 two passes (a small
  * lane-bound graph whose 2N coordinate words fit one compute unit's LDS: pgsgd_session_n_streams() streams sample, one
  * workgroup of *apply_lanes lanes moves the ends in LDS). */

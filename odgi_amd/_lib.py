@@ -154,6 +154,7 @@ SIGNATURES = [
     ("pgsgd_graph_path_order", C.c_int, [P(GraphView), P(u32), P(f64), P(f64)]),
     ("pgsgd_tile_wave_coin", C.c_int, [u64, u64, u64, u32, u64]),
     ("pgsgd_tile_pair_partner", u32, [u32, u32, u32, u32]),
+    ("pgsgd_tile_quad_partner", u32, [u32, u32, u32, u32, u32]),
     ("pgsgd_session_trace_terms", C.c_int, [C.c_void_p, C.c_int, u64, P(u64)]),
     ("pgsgd_graph_from_gfa", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),
     ("pgsgd_graph_from_og", C.c_int, [C.c_char_p, C.c_int, P(C.c_void_p)]),

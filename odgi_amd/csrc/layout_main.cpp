@@ -59,7 +59,7 @@ const Opt kOpts[] = {
     {0, "gpu-sync-drain", false, "", "Tiled kernel: deliver every launch's far updates before the very next launch (default for schedules shorter than 30 iterations)."},
     {0, "gpu-terms-per-anchor", true, "N", "Partners drawn per sampled first step (default: 1 = the reference's term stream)."},
     {0, "gpu-exact-math", false, "", "Tile kernel: IEEE divisions and square root in a term's geometry instead of the hardware's reciprocal / reciprocal square root (1 ulp)."},
-    {0, "gpu-no-partner-pairs", false, "", "Tile kernel: every lane keeps its own uniform partner (default: the lanes of a wavefront share them in pairs of neighbouring steps)."},
+    {0, "gpu-no-partner-pairs", false, "", "Tile kernel: every lane keeps its own uniform partner (default: the lanes of a wavefront share them in quads of neighbouring steps)."},
     {0, "gpu-no-relabel", false, "", "Keep the graph's node ranks even if they do not follow the paths (default: such a graph is laid out under ranks by path position, which lets the tile kernel run)."},
     {0, "gpu-lock-window-ends", false, "", "Tile kernel: conflict resolution on shared node ends (measured: no effect on the layout)."},
     {0, "stress", false, "", "Print sampled path stress and the odgi-stats 2D path distance of the result to stderr."},

@@ -357,6 +357,9 @@ extern "C" int pgsgd_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t
 extern "C" uint32_t pgsgd_tile_pair_partner(uint32_t lead_flat_step, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank) {
     return pgsgd::tile_pair_partner(lead_flat_step, path_first_step, path_steps, own_rank);
 }
+extern "C" uint32_t pgsgd_tile_quad_partner(uint32_t lead_flat_step, uint32_t lane_in_quad, uint32_t path_first_step, uint32_t path_steps, uint32_t own_rank) {
+    return pgsgd::tile_quad_partner(lead_flat_step, lane_in_quad & 3u, path_first_step, path_steps, own_rank);
+}
 // Host side of the tiled kernel: cut paths into tiles, bind tiles to region windows, order the work.
 struct HostTiles {
     std::vector<pgsgd::Tile> tiles;
@@ -999,7 +1002,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         const bool force = pgsgd::debug_env("PGSGD_TILE_FORCE") != nullptr;
         s->tile_forced = force;
         s->snapshot_pass = pgsgd::debug_env("PGSGD_TILE_SNAPSHOT_PASS") != nullptr;
-        s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 1u;
+        s->tile_pair_uniform = (p->flags & PGSGD_FLAG_NO_PARTNER_PAIRS) ? 0u : 2u;   // partner quads (pgsgd_tiles.hpp: tile_quad_partner)
         s->tile_lock_mu = (p->flags & PGSGD_FLAG_LOCK_WINDOW_ENDS) ? 0.1f : 0.0f;
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_LOCK_MU")) s->tile_lock_mu = (float)std::max(0.0, atof(e));  // experiment knob: the threshold
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_SNAP_EVERY")) s->tile_snap_every = (uint32_t)std::min(8, std::max(1, atoi(e)));
@@ -1010,7 +1013,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX_MAX")) s->tile_far_relax_max = (float)std::min(2.0, std::max(0.0, atof(e)));
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX_SLOPE")) s->tile_far_relax_slope = (float)std::min(2.0, std::max(0.0, atof(e)));
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
-        if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_QUADS")) s->tile_pair_uniform = 2;  // experiment: partner quads (no mirror in the oracle)
+        if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_PAIRS")) s->tile_pair_uniform = 1;  // A/B knob: the partner pairs of rounds 4-6 (oracle: ORC_TILE_PAIRS)
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52

@@ -582,7 +582,7 @@ __host__ __device__ inline uint64_t tile_coin_seed(uint64_t seed_base, uint64_t 
     return seed_base + epoch * 0xd1342543de82ef95ull + ((tile << 10) | (1023u - wave));
 }
 
-// Partner pairs.  A uniform partner (path_sgd_layout.cpp:235-237) is a random step of the path: one 128-byte line from HBM
+// Partner pairs (rounds 4-6; quads since: tile_quad_partner below).  A uniform partner (path_sgd_layout.cpp:235-237) is a random step of the path: one 128-byte line from HBM
 // per term that nothing else shares, and HBM delivers 51-55 G random lines per second (profiles/r04/NOTES.md section 6) —
 // the tile kernel's warm iterations ran at that ceiling.  A 64-byte half of a line
 // holds the records of TWO consecutive steps, so the lanes of a wave pair up in a uniform trip: the even lane draws its
@@ -597,6 +597,19 @@ __host__ __device__ inline uint64_t tile_coin_seed(uint64_t seed_base, uint64_t 
 __host__ __device__ inline uint32_t tile_pair_partner(uint32_t lead_flat_step, uint32_t pstart, uint32_t cnt, uint32_t own_rank) {
     const uint32_t twin = (lead_flat_step ^ 1u) - pstart;
     return twin < cnt ? twin : own_rank;
+}
+// Partner QUADS (what sessions run since round 6's second session; pairs: rounds 4-6, debug knob PGSGD_TILE_PAIRS).  A 128-byte line of
+// gather records holds FOUR consecutive steps (recs2: [s0 s1 s2 s3 | n0 n1 n2 n3]) and a read request moves the whole line, so lane r of
+// four consecutive lanes takes flat step lead ^ r of the line its group's first lane drew — one memory request for four terms, every
+// partner still uniform over the path's steps (the map step -> step ^ r permutes the steps of every line that lies inside the path; the
+// up to three steps at either end of a path whose line is cut are chosen a shade less often, one part in 1e6 on a 1e6-step path), and
+// the lane keeps its own draw where the line is cut.  Once the waits in front of the term loops were gone the kernel ran at 90 % of the
+// memory's random-line rate in warm launches: quads take 24 % of their read requests away — warm launches 0.624 -> 0.645 of the roofline
+// figure, the driver's window 0.667 -> 0.678, final stress unchanged (exact figure 0.20574 / 0.20583; profiles/r06/quads_ab.jsonl).
+// The oracle draws the same quads (orc_tile_partner).
+__host__ __device__ inline uint32_t tile_quad_partner(uint32_t lead_flat_step, uint32_t r, uint32_t pstart, uint32_t cnt, uint32_t own_rank) {
+    const uint32_t twin = (lead_flat_step ^ r) - pstart;
+    return r && twin < cnt ? twin : own_rank;
 }
 
 // MATH: kMathFast is the instance sessions run — the term's geometry with the hardware's reciprocal and reciprocal
@@ -946,10 +959,9 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
                         if (ta.pair_uniform == 1u) {
                             const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0xA0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]: the even lane's step
                             if (threadIdx.x & 1u) b_rank = tile_pair_partner(lead, pstart, cnt, b_rank);
-                        } else if (ta.pair_uniform == 2u) {  // experiment (PGSGD_TILE_QUADS, not mirrored by the oracle): four lanes share a 128-byte line of four records
-                            const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
-                            const uint32_t twin = (lead ^ (threadIdx.x & 3u)) - pstart;
-                            if ((threadIdx.x & 3u) && twin < cnt) b_rank = twin;
+                        } else if (ta.pair_uniform == 2u) {  // partner quads (tile_quad_partner): four lanes share a 128-byte line of four records
+                            const uint32_t lead = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(pstart + b_rank), 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]: the quad's first lane's step
+                            b_rank = tile_quad_partner(lead, threadIdx.x & 3u, pstart, cnt, b_rank);
                         }
                     }
                     // the partner's record: the tile's LDS copy when it is a step of the tile (read where it is used), otherwise
@@ -1368,9 +1380,12 @@ __global__ __launch_bounds__(kTileBlock) void tile_trace_kernel(DevConst c, Tile
                 b_rank = below32_hi(rng, (uint32_t)cnt, unused);
             }
         }
-        if (!zipf_trip && pair_uniform) {   // (every lane of the wave: an odd live lane's even neighbour is live too)
+        if (!zipf_trip && pair_uniform == 1u) {   // (every lane of the wave: an odd live lane's even neighbour is live too)
             const uint32_t lead = (uint32_t)__shfl((int)(uint32_t)(pstart + b_rank), (int)((threadIdx.x & 63u) & ~1u));
             if (live && (lane & 1u)) b_rank = tile_pair_partner(lead, (uint32_t)pstart, (uint32_t)cnt, (uint32_t)b_rank);
+        } else if (!zipf_trip && pair_uniform == 2u) {   // (a live lane's quad leader is live too: the live lanes of a trip are a prefix)
+            const uint32_t lead = (uint32_t)__shfl((int)(uint32_t)(pstart + b_rank), (int)((threadIdx.x & 63u) & ~3u));
+            if (live) b_rank = tile_quad_partner(lead, lane & 3u, (uint32_t)pstart, (uint32_t)cnt, (uint32_t)b_rank);
         }
         if (live) {
             const uint64_t kb = pstart + b_rank;

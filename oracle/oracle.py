@@ -64,7 +64,7 @@ def _load(name):
     lib.orc_trace_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32, C.c_uint32,
                                     C.c_int, C.c_uint32, C.c_uint64, _U64P]
     lib.orc_tile_terms.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
-                                   C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _U64P]
+                                   C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _U64P]
     lib.orc_tile_terms.restype = C.c_uint64
     lib.orc_layout_streams_f32.argtypes = [C.POINTER(OrcGraph), C.POINTER(OrcParams), C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_uint32, _F32P, _F32P, _F64P]
@@ -193,11 +193,12 @@ def trace_terms(g, p, seed, n_streams, stream_offset, cooling, terms_per_stream,
     return out
 
 
-def tile_terms(g, p, seed_base, epoch, n_terms, steps_total, tile, lanes, t0, cum, n, path, cooling, capacity=1 << 16):
-    """Terms of tile number `tile` of the tile table, worked on by `lanes` lanes (one stream per lane), in term order."""
+def tile_terms(g, p, seed_base, epoch, n_terms, steps_total, tile, lanes, t0, cum, n, path, cooling, capacity=1 << 16, share=4):
+    """Terms of tile number `tile` of the tile table, worked on by `lanes` lanes (one stream per lane), in term order.  share: the lanes
+    that share a line of partner records in a uniform trip (4: quads, what sessions run; 2: the pairs of rounds 4-6; 1: none)."""
     out = np.zeros((capacity, 4), dtype=np.uint64)
     cnt = lib().orc_tile_terms(C.byref(g.view), C.byref(p), seed_base, epoch, n_terms, steps_total, int(tile), int(lanes), int(t0), int(cum),
-                               int(n), int(path), 1 if cooling else 0, out.ctypes.data_as(_U64P))
+                               int(n), int(path), 1 if cooling else 0, int(share), out.ctypes.data_as(_U64P))
     return out[:cnt]
 
 
@@ -224,10 +225,11 @@ def layout_streams_q32(g, p, seed, n_streams, X, Y, x_off, y_off, quanta_per_bp,
 
 
 TILE_DRAIN_AFTER, TILE_TWO_SNAPSHOTS, TILE_NO_FLUSH, TILE_CONSTANT_RELAX, TILE_SNAPSHOT_PASS, TILE_LANE_COIN, TILE_NO_PAIRS, TILE_RELAX_R5 = 1, 2, 4, 8, 16, 32, 64, 128
+TILE_PAIRS = 0x10000           # uniform partners shared by pairs of lanes (rounds 4-6) instead of quads
 TILE_DRAIN_BESIDE = 0x8000   # per-colour outboxes, pulls delivered before the same colour's next launch (sessions of >= 30 iterations)
 TILE_ROUND2 = TILE_DRAIN_AFTER | TILE_TWO_SNAPSHOTS | TILE_CONSTANT_RELAX | TILE_SNAPSHOT_PASS | TILE_LANE_COIN | TILE_NO_PAIRS   # the launch order, far-pull policy and per-lane coin of round 2
 TILE_ROUND3 = TILE_LANE_COIN | TILE_NO_PAIRS | TILE_RELAX_R5   # round 3's pipeline: today's launch order, the Zipf/uniform coin per lane, far pulls ramping to half a projection
-TILE_ROUND5 = TILE_RELAX_R5   # rounds 4-5: wave coin, partner pairs; far pulls ramping 0.1 .. 0.5 (round 6: 0.2 .. 1.0)
+TILE_ROUND5 = TILE_RELAX_R5 | TILE_PAIRS   # rounds 4-5: wave coin, partner pairs; far pulls ramping 0.1 .. 0.5 (round 6: 0.2 .. 1.0, partner quads)
 
 
 def tile_wave_coin(seed_base, epoch, tile, wave, trip):

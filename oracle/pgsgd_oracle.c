@@ -269,13 +269,14 @@ static void orc_tile_pick_first(const orc_graph* g, const orc_params* p, int coo
     }
 }
 
-/* Partner pairs (round 4; pgsgd_tiles.hpp: tile_pair_partner): in a uniform trip the odd lanes of a tile take the step
- * that shares a 64-byte unit of the step records with their even neighbour's partner — flat step ^ 1 — when that is a
- * step of the path; the odd lane still draws its own partner first (its stream advances as before) and keeps it
- * otherwise.  pair_lead: the even neighbour's partner (flat step) for an odd lane, ORC_NO_PAIR for an even lane, a Zipf
- * term, or the pipelines of rounds 2 and 3 (ORC_TILE_NO_PAIRS). */
+/* Partner pairs (rounds 4-6) and quads (round 6's second session; pgsgd_tiles.hpp: tile_pair_partner, tile_quad_partner): in a
+ * uniform trip the lanes of a tile share the 128-byte line of four step records their group's first lane drew — lane r of a
+ * group of `share` lanes (2: pairs, 4: quads) takes flat step lead ^ r, lead = the partner of the group's lane 0, when that is
+ * a step of the path; it still draws its own partner first (its stream advances as before) and keeps it otherwise.
+ * pair_lead: the group's lane-0 partner (flat step) for the other lanes of the group, ORC_NO_PAIR for lane 0, a Zipf term, or
+ * the pipelines of rounds 2 and 3 (ORC_TILE_NO_PAIRS); r: the lane's index in its group (1 for the odd lane of a pair). */
 #define ORC_NO_PAIR (~(uint64_t)0)
-static void orc_tile_partner(const orc_graph* g, const orc_params* p, const double* zetas, const orc_tile_pick* pk, uint64_t pair_lead,
+static void orc_tile_partner(const orc_graph* g, const orc_params* p, const double* zetas, const orc_tile_pick* pk, uint64_t pair_lead, uint32_t r,
                              uint64_t s[4], orc_term* t) {
     uint64_t b_rank;
     if (pk->zipf) {
@@ -286,8 +287,8 @@ static void orc_tile_partner(const orc_graph* g, const orc_params* p, const doub
     } else {
         uint32_t unused;
         b_rank = orc_below32_hi(s, (uint32_t)pk->an.cnt, &unused);                             /* :235-237 */
-        if (pair_lead != ORC_NO_PAIR) {
-            const uint32_t twin = ((uint32_t)pair_lead ^ 1u) - (uint32_t)pk->an.pstart;
+        if (pair_lead != ORC_NO_PAIR && r) {
+            const uint32_t twin = ((uint32_t)pair_lead ^ r) - (uint32_t)pk->an.pstart;
             if (twin < (uint32_t)pk->an.cnt) b_rank = twin;
         }
     }
@@ -497,7 +498,7 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
  * partner by the reference rule. */
 uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
                         uint64_t steps_total, uint64_t tile, uint32_t lanes, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path,
-                        int cooling, uint64_t* out) {
+                        int cooling, uint32_t share, uint64_t* out) {
     const size_t nz = orc_zeta_size(p->space, p->space_max, p->space_quantization_step);
     double* zetas = (double*)malloc(nz * sizeof(double));
     orc_zetas(p->theta, p->space, p->space_max, p->space_quantization_step, zetas);
@@ -519,8 +520,10 @@ uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_b
         orc_tile_pick cur;
         orc_tile_pick_first(g, p, cooling, coin[lane / 64], t0, n, path, streams + 4 * (size_t)lane, &cur);
         orc_term t;
-        orc_tile_partner(g, p, zetas, &cur, (lane & 1u) ? lead : ORC_NO_PAIR, streams + 4 * (size_t)lane, &t);
-        lead = cur.zipf ? ORC_NO_PAIR : t.kb;
+        /* share: lanes per shared line of partner records in a uniform trip (4: quads, what sessions run; 2: the pairs of rounds 4-6; 0, 1: none) */
+        const uint32_t r = share > 1 ? lane % share : 0;
+        orc_tile_partner(g, p, zetas, &cur, r ? lead : ORC_NO_PAIR, r, streams + 4 * (size_t)lane, &t);
+        if (!r) lead = cur.zipf ? ORC_NO_PAIR : t.kb;   /* (the group's lane 0 drew the term before the others, in the same trip) */
         uint64_t* o = out + (q - term_begin) * 4;
         o[0] = t.ka; o[1] = t.kb; o[2] = t.off_a; o[3] = t.off_b;
     }
@@ -1316,6 +1319,7 @@ static inline float displacement_capped_f32(float eta, uint64_t pos_a, uint64_t 
  *   ORC_TILE_NO_FLUSH       return the coordinates as a snapshot between iterations sees them: without the pulls still waiting
  *   ORC_TILE_LANE_COIN      the Zipf/uniform coin of a warm term is bit 31 of the lane's own word (rounds 2 and 3), not the wave's
  *   ORC_TILE_NO_PAIRS       every lane keeps its own uniform partner (rounds 2 and 3; PGSGD_FLAG_NO_PARTNER_PAIRS)
+ *   ORC_TILE_PAIRS          the lanes share uniform partners in pairs (rounds 4-6) instead of quads
  *   ORC_TILE_DRAIN_BESIDE   every region colour has its own outbox and a launch's far pulls are delivered right before the SAME colour's
  *                           next launch — a launch later than by default — from the sixth iteration on (the first five's arrive before
  *                           the very next launch, as by default): what a session does whose drain runs on a second stream beside the
@@ -1430,8 +1434,9 @@ void orc_tile_layout_q32_ex(const orc_graph* g, const orc_params* p, uint64_t se
                         const int coin = (policy & ORC_TILE_LANE_COIN) ? -1 : orc_tile_wave_coin(seed_base, epoch, ti, lane / 64, (q - term_begin) / lanes);
                         orc_tile_pick_first(g, p, cooling, coin, t0[ti], tn[ti], tpath[ti], s, &cur);
                         orc_term t;
-                        orc_tile_partner(g, p, zetas, &cur, ((lane & 1u) && !(policy & ORC_TILE_NO_PAIRS)) ? pair_lead : ORC_NO_PAIR, s, &t);
-                        pair_lead = cur.zipf ? ORC_NO_PAIR : t.kb;   /* (an odd lane's even neighbour drew the term before, in the same trip) */
+                        const uint32_t share = (policy & ORC_TILE_NO_PAIRS) ? 1u : (policy & ORC_TILE_PAIRS) ? 2u : 4u, r = lane % share;
+                        orc_tile_partner(g, p, zetas, &cur, r ? pair_lead : ORC_NO_PAIR, r, s, &t);
+                        if (!r) pair_lead = cur.zipf ? ORC_NO_PAIR : t.kb;   /* (the group's lane 0 drew the term before the others, in the same trip) */
                         const uint64_t ea = 2 * (uint64_t)(g->step_handle[t.ka] >> 1) + t.off_a;
                         const uint64_t eb = 2 * (uint64_t)(g->step_handle[t.kb] >> 1) + t.off_b;
                         const int in_a = local[it] && ea >= wbase && ea - wbase < win_words;

@@ -75,7 +75,7 @@ void orc_trace_terms(const orc_graph* g, const orc_params* p, uint64_t seed, uin
 /* the terms one tile of the device's tile kernel draws in iteration `epoch`; returns their number */
 uint64_t orc_tile_terms(const orc_graph* g, const orc_params* p, uint64_t seed_base, uint64_t epoch, uint64_t n_terms,
                         uint64_t steps_total, uint64_t tile, uint32_t lanes, uint64_t t0, uint64_t cum, uint32_t n, uint32_t path,
-                        int cooling, uint64_t* out);
+                        int cooling, uint32_t share, uint64_t* out);
 /* the Zipf/uniform coin the 64 lanes of wave `wave` of a tile share in their trip `trip` of a warm iteration */
 int orc_tile_wave_coin(uint64_t seed_base, uint64_t epoch, uint64_t tile, uint32_t wave, uint64_t trip);
 /* fp32 mirror of the device arithmetic; bit-exact with the GPU for n_streams == 1 */
@@ -94,6 +94,7 @@ void orc_layout_streams_f32(const orc_graph* g, const orc_params* p, uint64_t se
 #define ORC_TILE_LANE_COIN 32u
 #define ORC_TILE_NO_PAIRS 64u
 #define ORC_TILE_RELAX_R5 128u
+#define ORC_TILE_PAIRS 0x10000u
 #define ORC_TILE_DRAIN_BESIDE 0x8000u
 void orc_tile_layout_q32(const orc_graph* g, const orc_params* p, uint64_t seed_base,
                          uint64_t n_tiles, const uint64_t* t0, const uint64_t* cum, const uint32_t* tn, const uint32_t* tpath,

@@ -499,7 +499,8 @@ def test_tile_sampler_rules_host_copies_match_the_oracle(orc):
     """The wave coin and the partner pair of the tile kernel's sampler (pgsgd_tiles.hpp: tile_coin_seed,
     tile_pair_partner), through the library's host copies, against the oracle's restatement: the same coins for any
     (seed, iteration, tile, wave, trip), fair and serially independent; the odd lane's partner is its even neighbour's
-    twin in the 64-byte unit when that is a step of the path and its own draw otherwise."""
+    twin in the 64-byte unit when that is a step of the path and its own draw otherwise (rounds 4-6), and lane r of a quad takes
+    step lead ^ r of its first lane's 128-byte line (what sessions run since round 6)."""
     from odgi_amd import _lib
     lib = _lib.lib
     rs = np.random.RandomState(3)
@@ -521,6 +522,18 @@ def test_tile_sampler_rules_host_copies_match_the_oracle(orc):
     # every step is some step's twin exactly once, but for the path's unpaired ends
     twins = [lib.pgsgd_tile_pair_partner(first + r, first, cnt, 99) for r in range(cnt)]
     assert sorted(t for t in twins if t != 99) == [r for r in range(cnt) if 0 <= ((first + r) ^ 1) - first < cnt]
+    # partner quads (what sessions run): lane r of a quad takes flat step lead ^ r when that is a step of the path, lane 0 and a cut line keep the own draw
+    for lead_rank in range(cnt):
+        assert lib.pgsgd_tile_quad_partner(first + lead_rank, 0, first, cnt, 3) == 3
+        for r in (1, 2, 3):
+            got = lib.pgsgd_tile_quad_partner(first + lead_rank, r, first, cnt, 3)
+            twin = ((first + lead_rank) ^ r) - first
+            assert got == (twin if 0 <= twin < cnt else 3), (lead_rank, r, got)
+    # for every r the map lead -> lead ^ r permutes the steps whose line lies inside the path: each is taken exactly once
+    for r in (1, 2, 3):
+        taken = [lib.pgsgd_tile_quad_partner(first + k, r, first, cnt, 99) for k in range(cnt)]
+        inside = [k for k in range(cnt) if 0 <= ((first + k) ^ r) - first < cnt]
+        assert sorted(t for t in taken if t != 99) == inside
 
 
 def test_path_order_renames_nodes_along_the_paths(oa):

@@ -331,21 +331,32 @@ def test_tile_sampler_draws_the_reference_term_distribution(orc, ographs):
             # a uniform trip's partners are uniform over the path's steps, whatever the first step
             uni = til[np.repeat(coins == 0, lanes)][:400000]
             kb = np.bincount((uni[:, 1] - first) * 16 // L, minlength=16)
-            # (partner pairs: the odd lanes' partners are their even neighbours' twins — the even lanes' draws are the independent ones)
-            even = uni[0::2]
-            kb_even = np.bincount((even[:, 1] - first) * 16 // L, minlength=16)
-            assert np.all(np.abs(kb_even - len(even) / 16) < 5 * np.sqrt(len(even) / 16)), kb_even
-            assert np.all(np.abs(kb - len(uni) / 16) < 5 * np.sqrt(2 * len(uni) / 16)), kb
-            # the lanes of a wave pair up in a uniform trip (pgsgd_tiles.hpp: tile_pair_partner): the odd lane's partner shares a
-            # 64-byte unit of the step records with the even lane's (flat step ^ 1) unless that twin lies outside the path
-            odd = uni[1::2]
+            # (partner quads: lanes 1..3 of four consecutive lanes take their first lane's line — the first lanes' draws are the independent ones)
+            lead = uni[0::4]
+            kb_lead = np.bincount((lead[:, 1] - first) * 16 // L, minlength=16)
+            assert np.all(np.abs(kb_lead - len(lead) / 16) < 5 * np.sqrt(len(lead) / 16)), kb_lead
+            assert np.all(np.abs(kb - len(uni) / 16) < 5 * np.sqrt(4 * len(uni) / 16)), kb
+            # the lanes of a wave share a 128-byte line of four step records in a uniform trip (pgsgd_tiles.hpp: tile_quad_partner): lane r's
+            # partner is flat step lead ^ r unless that step lies outside the path
+            for r in (1, 2, 3):
+                other = uni[r::4]
+                twin = lead[:len(other), 1] ^ r
+                inside = (twin >= first) & (twin < first + L)
+                assert np.array_equal(other[inside, 1], twin[inside]) and inside.mean() > 0.999
+                assert np.all((other[~inside, 1] >= first) & (other[~inside, 1] < first + L))
+                # ... and is itself uniform over the path's steps, with fair end choices of its own
+                kb_r = np.bincount((other[:, 1] - first) * 16 // L, minlength=16)
+                assert np.all(np.abs(kb_r - len(other) / 16) < 5 * np.sqrt(len(other) / 16)), (r, kb_r)
+            # the pairs of rounds 4-6 (share=2) are still what the oracle draws when asked: odd lanes take their even neighbour's twin
+            til2 = orc.tile_terms(g, p, 12345, 3, 64 * 2000, L, 0, lanes, first, 0, L, path, cooling, capacity=64 * 2000, share=2).astype(np.int64)
+            uni2 = til2[np.repeat(coins[:2000] == 0, lanes)]
+            even, odd = uni2[0::2], uni2[1::2]
             twin = even[:, 1] ^ 1
             inside = (twin >= first) & (twin < first + L)
             assert np.array_equal(odd[inside, 1], twin[inside]) and inside.mean() > 0.999
-            assert np.all((odd[~inside, 1] >= first) & (odd[~inside, 1] < first + L))
-            # ... and is itself uniform over the path's steps, with fair end choices of its own
-            kb_odd = np.bincount((odd[:, 1] - first) * 16 // L, minlength=16)
-            assert np.all(np.abs(kb_odd - len(odd) / 16) < 5 * np.sqrt(len(odd) / 16)), kb_odd
+            # (the streams are the same under either rule: the quads' first lanes and the pairs' even lanes of the same trips drew the same partners)
+            uni4 = til[:64 * 2000][np.repeat(coins[:2000] == 0, lanes)]
+            assert np.array_equal(uni4[0::4, 1], uni2[0::4, 1]) and np.array_equal(uni4[:, 0], uni2[:, 0])
             til = til[:400000]
             M = len(til)
         # first steps: uniform over the path in both

@@ -21,7 +21,7 @@ variant() {  # name, env assignments..., then "--", then extra bench flags
   (cd /tmp && env "${envs[@]}" timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d "$OUT/${name}_sq" -o bench -- $BENCH "$@" > "$OUT/${name}_sq.json" 2> "$OUT/${name}_sq.err")
 }
 variant pairs PGSGD_AB=pairs --
-variant quads PGSGD_DEBUG=1 PGSGD_TILE_QUADS=1 --
+variant pairs PGSGD_DEBUG=1 PGSGD_TILE_PAIRS=1 --   # (quads are what sessions run since round 6; rounds 4-5 ran this A/B the other way round)
 variant nopairs PGSGD_AB=nopairs -- --flags 0x4000
 python3 - "$OUT" <<'PY'
 import sqlite3, sys, os, json, glob, re
