@@ -1,7 +1,7 @@
 #!/bin/bash
 # What bounds the tile kernel — memory lines or latency?  The same rocprofv3 --pmc passes (counters only, one small group
 # per pass) of the bench command for three partner rules: the shipped one (partner pairs: two lanes share a 64-byte
-# half line), partner quads (PGSGD_TILE_QUADS: four lanes share a 128-byte line; halves the uniform partners' lines
+# half line), partner quads (the shipped rule since round 6; PGSGD_TILE_PAIRS=1: the pairs of rounds 4-6) — four lanes share a 128-byte line; halves the uniform partners' lines
 # again) and no sharing (PGSGD_FLAG_NO_PARTNER_PAIRS).  If the read requests fall with the sharing and the time does
 # not, the kernel is not bound by lines.  Usage: tools/profile_bound_ab.sh <tag> -> gpurun_out/bound_ab_<tag>/bound_ab.json
 cd "${GRAFT_REPO_ROOT:-.}"
