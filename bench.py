@@ -85,6 +85,9 @@ def main():
     from odgi_amd import _lib
     p = oa.LayoutParams.defaults(g, iter_max=iters, n_streams=args.streams, device=local_rank,
                                  flags=(_lib.FLAG_NO_TILES if args.no_tiles else 0) | args.flags)
+    # several ranks: regions of 128 nodes where 256-node windows would not fill the devices — the sessions' rule then shards by
+    # region with the exact exchange (G ranks hold one GPU's layout bit for bit); --flags 0x80000: by tile, faster and lossy
+    p.flags |= oa.shard_flags(g, world, p.flags)
     if args.seed is not None:
         p.seed = args.seed
     X0, Y0 = oa.initial_layout(g, "d", seed=42)

@@ -34,9 +34,13 @@ extern "C" {
  * the pulls of the last TWO launches; the far pulls of a launch amount to one projection, not half (tile kernel; final layouts of
  * short schedules change); pgsgd_graph_view::step_path / step_pos may be NULL.  New entry points (nothing removed):
  * pgsgd_path_stress_near, pgsgd_session_terms_executed, pgsgd_session_drain_beside, pgsgd_session_read_step_records,
- * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index, pgsgd_session_probe_words, pgsgd_tile_quad_partner; the lanes of a tile share the
- * uniform partners of a warm trip in quads (one 128-byte line of step records for four terms), not pairs. */
-#define PGSGD_ABI_VERSION 6
+ * pgsgd_graph_load_flags, pgsgd_graph_drop_step_index, pgsgd_session_probe_words, pgsgd_tile_quad_partner, pgsgd_session_drain_plan; the lanes of a tile share the
+ * uniform partners of a warm trip in quads (one 128-byte line of step records for four terms), not pairs.
+ * 7: pgsgd_session_set_shard(.., -1) shards a fixed-point tiled session by region with the exact exchange from PGSGD_SHARD_MIN_WINDOWS
+ * (240) windows per device on (a thousand until now; by tile below): a multi-GPU run is one GPU's layout on every graph that can
+ * occupy its devices; PGSGD_FLAG_SHARD_TILES asks for the tile shard, PGSGD_FLAG_REGION_128 for 128-node regions; new entry points
+ * pgsgd_shard_flags, pgsgd_session_drain_plan. */
+#define PGSGD_ABI_VERSION 7
 int pgsgd_abi_version(void);
 /* sizeof(pgsgd_graph_view), sizeof(pgsgd_params), sizeof(pgsgd_stats) as the LIBRARY was built (any pointer may be NULL) */
 void pgsgd_abi_struct_sizes(size_t* graph_view, size_t* params, size_t* stats);
@@ -130,6 +134,12 @@ typedef struct pgsgd_graph_view {
 #define PGSGD_FLAG_SYNC_DRAIN    0x20000u /* tile kernel: deliver every launch's far pulls in front of the very next launch.  By default a session of a  */
                                          /* schedule as long as the reference's (iter_max >= 30) sums them on a second stream BESIDE the next     */
                                          /* launch and delivers them a launch later, from the sixth iteration on (+2.7 %, same layout). */
+#define PGSGD_FLAG_REGION_128    0x40000u /* tile kernel: regions of 128 nodes (tiles of 112 steps) instead of 256 / 224: twice the windows per launch.  For  */
+                                         /* the sessions of a multi-GPU run sharded by region on a graph whose 256-node windows would leave a device     */
+                                         /* fewer than a thousand per launch (pgsgd_shard_flags sets it): 9 % slower on one GPU, same layout  */
+#define PGSGD_FLAG_SHARD_TILES   0x80000u /* multi-GPU: shard the tile kernel by TILE wherever the rule would shard by region — every device stages every */
+                                         /* window and runs every G-th tile: faster on graphs too small to fill G devices with windows (config 4 at G = 8:  */
+                                         /* 41 ms of kernels per rank against 79) and NOT one GPU's layout: stress +8 / +14 / +21 % at G = 2 / 4 / 8         */
 #define PGSGD_FLAG_ABLATE(n)  (((n) & 0xfu) << 8) /* profiling only: 1 no atomics,                     */
                                                   /* 3 no coordinate loads, 4 neither (results invalid) */
 
@@ -280,6 +290,10 @@ int pgsgd_session_read_step_records(pgsgd_session* s, uint64_t first, uint64_t c
 /* whether the session sums its launches' far pulls on a second stream beside the next launch (PGSGD_FLAG_SYNC_DRAIN: never), and
  * far_drain_kernel's time there (ms, HIP events) — off the launch stream's critical path */
 int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* drain_ms);
+/* how the session's far pulls are summed (far_drain_kernel): parts = workgroups that share a bucket's node range (1 up to 2.1e6
+ * nodes, 2^(shift - 14) beyond: every part looks at every message of the bucket and keeps its own), slices = workgroups that share a
+ * (bucket, part)'s messages */
+int pgsgd_session_drain_plan(pgsgd_session* s, uint32_t* parts, uint32_t* slices);
 /* terms the session's tile launches have executed, counted on the device (cumulative; 0 without tiles) */
 int pgsgd_session_terms_executed(pgsgd_session* s, uint64_t* terms);
 /* Tile kernel only: far updates that found their bucket's share of the message pool used up and were applied as
@@ -295,14 +309,23 @@ uint32_t pgsgd_session_n_streams(const pgsgd_session* s);
  *   by_region = 2: by region with the EXACT exchange (pgsgd_session_exchange_exact_begin / _end below): an iteration is two
  *                  parts, one per region colour, each followed by an integer exchange — the devices then hold, bit for
  *                  bit, one GPU's coordinates.
- *   by_region -1: the session's rule, the one both drivers use: by region when that leaves every launch at least a thousand
- *                  WINDOWS per device (windows, not the parts a one-GPU session cuts them into) — with the exact exchange (2)
- *                  when the coordinates are fixed-point, the default, with the merge rule (1) otherwise — and by tile (0)
- *                  when it does not.
+ *   by_region -1: the session's rule, the one both drivers use.  Fixed-point coordinates (the default): by region with the exact
+ *                  exchange (2) when that leaves every launch at least PGSGD_SHARD_MIN_WINDOWS windows per device (windows, not
+ *                  the parts a one-GPU session cuts them into; rounds 4-6 asked for a thousand and sharded config 4 by tile:
+ *                  faster and +8..21 % stress — now PGSGD_FLAG_SHARD_TILES), by tile (0) when it does not.  fp32 words: by
+ *                  region with the merge rule (1) from a thousand windows per device on, by tile below.
  * Returns 1 (sharded by tile), 2 (by region) or 3 (by region, exact) when the session is tiled, 0 when it runs the
  * per-lane kernel (shard the term count instead), < 0 on error.  The tile streams of a sharded session are keyed on (seed, iteration,
  * tile, lane) — stream_offset, which the devices' per-lane streams need to differ, does not enter them. */
 int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region);
+/* Flag bits a multi-GPU driver ORs into the params of its `world` sessions BEFORE it creates them, so that pgsgd_session_set_shard(.., -1)
+ * can shard them by region with the exact exchange: PGSGD_FLAG_REGION_128 when 256-node regions would leave a device fewer than
+ * PGSGD_SHARD_FULL_WINDOWS windows per launch and 128-node regions leave it at least PGSGD_SHARD_MIN_WINDOWS; 0 otherwise (one device,
+ * no tiles, fp32 words, PGSGD_FLAG_SHARD_TILES, a graph too small either way).  Both in-tree drivers call it (pgsgd_multi.cpp,
+ * odgi_amd/distributed.py via bench.py). */
+#define PGSGD_SHARD_FULL_WINDOWS 1000u
+#define PGSGD_SHARD_MIN_WINDOWS   240u
+uint32_t pgsgd_shard_flags(uint64_t n_nodes, uint32_t world, uint32_t flags);
 /* returns 1 when the session runs the region-exclusive tile kernel, 0 when it runs the per-lane kernel, 2 (known
  * after pgsgd_session_upload_coords) when the initial layout has no global structure — long-range stress above
  * 0.1 — and the iterations before cooling therefore run the per-lane kernel, the cooling ones the tile kernel */

@@ -14,11 +14,11 @@ Everything computes through libpgsgd.so (HIP, gfx950); nothing here falls back t
 from .graph import Graph
 from .layout import (Layout, LayoutParams, LayoutSession, initial_layout, main_layout,
                      path_linear_sgd_layout_gpu, path_linear_sgd_layout_schedule, zeta_table,
-                     path_stress, path_stress_near, path_distance)
+                     path_stress, path_stress_near, path_distance, shard_flags)
 
 from .sort import path_linear_sgd, path_linear_sgd_order, sort_params_defaults, sort_stress
 
 __all__ = ["path_linear_sgd", "path_linear_sgd_order", "sort_params_defaults", "sort_stress",
            "Graph", "Layout", "LayoutParams", "LayoutSession", "initial_layout", "main_layout",
            "path_linear_sgd_layout_gpu", "path_linear_sgd_layout_schedule", "zeta_table",
-           "path_stress", "path_stress_near", "path_distance"]
+           "path_stress", "path_stress_near", "path_distance", "shard_flags"]

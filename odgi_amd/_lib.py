@@ -47,7 +47,7 @@ class Stats(C.Structure):
                 ("frame_doublings", u32), ("apply_lanes", u32), ("relabeled", u32), ("tiled", u32)]
 
 
-ABI_VERSION = 6   # include/pgsgd.h: PGSGD_ABI_VERSION this binding was written against
+ABI_VERSION = 7   # include/pgsgd.h: PGSGD_ABI_VERSION this binding was written against
 
 
 def _check_abi():
@@ -84,6 +84,8 @@ FLAG_NO_PARTNER_PAIRS = 0x4000
 FLAG_LOCK_WINDOW_ENDS = 0x8000
 FLAG_NO_RELABEL = 0x10000
 FLAG_SYNC_DRAIN = 0x20000
+FLAG_REGION_128 = 0x40000
+FLAG_SHARD_TILES = 0x80000
 DEFAULT_SEED = 9399220
 # error codes of include/pgsgd.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_IO, E_FORMAT, E_NOTOPTIMIZED, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7, -8
@@ -133,6 +135,8 @@ SIGNATURES = [
     ("pgsgd_session_terms_executed", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_read_step_records", C.c_int, [C.c_void_p, u64, u64, P(u32)]),
     ("pgsgd_session_drain_beside", C.c_int, [C.c_void_p, P(C.c_int), P(f64)]),
+    ("pgsgd_shard_flags", u32, [u64, u32, u32]),
+    ("pgsgd_session_drain_plan", C.c_int, [C.c_void_p, P(C.c_uint32), P(C.c_uint32)]),
     ("pgsgd_session_probe_words", C.c_int, [C.c_void_p, P(u64)]),
     ("pgsgd_session_outbox_overflow", i64, [C.c_void_p]),
     ("pgsgd_session_n_streams", u32, [C.c_void_p]),

@@ -56,6 +56,7 @@ const Opt kOpts[] = {
     {0, "gpus", true, "N", "Run on N GPUs of this node (devices --device .. --device+N-1): graph replicated, every iteration's terms split 1/N per GPU, coordinates merged with an RCCL all-reduce at every iteration (default: 1)."},
     {0, "device", true, "N", "HIP device ordinal (default: current)."},
     {0, "gpu-no-tiles", false, "", "Always use the per-lane kernel (one reference worker stream per GPU lane), never the tiled one."},
+    {0, "gpu-shard-tiles", false, "", "Several GPUs (--gpus): share the tiles of every window among the GPUs instead of the windows. Faster on graphs below ~5M nodes, and not one GPU's layout (stress +8..21 %)."},
     {0, "gpu-sync-drain", false, "", "Tiled kernel: deliver every launch's far updates before the very next launch (default for schedules shorter than 30 iterations)."},
     {0, "gpu-terms-per-anchor", true, "N", "Partners drawn per sampled first step (default: 1 = the reference's term stream)."},
     {0, "gpu-exact-math", false, "", "Tile kernel: IEEE divisions and square root in a term's geometry instead of the hardware's reciprocal / reciprocal square root (1 ulp)."},
@@ -274,6 +275,7 @@ extern "C" int pgsgd_main_layout(int argc, char** argv) {
     p.terms_per_anchor = (uint32_t)std::max<uint64_t>(1, tpa);
     if (a.has("gpu-no-tiles")) p.flags |= PGSGD_FLAG_NO_TILES;
     if (a.has("gpu-sync-drain")) p.flags |= PGSGD_FLAG_SYNC_DRAIN;
+    if (a.has("gpu-shard-tiles")) p.flags |= PGSGD_FLAG_SHARD_TILES;
     if (a.has("gpu-exact-math")) p.flags |= PGSGD_FLAG_EXACT_MATH;
     if (a.has("gpu-no-partner-pairs")) p.flags |= PGSGD_FLAG_NO_PARTNER_PAIRS;
     if (a.has("gpu-no-relabel")) p.flags |= PGSGD_FLAG_NO_RELABEL;

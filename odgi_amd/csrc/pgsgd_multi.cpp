@@ -180,6 +180,9 @@ void rank_main(Shared& sh, int r) {
     // takes the rank's offset out of a sharded session's tile seeds.
     p.stream_offset = p0.stream_offset + (uint32_t)r * (1u << 20);
     p.n_devices = 1;
+    // (regions of 128 nodes where 256-node windows would not fill the devices: the rule then shards by region with the exact
+    // exchange; not under the test knob that forces a way of sharding on a graph of any size)
+    if (!pgsgd::debug_env("PGSGD_MULTI_SHARD")) p.flags |= pgsgd_shard_flags(N, (uint32_t)G, p.flags);
     p.snapshot = 0;  // snapshots are written by rank 0 below, from the merged coordinates
     p.progress = r == 0 ? p0.progress : 0;
     pgsgd_session* s = nullptr;

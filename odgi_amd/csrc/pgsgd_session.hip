@@ -963,6 +963,10 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // seeds each: 3.10e10 terms/s, stress 0.246 against 2.98e10, 0.255 with R = 512;
         // profiles/r01/tiles_region_256_vs_512.jsonl).  R = 128 with 256 lanes diverges.
         bool region_given = false;
+        if (p->flags & PGSGD_FLAG_REGION_128) {  // (a multi-GPU run sharded by region on a graph that 256-node windows would not fill: pgsgd_shard_flags)
+            s->region = 128;
+            s->tile_steps = 112;
+        }
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_REGION")) {  // experiment knob: region size in nodes (a multiple of 8)
             const long r = atol(e);
             if (r >= 32 && r <= 2048 && r % 8 == 0) {
@@ -1582,12 +1586,28 @@ extern "C" int64_t pgsgd_session_trace_tile_terms(pgsgd_session* s, uint64_t til
 // A sharded session's tile streams are keyed on (seed, iteration, tile, lane) only: every tile is run by exactly one
 // rank, and a rank-dependent stream_offset (which the per-lane streams of the ranks need to differ) would make rank r's
 // tile t draw the stream of rank 0's tile t + 1024 r.
+// What a multi-GPU driver adds to its sessions' flags before it creates them (include/pgsgd.h).  Measured at config 4 with virtual
+// ranks (profiles/r06/virtual_ranks_exact_small_regions_config4.jsonl), exact shard, kernels per rank and schedule at G = 1 / 2 / 4 / 8:
+// R = 256: 174.5 / 138.6 / 122.0 / 113.3 ms; R = 192: 168 / - / 92.7 / 88.6; R = 128: 190.3 / 108.4 / 85.5 / 78.9 (R = 64 diverges); the exact
+// figure of the final layout is the one-GPU one everywhere (0.2049-0.2053).  By tile: 178.4 / 99.5 / 59.6 / 41.4 ms at +7.6 / +13.9 / +20.5 %.
+extern "C" uint32_t pgsgd_shard_flags(uint64_t n_nodes, uint32_t world, uint32_t flags) {
+    if (world < 2 || (flags & (PGSGD_FLAG_NO_TILES | PGSGD_FLAG_SHARD_TILES | PGSGD_FLAG_FP32_ATOMICS | PGSGD_FLAG_HOGWILD_STORES | PGSGD_FLAG_REGION_128))) return 0;
+    const uint64_t w256 = (n_nodes + 511) / 512, w128 = (n_nodes + 255) / 256;   // windows per colour
+    if (w256 / world >= PGSGD_SHARD_FULL_WINDOWS) return 0;   // 256-node windows fill every device
+    return w128 / world >= PGSGD_SHARD_MIN_WINDOWS ? PGSGD_FLAG_REGION_128 : 0;
+}
+
 extern "C" int pgsgd_session_set_shard(pgsgd_session* s, uint32_t rank, uint32_t world, int by_region) {
     pgsgd::clear_error();
     if (!s || world == 0 || rank >= world || by_region > 2) return PGSGD_E_INVALID;
     // -1: the one rule both drivers use (pgsgd_multi.cpp and odgi_amd/distributed.py pass -1 and take what comes back).  It counts
     // WINDOWS (n_items: the session's unsplit work items per colour), not the parts a one-GPU session cuts them into.
-    if (by_region < 0) by_region = !(s->tiled && std::min(s->n_items[0], s->n_items[1]) / world >= 1000) ? 0 : s->fmt == pgsgd::kFmtQ32 ? 2 : 1;
+    if (by_region < 0) {
+        const uint64_t per_rank = s->tiled ? std::min(s->n_items[0], s->n_items[1]) / world : 0;
+        if (!s->tiled || (s->params.flags & PGSGD_FLAG_SHARD_TILES)) by_region = 0;
+        else if (s->fmt == pgsgd::kFmtQ32) by_region = per_rank >= PGSGD_SHARD_MIN_WINDOWS ? 2 : 0;   // the ranks then hold one GPU's layout bit for bit
+        else by_region = per_rank >= PGSGD_SHARD_FULL_WINDOWS ? 1 : 0;
+    }
     if (by_region == 2 && (!s->tiled || s->fmt != pgsgd::kFmtQ32)) { set_error("the exact exchange needs a tiled session with fixed-point coordinates"); return PGSGD_E_UNSUPPORTED; }
     if (world > 1 || by_region == 2) {  // a sharded session exchanges after every launch: its far pulls are delivered in front of the next one
         if (pulls_waiting(s)) { const int rc = pgsgd_session_flush(s); if (rc) return rc; }
@@ -2376,6 +2396,14 @@ extern "C" int pgsgd_session_drain_beside(pgsgd_session* s, int* on, double* dra
         if (s->drain_stream) { HIP_TRY(hipStreamSynchronize(s->drain_stream)); (void)collect_drain_events(s); }
         *drain_ms = s->drain_beside_ms;
     }
+    return PGSGD_OK;
+}
+
+// How the session's far pulls are summed (far_drain_kernel): workgroups per bucket's node range, and per (bucket, part)'s messages.
+extern "C" int pgsgd_session_drain_plan(pgsgd_session* s, uint32_t* parts, uint32_t* slices) {
+    if (!s) return PGSGD_E_INVALID;
+    if (parts) *parts = s->tiled ? 1u << (s->ob.shift - s->ob_part_shift) : 0u;
+    if (slices) *slices = s->tiled ? s->ob_slices : 0u;
     return PGSGD_OK;
 }
 

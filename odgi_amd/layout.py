@@ -320,6 +320,12 @@ class LayoutSession:
         check(lib.pgsgd_session_drain_beside(self._h, C.byref(on), C.byref(ms)), "drain_beside")
         return bool(on.value), ms.value
 
+    def drain_plan(self):
+        """(parts, slices): workgroups per bucket's node range and per (bucket, part)'s messages in far_drain_kernel."""
+        parts, slices = C.c_uint32(), C.c_uint32()
+        check(lib.pgsgd_session_drain_plan(self._h, C.byref(parts), C.byref(slices)), "drain_plan")
+        return parts.value, slices.value
+
     def probe_words(self):
         """Profiling hook: the twelve raw words of the tile kernel's probes (pgsgd_session_probe_words)."""
         out = (C.c_uint64 * 12)()
@@ -391,6 +397,13 @@ class Layout:
 
     def get_Y(self):
         return self.Y
+
+
+def shard_flags(graph: Graph, world, flags=0):
+    """Flag bits a multi-GPU driver ORs into the params of its `world` sessions before it creates them (pgsgd_shard_flags):
+    FLAG_REGION_128 where 256-node regions would leave a device fewer than a thousand windows per launch — the sessions' rule
+    (set_shard) then shards by region with the exact exchange: G ranks hold one GPU's layout bit for bit."""
+    return int(lib.pgsgd_shard_flags(int(graph.n_nodes), int(world), int(flags)))
 
 
 def weak_components(graph: Graph):

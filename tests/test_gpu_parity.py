@@ -577,18 +577,28 @@ def test_synthetic_million_node_properties(oa, orc):
     assert (info["region_nodes"], info["tile_steps"], info["n_work_items"], info["parts"]) == (256, 224, 3907, 13), info
     assert 12 * 3907 < info["n_launch_items"] <= 13 * 3907 and info["xcd_runs"]    # ... in node order, one run per XCD
     # how a multi-GPU run shards this graph is ONE rule, the session's (pgsgd_session_set_shard(.., -1)), whichever driver asks:
-    # it counts windows (1953 per colour), not the 13 parts each is cut into — regions with the exact exchange for one rank,
-    # tiles from two ranks on (976 windows per rank and colour < 1000)
+    # it counts windows (1953 per colour), not the 13 parts each is cut into — regions with the exact exchange (the ranks hold one
+    # GPU's layout bit for bit) down to 240 windows per rank and colour, i.e. up to eight ranks here (rounds 4-6 asked for a thousand
+    # and sharded this graph by tile from two ranks on: faster, +8..21 % stress — now behind PGSGD_FLAG_SHARD_TILES); the drivers
+    # create their sessions with regions of 128 nodes where 256-node windows would not fill the devices (pgsgd_shard_flags)
+    from odgi_amd import _lib as _L
     from odgi_amd._lib import lib as _l
     from odgi_amd.distributed import HipEngine
-    eng = HipEngine(g, _params(oa, g), X0, Y0)
-    try:
-        for world, want in ((1, "regions-exact"), (2, "tiles"), (8, "tiles")):
-            eng.set_shard(0, world)
-            assert eng.shard_mode == want, (world, eng.shard_mode)
-            assert _l.pgsgd_session_set_shard(eng.session._h, 0, world, -1) == {"tiles": 1, "regions": 2, "regions-exact": 3}[want]
-    finally:
-        eng.close()
+    assert [oa.shard_flags(g, w) for w in (1, 2, 4, 8)] == [0, _L.FLAG_REGION_128, _L.FLAG_REGION_128, _L.FLAG_REGION_128]
+    assert oa.shard_flags(g, 8, _L.FLAG_SHARD_TILES) == 0 and oa.shard_flags(g, 8, _L.FLAG_NO_TILES) == 0
+    assert _l.pgsgd_shard_flags(10_000_000, 8, 0) == 0 and _l.pgsgd_shard_flags(3_000_000, 8, 0) == _L.FLAG_REGION_128 and _l.pgsgd_shard_flags(100_000, 2, 0) == 0
+    for flags, wants in ((0, ((1, "regions-exact"), (2, "regions-exact"), (8, "regions-exact"), (16, "tiles"))),
+                         (_L.FLAG_REGION_128, ((8, "regions-exact"), (16, "regions-exact"))),
+                         (_L.FLAG_SHARD_TILES, ((1, "tiles"), (2, "tiles"), (8, "tiles")))):
+        eng = HipEngine(g, _params(oa, g, flags=flags), X0, Y0)
+        try:
+            assert eng.session.tile_info()["region_nodes"] == (128 if flags == _L.FLAG_REGION_128 else 256)
+            for world, want in wants:
+                eng.set_shard(0, world)
+                assert eng.shard_mode == want, (flags, world, eng.shard_mode)
+                assert _l.pgsgd_session_set_shard(eng.session._h, 0, world, -1) == {"tiles": 1, "regions": 2, "regions-exact": 3}[want]
+        finally:
+            eng.close()
 
 
 def test_step_positions_built_on_the_device(oa, monkeypatch):
@@ -1180,13 +1190,15 @@ def test_tile_sharded_virtual_ranks(oa, init):
     assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))
 
 
-@pytest.mark.parametrize("mode", ["tiles", "regions", "regions-exact"])
+@pytest.mark.parametrize("mode", ["tiles", "regions", "regions-exact", "rule"])
 def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     """The multi-GPU split at G = 1, 2, 4, 8 with G sessions on the one GPU of the test box (the exchange kernels as in
     production, the all-reduce replaced by a sum on the device), three seeds each, both ways of sharding the tile
     kernel's work: by tile (every G-th tile of every window) and by node region (every G-th window, the ranks' private
     windows disjoint).  Mean sampled stress of the merged layout against the one-rank runs'.  Measured in round 2 at
-    config 4: by tile +11 / +26 / +23 % at G = 2 / 4 / 8, by region +1 / +6 / +6 %."""
+    config 4: by tile +11 / +26 / +23 % at G = 2 / 4 / 8, by region +1 / +6 / +6 %.  `rule`: what the drivers do —
+    sessions created with pgsgd_shard_flags' bits (regions of 128 nodes at this size from two ranks on) and sharded by the session's own
+    rule, which must come out as the exact exchange: G ranks then hold one GPU's layout (here against one rank's 256-node regions)."""
     import torch
     from odgi_amd.distributed import HipEngine
     g = oa.Graph.synthetic(600_000, 24, seed=7)
@@ -1197,11 +1209,17 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     for G in (1, 2, 4, 8):
         for rep in range(3):
             X0, Y0 = oa.initial_layout(g, "d", seed=7 + rep)
-            engines = [HipEngine(g, _params(oa, g, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep, **kw), X0, Y0) for r in range(G)]
+            flags = oa.shard_flags(g, G) if mode == "rule" else 0
+            engines = [HipEngine(g, _params(oa, g, stream_offset=r * (1 << 20), seed=9399220 + 7919 * rep, flags=flags, **kw), X0, Y0) for r in range(G)]
             for r, e in enumerate(engines):
                 e.exchange_mark()
-                assert e.tiled and e.set_shard(r, G, by_region="exact" if mode == "regions-exact" else mode == "regions") and not e.warm_per_lane()
-            exact = mode == "regions-exact"
+                if mode == "rule":
+                    from odgi_amd import _lib as _L
+                    assert flags == (_L.FLAG_REGION_128 if G > 1 else 0) and e.session.tile_info()["region_nodes"] == (128 if G > 1 else 256)
+                    assert e.tiled and e.set_shard(r, G) and e.shard_mode == "regions-exact" and not e.warm_per_lane()
+                else:
+                    assert e.tiled and e.set_shard(r, G, by_region="exact" if mode == "regions-exact" else mode == "regions") and not e.warm_per_lane()
+            exact = mode in ("regions-exact", "rule")
             bufs = [e.new_exact_exchange_buffer(G) if exact else e.new_exchange_buffer() for e in engines]
 
             def exchange():
@@ -1239,9 +1257,11 @@ def test_virtual_rank_stress_band_up_to_eight_ranks(oa, mode):
     # + a margin, two-sided: a merge that made layouts BETTER than one device's would be as suspect as one that made them worse.
     # With the exact exchange the ranks compute what one GPU computes (bit for bit when the launches are sequential programs:
     # test_region_shard_with_the_exact_exchange_is_one_gpu_bit_for_bit): only the run-to-run scatter of a Hogwild launch is left.
-    band = {"tiles": {2: 1.06, 4: 1.09, 8: 1.16}, "regions": {2: 1.03, 4: 1.04, 8: 1.05}, "regions-exact": {2: 1.01, 4: 1.01, 8: 1.01}}[mode]
+    # `rule`: the ranks' regions are 128 nodes wide, the one rank's 256 (config 4, one rank: 0.20492 against 0.20529): 2 % either way.
+    band = {"tiles": {2: 1.06, 4: 1.09, 8: 1.16}, "regions": {2: 1.03, 4: 1.04, 8: 1.05}, "regions-exact": {2: 1.01, 4: 1.01, 8: 1.01},
+            "rule": {2: 1.02, 4: 1.02, 8: 1.02}}[mode]
     for G in (2, 4, 8):
-        assert 0.99 * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
+        assert (0.98 if mode == "rule" else 0.99) * means[1] <= means[G] <= band[G] * means[1], (mode, G, means)
 
 
 @pytest.mark.parametrize("G", [2, 3, 8])
@@ -1314,8 +1334,9 @@ def test_cpp_multi_gpu_run_with_two_virtual_devices(oa, graphs, graph_name, monk
     host thread and one session per device, terms split 1/G, coordinates merged after every exchange block.  The test
     box has one GPU, so both ranks run on it and the RCCL all-reduce is replaced by its host-staged stand-in
     (PGSGD_MULTI_HOST_REDUCE); everything else — threads, sharding, exchange kernels, stop rule — is the product path.
-    Tile-sharded on the sorted 300k-node graph, term-sharded with four exchanges per iteration on LPA.  Band: the
-    two-rank merge costs +5..11 % stress at this size: means of three runs within 20 %."""
+    Sharded by region with the exact exchange on the sorted 300k-node graph (128-node regions: pgsgd_shard_flags; rounds 2-6: by
+    tile, +5..11 % stress at this size), term-sharded with four exchanges per iteration on LPA.  Band: means of three runs within 20 %
+    (the sampled figure's own scatter; the exact exchange itself: test_cpp_multi_gpu_run_with_the_exact_exchange)."""
     import dataclasses
     monkeypatch.setenv("PGSGD_MULTI_HOST_REDUCE", "1")
     g = oa.Graph.synthetic(300_000, 24, seed=7) if graph_name == "synthetic-300k" else graphs(graph_name)
@@ -1329,9 +1350,13 @@ def test_cpp_multi_gpu_run_with_two_virtual_devices(oa, graphs, graph_name, monk
             st = oa.path_linear_sgd_layout_gpu(g, p, X, Y)
             assert st["iterations"] == p.iter_max and st["term_updates"] == p.iter_max * p.min_term_updates
             assert np.isfinite(X).all() and np.isfinite(Y).all()
-            res[G].append(oa.path_stress(g, X, Y, 1_000_000, seed=1))
+            # (the sorted graph by the figure without sampling error: the sampled one moves by -15 .. +27 % with its own seed on ONE layout)
+            res[G].append(_near_exact(oa, g, X, Y) if graph_name == "synthetic-300k" else oa.path_stress(g, X, Y, 1_000_000, seed=1))
     print(f"C++ multi-GPU driver, {graph_name}: stress one device {res[1]}, two virtual devices {res[2]}")
-    assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))   # measured +4.6 % (synthetic), -6 % (LPA)
+    if graph_name == "synthetic-300k":   # 128-node regions against one device's 256-node ones: measured -0.4 % (tools/gpu_region128_quality.py: -0.4 .. +1.6 %)
+        assert 0.97 * float(np.mean(res[1])) <= float(np.mean(res[2])) <= 1.04 * float(np.mean(res[1]))
+    else:
+        assert float(np.mean(res[2])) <= 1.20 * float(np.mean(res[1]))   # measured -6 .. +5 % (LPA, sampled figure)
 
 
 def test_cpp_multi_gpu_run_with_the_exact_exchange(oa, monkeypatch):
@@ -1492,7 +1517,8 @@ def _ragged_graph(oa):
 
 
 @pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages", "synthetic-split", "DRB1-3123-split",
-                                        "synthetic-drain-beside", "DRB1-3123-drain-beside", "synthetic-narrow-messages-drain-beside"])
+                                        "synthetic-drain-beside", "DRB1-3123-drain-beside", "synthetic-narrow-messages-drain-beside",
+                                        "synthetic-drain-parts", "DRB1-3123-drain-parts", "synthetic-narrow-messages-drain-parts"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
@@ -1505,8 +1531,13 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     the same item list.  `-drain-beside`: the session sums every launch's far pulls on a second stream beside the NEXT launch and
     delivers them before the same colour's next launch from the sixth iteration on (what sessions of 30 iterations and more do; forced
     here on nine); the mirror
-    keeps one outbox per colour and delivers in that order (ORC_TILE_DRAIN_BESIDE)."""
-    split, policy = 1, 0
+    keeps one outbox per colour and delivers in that order (ORC_TILE_DRAIN_BESIDE).  `-drain-parts`: a bucket's node range in eight parts,
+    one drain workgroup each, as beyond 2.1e6 nodes (every part looks at every message of the bucket and keeps its own; the parts' sums
+    in slices, added by far_combine_kernel) — the same sums."""
+    split, policy, parts = 1, 0, 1
+    if graph_name.endswith("-drain-parts"):
+        monkeypatch.setenv("PGSGD_OUTBOX_PART_SHIFT", "10")
+        graph_name, parts = graph_name[:-12], 8
     if graph_name.endswith("-drain-beside"):
         monkeypatch.setenv("PGSGD_ASYNC_DRAIN", "1")
         graph_name, policy = graph_name[:-13], orc.TILE_DRAIN_BESIDE
@@ -1534,6 +1565,7 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
         info, tiles, items = s.tile_info(), s.tile_table(), s.tile_items()
         assert info["tiled"] and info["region_nodes"] == 64 and s.n_streams == 64 and not info["fast_math"]
         assert s.drain_beside()[0] == bool(policy)
+        assert s.drain_plan()[0] == parts
         assert (info["n_nonlocal_tiles"] == 0) == (graph_name != "DRB1-3123")
         assert len(items["local"]) == info["n_launch_items"] and int((items["local"] == 0).sum()) == info["n_nonlocal_tiles"]
         assert info["parts"] == split and (len(items["local"]) > info["n_work_items"]) == (split > 1)
