@@ -165,7 +165,7 @@ struct pgsgd_session {
     uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
     float tile_far_relax_max = 0.0f, tile_far_relax_slope = 0.0f;   // debug knobs PGSGD_TILE_FAR_RELAX_MAX / _SLOPE: min(max, slope * iteration) after the two gentle iterations
     float tile_far_relax_override = 0.0f;  // debug knob PGSGD_TILE_FAR_RELAX: a constant under-relaxation of the far pulls instead of tile_far_relax()
-    uint32_t tile_wq_threshold = 64;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once)
+    uint32_t tile_wq_threshold = 64 * pgsgd::kWqPush;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once; 64: one message per lane and call, as until round 6's third session)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
     // kernel timing: e[0..1] bracket the update kernel; a tile launch also has e[2] (before the drain of the launch
@@ -1019,7 +1019,7 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         if (const char* e = pgsgd::debug_env("PGSGD_TILE_FAR_RELAX")) s->tile_far_relax_override = (float)std::min(1.0, std::max(0.0, atof(e)));
         if (s->tile_pair_uniform && pgsgd::debug_env("PGSGD_TILE_PAIRS")) s->tile_pair_uniform = 1;  // A/B knob: the partner pairs of rounds 4-6 (oracle: ORC_TILE_PAIRS)
         if (s->tile_lane_coin) s->tile_pair_uniform = 0;  // (pairs need the wave's lanes on one partner path: an odd lane reads its even neighbour's draw)
-        if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min(64, std::max(1, atoi(e)));
+        if (const char* e = pgsgd::debug_env("PGSGD_TILE_WQ")) s->tile_wq_threshold = (uint32_t)std::min<int>(64 * pgsgd::kWqPush, std::max(1, atoi(e)));
         // the tile kernel converts path distances through fp64 (term_displacement<true>): positions must stay below 2^52
         bool short_paths = true, paths_32 = true;  // (the fast instance keeps positions as 32-bit words: every path shorter than 2^32 bp)
         for (uint64_t q = 0; q < g->n_paths && short_paths; ++q)
@@ -2038,7 +2038,7 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
-            ta.wq_threshold = s->tile_wq_threshold;
+            ta.wq_threshold = std::min<uint32_t>(s->tile_wq_threshold, 64u * pgsgd::tile_push_messages(a.cooling != 0));   // (one message per lane and call in a cooling launch, two in a warm one)
             ta.lane_coin = s->tile_lane_coin;
             ta.snap_every = s->tile_snap_every;
             ta.tile_rotate = s->tile_rotate;

@@ -175,7 +175,7 @@ struct TileArgs {
     float lock_mu;                     // conflict resolution inside a window: terms whose learning rate mu reaches this take both their ends' locks or do nothing (0: off)
     uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
-    uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 (one per lane); debug knob PGSGD_TILE_WQ
+    uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 * kWqPush (kWqPush per lane); debug knob PGSGD_TILE_WQ
     unsigned long long* term_count;    // terms this session's tile launches have executed (cumulative; every wave adds what its lanes finished): pgsgd_session_terms_executed
     uint32_t tile_rotate;              // debug knob PGSGD_TILE_ROTATE: an item's tiles start at another one every iteration (which path has the last word on a window)
     Outbox ob;
@@ -233,9 +233,16 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 // A term appends its message there — a ballot, a prefix count and two LDS stores, the fill count lives in a scalar
 // register — and the ring protocol below runs only when 64 messages are waiting, one per lane: its cost does not depend
 // on how many lanes take part (about a hundred vector instructions per call), and in most iterations only a third of the
-// lanes have a message per trip (a step that rounds to no quantum sends nothing).
+// lanes have a message per trip (a step that rounds to no quantum sends nothing).  Since round 6's third session a WARM launch
+// waits for 128 and hands the rings TWO messages per lane and call (outbox_push<2>): the protocol's cost is its chain of dependent
+// LDS round trips, every round trip then carries both messages, and a wave calls half as often — warm launches +2 ... 3.5 %, the
+// driver's window 0.668-0.673 -> 0.680-0.681 on one box (profiles/r06/push2_ab.jsonl); a cooling launch, whose messages go to the two
+// hot rings, keeps one (with two its waves wait for each other's lines there).  The queue grew by 64 entries per wave for it and
+// the list of completed lines moved INTO the queue (the entries a call has just taken): 30 848 bytes of LDS per workgroup, five per CU.
 constexpr uint32_t kObStateShift = 4;                 // (kObLine = 8 slots < 1 << 4)
-constexpr uint32_t kWqCap = 128;                      // fewer than 64 waiting + at most 64 appended per call
+constexpr uint32_t kWqPush = 2;                       // most messages a lane hands to the rings in one call of their protocol (outbox_push<K>: the warm
+                                                      // instance 2, the cooling instance 1)
+constexpr uint32_t kWqCap = 64 * (kWqPush + 1);       // fewer than 64 * kWqPush waiting + at most 64 appended per call
 // The arrays follow one another behind the tile records; the struct keeps their common base as a byte offset into the
 // workgroup's LDS and works the others out where they are used (a few scalar operations in the rings' protocol, which
 // runs once per 64 messages of a wave) instead of holding eight pointers in scalar registers across the term loop.
@@ -256,11 +263,10 @@ struct OutboxLds {
     // [waves][kWqCap] the waves' private queues: packed messages ...
     __device__ __forceinline__ uint32_t wq_msg_off() const { return lines() * kObLine * 8u; }
     __device__ __forceinline__ uint64_t* wq_msg() const { return ptr<uint64_t>(at(wq_msg_off())); }
-    // [waves][64] lines completed in one round of one wave: {staged line, global line index}
-    __device__ __forceinline__ uint32_t list_off() const { return wq_msg_off() + kTileWaves * kWqCap * 8u; }
-    __device__ __forceinline__ uint2* list() const { return ptr<uint2>(at(list_off())); }
+    // (the lines completed in one round of one wave — {staged line, global line index} — are listed in the part of the wave's queue
+    // the round's messages were taken from: no array of their own)
     // [B + kObRings] slots claimed
-    __device__ __forceinline__ uint32_t head_off() const { return list_off() + kTileWaves * 64u * 8u; }
+    __device__ __forceinline__ uint32_t head_off() const { return wq_msg_off() + kTileWaves * kWqCap * 8u; }
     __device__ __forceinline__ uint32_t* head() const { return ptr<uint32_t>(at(head_off())); }
     // [B + kObRings * kObRingLines] per line: (rounds completed << kObStateShift) | slots written
     __device__ __forceinline__ uint32_t state_off() const { return head_off() + (n_buckets + kObRings) * 4u; }
@@ -279,7 +285,7 @@ struct OutboxLds {
 __host__ __device__ inline uint32_t tile_lock_words(uint32_t region) { return (4u * region + 31u) / 32u; }
 __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
     const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
-    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * 64 * sizeof(uint2) + (size_t)kTileWaves * kWqCap * (sizeof(uint64_t) + 1) +
+    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * kWqCap * (sizeof(uint64_t) + 1) +
            ((size_t)n_buckets + kObRings + lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
 }
 
@@ -287,21 +293,21 @@ __host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
 // lanes may ask for lines of one bucket at once (two lines of a ring completed in the same round): lines are claimed
 // with an LDS atomic; the lane that claims line kObLinesPerGroup replaces the group, the others wait for it without
 // adding to the word (every lane strays at most once per replacement, so the 10-bit field cannot overflow).
-__device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b) {
+// (`c0` = L.chunk0()[b] and `first` = the value a caller's own atomicAdd(L.line() + b, 1) returned: a caller with several lines to
+// place issues all those LDS requests before it waits for any)
+__device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b, uint32_t c0, uint32_t first) {
     // (No spin loop of its own for a lane that finds the group being replaced: the replacing lane may be in the same
     // wave, and a wave runs the two sides of a branch one after the other — a lane spinning in an inner loop would
     // wait for a lane that is not running.  The poll sits at the top of the one loop instead: every lane still in it
     // reaches the loop's end before any starts the next pass, and the replacing lane finishes within its pass.)
-    bool strayed = false;
-    // (read BEFORE the claim it does not depend on: the two LDS requests then travel together — one round trip of the rings'
-    // protocol less per call, whose cost is its chain of dependent LDS round trips, profiles/r06/NOTES.md section 9)
-    const uint32_t c0 = L.chunk0()[b];
+    bool strayed = false, have = true;
     for (;;) {
-        if (strayed && (__hip_atomic_load(L.line() + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
+        if (!have && strayed && (__hip_atomic_load(L.line() + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kObUsedMask) > kObLinesPerGroup) {
             __builtin_amdgcn_s_sleep(1);  // still being replaced (by a lane of another wave)
             continue;
         }
-        const uint32_t lp = atomicAdd(L.line() + b, 1u);
+        const uint32_t lp = have ? first : atomicAdd(L.line() + b, 1u);
+        have = false;
         const uint32_t chunk = lp >> kObUsedBits, used = lp & kObUsedMask;  // first chunk of the group, lines claimed in the group
         if (used < kObLinesPerGroup && chunk < kObOverflow) return (c0 + chunk) * kObLinesPerChunk + used;  // the group's chunks are consecutive
         if (chunk == kObOverflow) {  // the bucket's share of the pool is used up (sticky; the count field is put back so that it cannot run over)
@@ -323,48 +329,84 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
     }
 }
 
-// Stage one packed message per lane that has one (bucket b), writing out every line this completes.  Called by all 64
-// lanes of a wave together (converged).
-__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, bool has, uint32_t b, uint64_t packed) {
-    if (!__ballot(has)) return;
+__device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const OutboxLds& L, uint32_t b) {
+    // (the read BEFORE the claim it does not depend on: the two LDS requests travel together)
+    const uint32_t c0 = L.chunk0()[b];
+    return outbox_next_line(ob, L, b, c0, atomicAdd(L.line() + b, 1u));
+}
+
+// Stage up to kWqPush packed messages per lane (message k of the lane: has[k], bucket b[k]), writing out every line this completes.
+// Called by all 64 lanes of a wave together (converged).  The protocol's cost is its chain of dependent LDS round trips — claim, line
+// state, slot write + count, the completed lines' places in the pool, their list, their words — not its instructions
+// (profiles/r06/NOTES.md sections 9, 15): with two messages per lane every round trip carries both, and a wave calls half as often.
+__host__ __device__ constexpr uint32_t tile_push_messages(bool cooling) { return cooling ? 1u : kWqPush; }
+template <uint32_t K>
+__device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, uint2* list, const bool (&has_in)[K], const uint32_t (&b)[K], const uint64_t (&packed)[K]) {
+    static_assert((K == 1 || K == 2) && K <= kWqPush && kObRings == 2, "the claims below are written for one or two messages per lane and two hot rings");
+    constexpr uint32_t k1 = K - 1;   // the lane's last message (= its first when K == 1: the second's code then folds away)
+    if (!__ballot(has_in[0] || has_in[k1])) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint32_t r = b - L.ring_b0;  // hot ring of the bucket, if it has one
-    const bool hot = has && r < kObRings;
+    auto rank_in = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };  // lanes below this one in the mask
     // claim a slot: the hot rings with one LDS instruction per wave (lane rr claims for ring rr what the wave's lanes
-    // need of it), ordinary buckets with one atomic per lane
-    static_assert(kObRings == 2, "the claim below is written for two hot rings");
-    uint32_t slot = 0;
-    if (has && !hot) slot = atomicAdd(L.head() + b, 1u);   // (issued before the hot claim below is waited for: the two travel together)
-    const uint64_t m0 = __ballot(hot && r == 0), m1 = __ballot(hot && r == 1);
-    if (m0 | m1) {  // wave-uniform
-        const uint32_t want = lane == 0 ? (uint32_t)__popcll(m0) : (uint32_t)__popcll(m1);
+    // need of it), ordinary buckets with one atomic per message — all of them issued before any is waited for
+    uint32_t slot[K] = {}, r[K];
+    bool hot[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        r[k] = b[k] - L.ring_b0;  // hot ring of the bucket, if it has one
+        hot[k] = has_in[k] && r[k] < kObRings;
+        if (has_in[k] && !hot[k]) slot[k] = atomicAdd(L.head() + b[k], 1u);
+    }
+    const uint64_t m00 = __ballot(hot[0] && r[0] == 0), m01 = __ballot(hot[0] && r[0] == 1);
+    const uint64_t m10 = K > 1 ? __ballot(hot[k1] && r[k1] == 0) : 0ull, m11 = K > 1 ? __ballot(hot[k1] && r[k1] == 1) : 0ull;
+    if (m00 | m01 | m10 | m11) {  // wave-uniform
+        const uint32_t n00 = (uint32_t)__popcll(m00), n01 = (uint32_t)__popcll(m01);
+        const uint32_t want = lane == 0 ? n00 + (uint32_t)__popcll(m10) : n01 + (uint32_t)__popcll(m11);
         uint32_t base = 0;
         if (lane < kObRings && want) base = atomicAdd(L.head() + L.n_buckets + lane, want);
         const uint32_t base0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), base1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
-        const uint32_t rank0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));  // lanes below this one in the mask
-        const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-        if (hot) slot = r == 0 ? base0 + rank0 : base1 + rank1;
+        if (hot[0]) slot[0] = r[0] == 0 ? base0 + rank_in(m00) : base1 + rank_in(m01);
+        if (K > 1 && hot[k1]) slot[k1] = r[k1] == 0 ? base0 + n00 + rank_in(m10) : base1 + n01 + rank_in(m11);
     }
-    const uint32_t lines_log2 = hot ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
-    const uint32_t src = (hot ? L.n_buckets + r * kObRingLines : b) + ((slot >> kObLineLog2) & ((1u << lines_log2) - 1u));  // staged line of the slot
-    const uint32_t round = slot >> (kObLineLog2 + lines_log2);
-    uint2* list = L.list() + (threadIdx.x >> 6) * 64;
-    bool pending = has;
+    uint32_t src[K], round[K];
+    bool pending[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t lines_log2 = hot[k] ? kObRingLinesLog2 : 0u;  // (shifts and masks: a ring's line count is a power of two)
+        src[k] = (hot[k] ? L.n_buckets + r[k] * kObRingLines : b[k]) + ((slot[k] >> kObLineLog2) & ((1u << lines_log2) - 1u));  // staged line of the slot
+        round[k] = slot[k] >> (kObLineLog2 + lines_log2);
+        pending[k] = has_in[k];
+    }
+    bool defer = false;   // the lane's two messages completed a line each in one pass: the second line goes out in the next pass
     do {
-        bool completes = false;
-        // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out)
-        if (pending && (__hip_atomic_load(L.state() + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> kObStateShift) == (round & (0xffffffffu >> kObStateShift))) {
-            L.stage()[src * kObLine + slot % kObLine] = packed;
-            pending = false;
-            completes = ((atomicAdd(L.state() + src, 1u) + 1u) & ((1u << kObStateShift) - 1u)) == kObLine;  // the last of the line's writers writes it out
-        } else if (pending) {
-            __builtin_amdgcn_s_sleep(2);  // waiting for another wave to write a line out: leave it the issue slots
-        }
+        // the line must be back from its previous round (it is, unless every slot of the ring is claimed and not yet out — or the lane's
+        // other message holds the slot in front of it in the same line: that one goes out in this pass, this one in the next)
+        uint32_t st[K] = {};
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k)
+            if (pending[k]) st[k] = __hip_atomic_load(L.state() + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool wrote[K] = {};
+        uint32_t cnt[K] = {};
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k)
+            if (pending[k] && (st[k] >> kObStateShift) == (round[k] & (0xffffffffu >> kObStateShift))) {
+                L.stage()[src[k] * kObLine + slot[k] % kObLine] = packed[k];
+                pending[k] = false;
+                wrote[k] = true;
+                cnt[k] = atomicAdd(L.state() + src[k], 1u);
+            }
+        const bool comp0 = wrote[0] && ((cnt[0] + 1u) & ((1u << kObStateShift) - 1u)) == kObLine;  // the last of a line's writers writes it out
+        const bool comp1 = K > 1 && (defer || (wrote[k1] && ((cnt[k1] + 1u) & ((1u << kObStateShift) - 1u)) == kObLine));
+        if ((pending[0] || pending[k1]) && !(wrote[0] || wrote[k1])) __builtin_amdgcn_s_sleep(2);  // waiting for another wave to write a line out: leave it the issue slots
+        // one completed line per lane and pass (two at once are rare: one time in 64)
+        const bool completes = comp0 || comp1;
+        defer = comp0 && comp1;
+        const uint32_t csrc = comp0 ? src[0] : src[k1], cb = comp0 ? b[0] : b[k1], cround = comp0 ? round[0] : round[k1];
         const uint64_t mask = __ballot(completes);
-        if (mask) {  // wave-uniform: the lines completed in this round, kObLine lanes per line
-            const uint32_t dst = completes ? outbox_next_line(ob, L, b) : 0u;
-            if (completes) list[__popcll(mask & below)] = make_uint2(src, dst);
+        if (mask) {  // wave-uniform: the lines completed in this pass, kObLine lanes per line
+            const uint32_t dst = completes ? outbox_next_line(ob, L, cb) : 0u;
+            if (completes) list[__popcll(mask & below)] = make_uint2(csrc, dst);
             // the wave's LDS operations execute in order; keep the compiler from moving the reads below above the writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -390,9 +432,9 @@ __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
             if (completes)  // reopen the line for its next round
-                __hip_atomic_store(L.state() + src, (round + 1u) << kObStateShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(L.state() + csrc, (cround + 1u) << kObStateShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    } while (__ballot(pending));
+    } while (__ballot(pending[0] || pending[k1] || defer));
 }
 
 // A wave's private message queue in front of outbox_push (see OutboxLds).  `n` is the wave's fill count: wave-uniform,
@@ -417,20 +459,32 @@ __device__ __forceinline__ void wq_append(const Outbox& ob, const WaveQueue& q, 
     }
     n += (uint32_t)__popcll(m);
 }
-// hand the last min(n, 64) queued messages to the rings, one per lane (the wave's LDS operations execute in order: what
-// wq_append stored is what this reads)
+// hand the last min(n, 64 * K) queued messages to the rings, K per lane (the wave's LDS operations execute in order: what
+// wq_append stored is what this reads).  The part of the queue they are taken from is free from then on: the rings' protocol lists the
+// lines it completes there.
+template <uint32_t K>
 __device__ __forceinline__ void wq_push(const Outbox& ob, const OutboxLds& L, const WaveQueue& q, uint32_t& n) {
-    const uint32_t take = n < 64u ? n : 64u, lane = threadIdx.x & 63u;
-    const bool has = lane < take;
-    const uint32_t idx = n - take + lane;
-    uint64_t packed = 0;
-    uint32_t b = 0;
-    if (has) {
-        packed = q.msg[idx];
-        b = q.b[idx];
+    const uint32_t take = n < 64u * K ? n : 64u * K, lane = threadIdx.x & 63u;
+    const uint32_t first = n - take;
+    bool has[K];
+    uint64_t packed[K];
+    uint32_t b[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        has[k] = 64u * k + lane < take;
+        packed[k] = 0;
+        b[k] = 0;
+        if (has[k]) {
+            packed[k] = q.msg[first + 64u * k + lane];
+            b[k] = q.b[first + 64u * k + lane];
+        }
     }
     n -= take;
-    outbox_push(ob, L, has, b, packed);
+    // (the messages are in registers before the list is written over them)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    outbox_push<K>(ob, L, reinterpret_cast<uint2*>(q.msg + first), has, b, packed);
 }
 
 // Write out the partly filled line of every ring in [first, first + count) (ring index: bucket, or n_buckets + r for a
@@ -704,6 +758,10 @@ struct PendingTerm {
 template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     static_assert(COORD_LOAD == 1, "the tile kernel stages windows with agent-scope loads: a part of a window may have been written by another workgroup of this launch");
+    // Messages a lane hands to the rings per call of their protocol (tile_push_messages): two in a warm launch — every uniform term sends one, scattered over
+    // all buckets, and half as many calls buy 3.5 % of the launch — one in a cooling launch, whose messages go to the two hot rings at the window
+    // and wait for each other's lines there when a call brings 128 (measured: -0.7 %; profiles/r06/NOTES.md section 15).
+    constexpr uint32_t kPush = tile_push_messages(COOLING);
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
     uint4* trec = reinterpret_cast<uint4*>(lds + 4 * (size_t)ta.region);         // [T] tile records
@@ -1083,10 +1141,10 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
             // messages wait in the wave's queue; the rings' protocol runs when 64 are there, one per lane
             auto send = [&](const FarMessages m) {
                 wq_append(ta.ob, wq, wq_n, m.to_b, m.end_b, m.qx, m.qy);
-                if (wq_n >= ta.wq_threshold) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }  // 3 messages are queued but never leave the wave's queue,
+                if (wq_n >= ta.wq_threshold) { if (ABL == 3) wq_n = 0; else wq_push<kPush>(ta.ob, L, wq, wq_n); }  // 3 messages are queued but never leave the wave's queue,
                 if (!LOCAL) {
                     wq_append(ta.ob, wq, wq_n, m.to_a, m.end_a, -m.qx, -m.qy);
-                    if (wq_n >= ta.wq_threshold) wq_push(ta.ob, L, wq, wq_n);
+                    if (wq_n >= ta.wq_threshold) wq_push<kPush>(ta.ob, L, wq, wq_n);
                 }
             };
             if (ABL == 5) { const uint64_t now = wall_clock64(); ph[1] += now - ph_t; ph_t = now; }
@@ -1152,7 +1210,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     }
     // what still waits in the waves' queues, then the partly filled lines (the hot rings' too: the last pushes may have used them);
     // close the chunks this workgroup still has open
-    while (wq_n) { if (ABL == 3) wq_n = 0; else wq_push(ta.ob, L, wq, wq_n); }
+    while (wq_n) { if (ABL == 3) wq_n = 0; else wq_push<kPush>(ta.ob, L, wq, wq_n); }
     __syncthreads();
     outbox_flush_rings(ta.ob, L, 0, L.n_buckets + kObRings);
     for (uint32_t b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {

@@ -11,8 +11,10 @@ window write-back), and everything.  Shares of the last colour's launch of the l
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import odgi_amd as oa
-g = oa.Graph.synthetic(1_000_000, 50, seed=42)
-p = oa.LayoutParams.defaults(g)
+# gpu_tile_phases.py [NODES [FLAGS]]: another size (300000: a launch of 586 windows on 1 280 workgroup slots — the under-occupied
+# regime of mid-sized graphs and of multi-GPU ranks), extra PGSGD_FLAG_* bits (0x40000: 128-node regions)
+g = oa.Graph.synthetic(int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000, 50, seed=42)
+p = oa.LayoutParams.defaults(g, flags=int(sys.argv[2], 0) if len(sys.argv) > 2 else 0)
 X0, Y0 = oa.initial_layout(g, "d", seed=42)
 etas = oa.path_linear_sgd_layout_schedule(p)
 with oa.LayoutSession(g, p) as s:
