@@ -1518,7 +1518,8 @@ def _ragged_graph(oa):
 
 @pytest.mark.parametrize("graph_name", ["synthetic", "DRB1-3123", "ragged", "synthetic-narrow-messages", "synthetic-split", "DRB1-3123-split",
                                         "synthetic-drain-beside", "DRB1-3123-drain-beside", "synthetic-narrow-messages-drain-beside",
-                                        "synthetic-drain-parts", "DRB1-3123-drain-parts", "synthetic-narrow-messages-drain-parts"])
+                                        "synthetic-drain-parts", "DRB1-3123-drain-parts", "synthetic-narrow-messages-drain-parts",
+                                        "synthetic-wq-96", "DRB1-3123-wq-1"])
 def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, orc, graphs, graph_name, monkeypatch):
     """The tile kernel run by one workgroup with one lane per tile is a sequential program (work items in queue
     order, terms in term order), so the GPU must reproduce the oracle's mirror of it bit for bit: window
@@ -1533,8 +1534,13 @@ def test_tile_kernel_one_workgroup_one_lane_is_bit_exact_with_oracle_mirror(oa, 
     here on nine); the mirror
     keeps one outbox per colour and delivers in that order (ORC_TILE_DRAIN_BESIDE).  `-drain-parts`: a bucket's node range in eight parts,
     one drain workgroup each, as beyond 2.1e6 nodes (every part looks at every message of the bucket and keeps its own; the parts' sums
-    in slices, added by far_combine_kernel) — the same sums."""
+    in slices, added by far_combine_kernel) — the same sums.
+    `-wq-N`: a wave's queue goes to the rings when N messages wait (default: 128 in a warm launch — two per lane and call of the rings'
+    protocol — 64 in a cooling one): 96 leaves the lanes' second messages half empty, 1 sends every message at once."""
     split, policy, parts = 1, 0, 1
+    if "-wq-" in graph_name:
+        graph_name, wq = graph_name.rsplit("-wq-", 1)
+        monkeypatch.setenv("PGSGD_TILE_WQ", wq)
     if graph_name.endswith("-drain-parts"):
         monkeypatch.setenv("PGSGD_OUTBOX_PART_SHIFT", "10")
         graph_name, parts = graph_name[:-12], 8
