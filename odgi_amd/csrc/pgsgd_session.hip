@@ -156,7 +156,8 @@ struct pgsgd_session {
     uint32_t* d_queue = nullptr;          // [3][kItemQueues] work-item counters: colour 0, colour 1, colour 0's window-less items
     uint64_t tile_steps_total = 0;
     uint64_t n_tiles = 0, n_nonlocal_tiles = 0;
-    size_t tile_lds = 0;
+    size_t tile_lds = 0;                  // LDS of a workgroup of the session's warm windowed instance (sgd_tile_kernel<.., PUSH = tile_push>)
+    size_t tile_lds1 = 0;                 // ... of every other instance (PUSH = 1: cooling launches, window-less tiles, the lock instance)
     int tile_far = 0;  // pgsgd::kFarTwoSided / kFarExclusive
     uint32_t tile_pair_uniform = 1;   // TileArgs::pair_uniform (0: PGSGD_FLAG_NO_PARTNER_PAIRS)
     float tile_lock_mu = 0.0f;        // TileArgs::lock_mu (debug knob PGSGD_TILE_LOCK_MU)
@@ -165,6 +166,7 @@ struct pgsgd_session {
     uint32_t tile_lane_coin = 0;      // debug knob PGSGD_TILE_LANE_COIN
     float tile_far_relax_max = 0.0f, tile_far_relax_slope = 0.0f;   // debug knobs PGSGD_TILE_FAR_RELAX_MAX / _SLOPE: min(max, slope * iteration) after the two gentle iterations
     float tile_far_relax_override = 0.0f;  // debug knob PGSGD_TILE_FAR_RELAX: a constant under-relaxation of the far pulls instead of tile_far_relax()
+    uint32_t tile_push = 1;           // messages a lane hands to the rings per call of their protocol in a WARM launch (sgd_tile_kernel<.., PUSH>): 2 where the longer queues cost no workgroup per CU
     uint32_t tile_wq_threshold = 64 * pgsgd::kWqPush;  // TileArgs::wq_threshold (debug knob PGSGD_TILE_WQ: 1 = every message goes to the rings at once; 64: one message per lane and call, as until round 6's third session)
     int tile_math = 1; // pgsgd::kMathFast / kMathExact (PGSGD_FLAG_EXACT_MATH, or a path of 2^32 bp or more)
     uint32_t tile_grid = 0;
@@ -370,23 +372,24 @@ struct HostTiles {
 
 typedef void (*tile_kernel_t)(pgsgd::DevConst, pgsgd::TileArgs, pgsgd::TileSampler, pgsgd::IterArgs);
 template <int FAR, int MATH>
-static tile_kernel_t tile_kernel_f(bool cooling, bool local) {
+static tile_kernel_t tile_kernel_f(bool cooling, bool local, bool push2) {
     using namespace pgsgd;
 #ifndef PGSGD_TILE_ABL
 #define PGSGD_TILE_ABL 0   // experiment builds (make libpgsgd_x<N>.so): a profiling instance of the windowed tile kernel, results invalid
 #endif
-    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH, false, PGSGD_TILE_ABL> : sgd_tile_kernel<1, FAR, false, true, MATH, false, PGSGD_TILE_ABL>;
+    if (local) return cooling ? sgd_tile_kernel<1, FAR, true, true, MATH, false, PGSGD_TILE_ABL> : push2 ? sgd_tile_kernel<1, FAR, false, true, MATH, false, PGSGD_TILE_ABL, 2> : sgd_tile_kernel<1, FAR, false, true, MATH, false, PGSGD_TILE_ABL>;
     return cooling ? sgd_tile_kernel<1, FAR, true, false, MATH> : sgd_tile_kernel<1, FAR, false, false, MATH>;
 }
 // math: pgsgd::kMathFast (what sessions run) or kMathExact (PGSGD_FLAG_EXACT_MATH, paths of 2^32 bp and more); lock: the
 // instance with conflict resolution on the window ends (PGSGD_FLAG_LOCK_WINDOW_ENDS: two-sided far rule, fast math, windowed items)
-static tile_kernel_t tile_kernel(int far, int math, bool cooling = false, bool local = true, bool lock = false) {
+// push2: the warm windowed instance that hands the rings two messages per lane and call (pgsgd_session::tile_push)
+static tile_kernel_t tile_kernel(int far, int math, bool cooling = false, bool local = true, bool lock = false, bool push2 = false) {
     using namespace pgsgd;
     if (lock && local && far == kFarTwoSided && math == kMathFast)
         return cooling ? sgd_tile_kernel<1, kFarTwoSided, true, true, kMathFast, true> : sgd_tile_kernel<1, kFarTwoSided, false, true, kMathFast, true>;
     if (math == pgsgd::kMathExact)
-        return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathExact>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathExact>(cooling, local);
-    return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathFast>(cooling, local) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathFast>(cooling, local);
+        return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathExact>(cooling, local, push2) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathExact>(cooling, local, push2);
+    return far == pgsgd::kFarExclusive ? tile_kernel_f<pgsgd::kFarExclusive, pgsgd::kMathFast>(cooling, local, push2) : tile_kernel_f<pgsgd::kFarTwoSided, pgsgd::kMathFast>(cooling, local, push2);
 }
 
 struct RawTile { uint64_t t0; uint32_t n, path, rmin, rmax, maxmult; };
@@ -986,10 +989,26 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
             if (b >= 64 && b <= pgsgd::kTileBlock && b % 64 == 0) s->tile_block = (uint32_t)b;
         }
         const uint64_t cap = 2 * s->n_steps / std::max<uint64_t>(1, s->max_node_steps);
-        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
-        int bpc = 0;
-        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, s->tile_lds));
+        // LDS of a workgroup: the window, the tile's records, the outbox (staged lines, the waves' queues, counters), the lock bits.  The warm
+        // launches hand the rings TWO messages per lane and call (sgd_tile_kernel<.., PUSH = 2>: 64 more queue entries per wave) where that
+        // does not cost the session a workgroup per CU — config 4: 30 848 bytes, five per CU either way; 1e7 nodes (153 buckets): 33 240
+        // bytes would be four per CU where 30 936 are five, and the fifth workgroup is worth more than the halved calls (+6.7 % against
+        // +2 ... 3.5 % of a warm launch) — debug knob PGSGD_TILE_PUSH=1 / 2: one / two whatever it costs.
+        auto tile_lds_for = [&](uint32_t push) {
+            return (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets, pgsgd::tile_wq_cap(push)) +
+                   pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
+        };
+        int bpc = 0, bpc2 = 0;
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast), (int)s->tile_block, tile_lds_for(1)));
+        S_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc2, tile_kernel(pgsgd::kFarTwoSided, pgsgd::kMathFast, false, true, false, true), (int)s->tile_block, tile_lds_for(2)));
         if (bpc < 1) bpc = 1;
+        {
+            const char* e = pgsgd::debug_env("PGSGD_TILE_PUSH");
+            s->tile_push = e ? (atoi(e) == 2 ? 2u : 1u) : bpc2 >= bpc ? 2u : 1u;
+            if (s->tile_push == 2) bpc = std::max(1, bpc2);
+        }
+        s->tile_lds = tile_lds_for(s->tile_push);
+        s->tile_lds1 = tile_lds_for(1);
         // the hottest node must leave room for at least four workgroups per CU (the occupancy the kernel
         // was validated at); between that and full residency the grid is cut to the hot-node cap
         const uint64_t cu_lanes = (uint64_t)prop.multiProcessorCount * s->tile_block;
@@ -999,7 +1018,8 @@ extern "C" int pgsgd_session_create(const pgsgd_graph_view* g, const pgsgd_param
         // pointless: build_launch_items.  Measured with those, five workgroups per CU: R = 248 / 256 / 264 / 272 / 288 ->
         // 0.636 / 0.634 / 0.623 / 0.618 / 0.600.)
         if (!region_given && steps_given >= 16 && steps_given <= (long)s->region) s->tile_steps = (uint32_t)steps_given;
-        s->tile_lds = (size_t)4 * s->region * sizeof(uint64_t) + (size_t)s->tile_steps * sizeof(uint4) + pgsgd::outbox_lds_bytes(s->ob.n_buckets) + pgsgd::tile_lock_words(s->region) * sizeof(uint32_t);
+        s->tile_lds = tile_lds_for(s->tile_push);
+        s->tile_lds1 = tile_lds_for(1);
         // parity knobs: PGSGD_TILE_FORCE=1 runs the tile kernel on a graph of any shape, PGSGD_TILE_GRID and
         // PGSGD_TILE_LANES bound the workgroups of a launch and the lanes of a tile.  One workgroup with one
         // lane is a sequential program that the oracle mirrors bit for bit (tests/test_gpu_parity.py).
@@ -2038,7 +2058,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             ta.far_count = s->d_far + 2 * colour + (launches & 1u);
             ta.recs2 = s->d_recs2;
             ta.seed_base = s->tile_seed_base;
-            ta.wq_threshold = std::min<uint32_t>(s->tile_wq_threshold, 64u * pgsgd::tile_push_messages(a.cooling != 0));   // (one message per lane and call in a cooling launch, two in a warm one)
+            // (64 per message a lane of the launched instance hands over in one call: two only in the warm windowed instance without locks)
+            const bool push2 = s->tile_push == 2 && !a.cooling && !(s->tile_lock_mu > 0.0f);
+            ta.wq_threshold = std::min<uint32_t>(s->tile_wq_threshold, push2 ? 128u : 64u);   // (one message per lane and call in a cooling launch, two in a warm one)
             ta.lane_coin = s->tile_lane_coin;
             ta.snap_every = s->tile_snap_every;
             ta.tile_rotate = s->tile_rotate;
@@ -2099,7 +2121,9 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
             }
             HIP_TRY(hipEventRecord(ev.e[0], s->stream));
             if (ta.n_items) {
-                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, true, s->tile_lock_mu > 0.0f), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                // (the warm instance of a session with two messages per lane and call has the longer wave queues: its launches bring the LDS for them)
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, true, s->tile_lock_mu > 0.0f, push2), dim3(s->tile_grid), dim3(s->tile_block),
+                                   push2 ? s->tile_lds : s->tile_lds1, s->stream,
                                    s->dc, ta, ts, a);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());
@@ -2111,10 +2135,11 @@ extern "C" int pgsgd_session_iteration_part(pgsgd_session* s, double eta, int co
                 tw.clock_probe = nullptr;
                 tw.items = ta.items + ta.n_items;
                 tw.n_items = windowless;
+                tw.wq_threshold = std::min<uint32_t>(s->tile_wq_threshold, 64u);   // (the window-less instance: one message per lane and call)
                 tw.queue = s->d_queue + 2 * pgsgd::kItemQueues;
                 tw.chunk[0] = 0;
                 for (uint32_t q = 1; q <= pgsgd::kItemQueues; ++q) tw.chunk[q] = windowless;  // one run: every workgroup ends up pulling from it
-                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds, s->stream,
+                hipLaunchKernelGGL(tile_kernel(s->tile_far, s->tile_math, a.cooling != 0, false), dim3(s->tile_grid), dim3(s->tile_block), s->tile_lds1, s->stream,
                                    s->dc, tw, ts, a);
                 s->n_kernels++;
                 HIP_TRY(hipGetLastError());

@@ -175,7 +175,7 @@ struct TileArgs {
     float lock_mu;                     // conflict resolution inside a window: terms whose learning rate mu reaches this take both their ends' locks or do nothing (0: off)
     uint32_t snap_every;               // debug knob PGSGD_TILE_SNAP_EVERY: a tile rewrites its snapshot records every k-th iteration only
     uint32_t lane_coin;                // debug knob PGSGD_TILE_LANE_COIN: the Zipf/uniform coin per lane (bit 31 of its word), as in round 3 (A/B only)
-    uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 * kWqPush (kWqPush per lane); debug knob PGSGD_TILE_WQ
+    uint32_t wq_threshold;             // messages a wave's queue holds before it goes to the rings: 64 per message a lane hands over in one call (PUSH); debug knob PGSGD_TILE_WQ
     unsigned long long* term_count;    // terms this session's tile launches have executed (cumulative; every wave adds what its lanes finished): pgsgd_session_terms_executed
     uint32_t tile_rotate;              // debug knob PGSGD_TILE_ROTATE: an item's tiles start at another one every iteration (which path has the last word on a window)
     Outbox ob;
@@ -229,7 +229,7 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 // lane may write it once the line is back from its previous round, and the writer that completes a line writes it out
 // and reopens it.  A line's state word is (rounds completed << kObStateShift) | slots written in the open round.
 //
-// In front of the rings every WAVE keeps a private queue of packed messages (kWqCap entries: message word + bucket byte).
+// In front of the rings every WAVE keeps a private queue of packed messages (tile_wq_cap(PUSH) entries: message word + bucket byte).
 // A term appends its message there — a ballot, a prefix count and two LDS stores, the fill count lives in a scalar
 // register — and the ring protocol below runs only when 64 messages are waiting, one per lane: its cost does not depend
 // on how many lanes take part (about a hundred vector instructions per call), and in most iterations only a third of the
@@ -242,7 +242,7 @@ __global__ void tile_terms_kernel(const Tile* tiles, uint64_t n_tiles, uint64_t 
 constexpr uint32_t kObStateShift = 4;                 // (kObLine = 8 slots < 1 << 4)
 constexpr uint32_t kWqPush = 2;                       // most messages a lane hands to the rings in one call of their protocol (outbox_push<K>: the warm
                                                       // instance 2, the cooling instance 1)
-constexpr uint32_t kWqCap = 64 * (kWqPush + 1);       // fewer than 64 * kWqPush waiting + at most 64 appended per call
+__host__ __device__ constexpr uint32_t tile_wq_cap(uint32_t push) { return 64u * (push + 1u); }   // fewer than 64 * push waiting + at most 64 appended per call
 // The arrays follow one another behind the tile records; the struct keeps their common base as a byte offset into the
 // workgroup's LDS and works the others out where they are used (a few scalar operations in the rings' protocol, which
 // runs once per 64 messages of a wave) instead of holding eight pointers in scalar registers across the term loop.
@@ -251,6 +251,7 @@ struct OutboxLds {
     uint32_t base;      // byte offset of `stage` in the workgroup's LDS
     uint32_t n_buckets;
     uint32_t ring_b0;   // bucket of hot ring 0 (the window's), wave-uniform
+    uint32_t wq_cap;    // entries of a wave's queue: tile_wq_cap(PUSH), a constant of the kernel instance
     __device__ __forceinline__ uint32_t lines() const { return n_buckets + kObRings * kObRingLines; }
     __device__ __forceinline__ uint32_t at(uint32_t bytes) const {  // (the empty asm keeps the sum at its use: not hoisted out of the term loop into a register of its own)
         uint32_t off = base + bytes;
@@ -260,13 +261,13 @@ struct OutboxLds {
     template <class T> __device__ __forceinline__ T* ptr(uint32_t off) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(tile_lds) + off); }
     // [B + kObRings * kObRingLines][kObLine] staged lines: bucket b's line is b, hot ring r's lines follow
     __device__ __forceinline__ uint64_t* stage() const { return ptr<uint64_t>(at(0)); }
-    // [waves][kWqCap] the waves' private queues: packed messages ...
+    // [waves][wq_cap] the waves' private queues: packed messages ...
     __device__ __forceinline__ uint32_t wq_msg_off() const { return lines() * kObLine * 8u; }
     __device__ __forceinline__ uint64_t* wq_msg() const { return ptr<uint64_t>(at(wq_msg_off())); }
     // (the lines completed in one round of one wave — {staged line, global line index} — are listed in the part of the wave's queue
     // the round's messages were taken from: no array of their own)
     // [B + kObRings] slots claimed
-    __device__ __forceinline__ uint32_t head_off() const { return wq_msg_off() + kTileWaves * kWqCap * 8u; }
+    __device__ __forceinline__ uint32_t head_off() const { return wq_msg_off() + kTileWaves * wq_cap * 8u; }
     __device__ __forceinline__ uint32_t* head() const { return ptr<uint32_t>(at(head_off())); }
     // [B + kObRings * kObRingLines] per line: (rounds completed << kObStateShift) | slots written
     __device__ __forceinline__ uint32_t state_off() const { return head_off() + (n_buckets + kObRings) * 4u; }
@@ -277,15 +278,15 @@ struct OutboxLds {
     // [B] copy of Outbox::chunk0 (read for every line that goes out: not from global memory)
     __device__ __forceinline__ uint32_t chunk0_off() const { return line_off() + n_buckets * 4u; }
     __device__ __forceinline__ uint32_t* chunk0() const { return ptr<uint32_t>(at(chunk0_off())); }
-    // [waves][kWqCap] ... and the queued messages' buckets
+    // [waves][wq_cap] ... and the queued messages' buckets
     __device__ __forceinline__ uint32_t wq_b_off() const { return chunk0_off() + n_buckets * 4u; }
     __device__ __forceinline__ uint8_t* wq_b() const { return ptr<uint8_t>(at(wq_b_off())); }
 };
 
 __host__ __device__ inline uint32_t tile_lock_words(uint32_t region) { return (4u * region + 31u) / 32u; }
-__host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets) {
+__host__ __device__ inline size_t outbox_lds_bytes(uint32_t n_buckets, uint32_t wq_cap) {
     const size_t lines = (size_t)n_buckets + kObRings * kObRingLines;
-    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * kWqCap * (sizeof(uint64_t) + 1) +
+    return lines * kObLine * sizeof(uint64_t) + (size_t)kTileWaves * wq_cap * (sizeof(uint64_t) + 1) +
            ((size_t)n_buckets + kObRings + lines + 2 * (size_t)n_buckets) * sizeof(uint32_t);
 }
 
@@ -339,7 +340,6 @@ __device__ __forceinline__ uint32_t outbox_next_line(const Outbox& ob, const Out
 // Called by all 64 lanes of a wave together (converged).  The protocol's cost is its chain of dependent LDS round trips — claim, line
 // state, slot write + count, the completed lines' places in the pool, their list, their words — not its instructions
 // (profiles/r06/NOTES.md sections 9, 15): with two messages per lane every round trip carries both, and a wave calls half as often.
-__host__ __device__ constexpr uint32_t tile_push_messages(bool cooling) { return cooling ? 1u : kWqPush; }
 template <uint32_t K>
 __device__ __forceinline__ void outbox_push(const Outbox& ob, const OutboxLds& L, uint2* list, const bool (&has_in)[K], const uint32_t (&b)[K], const uint64_t (&packed)[K]) {
     static_assert((K == 1 || K == 2) && K <= kWqPush && kObRings == 2, "the claims below are written for one or two messages per lane and two hot rings");
@@ -755,24 +755,27 @@ struct PendingTerm {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "pgsgd_tiles.hpp is written for gfx950 (MI355X): the fence-free window hand-off and the 128-KiB drain accumulators do not carry over"
 #endif
-template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0>
+template <int COORD_LOAD, int FAR, bool COOLING, bool LOCAL, int MATH = kMathFast, bool LOCK = false, int ABL = 0, uint32_t PUSH = 1>
 __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSGD_TILE_WAVES, PGSGD_TILE_WAVES))) void sgd_tile_kernel(DevConst c, TileArgs ta, TileSampler ts, IterArgs a) {
     static_assert(COORD_LOAD == 1, "the tile kernel stages windows with agent-scope loads: a part of a window may have been written by another workgroup of this launch");
-    // Messages a lane hands to the rings per call of their protocol (tile_push_messages): two in a warm launch — every uniform term sends one, scattered over
-    // all buckets, and half as many calls buy 3.5 % of the launch — one in a cooling launch, whose messages go to the two hot rings at the window
-    // and wait for each other's lines there when a call brings 128 (measured: -0.7 %; profiles/r06/NOTES.md section 15).
-    constexpr uint32_t kPush = tile_push_messages(COOLING);
+    // PUSH: messages a lane hands to the rings per call of their protocol.  Two in the warm launches of a session whose longer wave queues do not cost
+    // it a workgroup per CU (pgsgd_session.hip: tile_push) — every uniform term sends a message, scattered over all buckets, and half as many calls buy
+    // 2 ... 3.5 % of the launch — one in a cooling launch, whose messages go to the two hot rings at the window and wait for each other's lines there when
+    // a call brings 128 (measured: -0.7 %; profiles/r06/NOTES.md section 15).
+    static_assert(PUSH == 1 || (PUSH == 2 && !COOLING), "two messages per lane and call: warm instances only");
+    constexpr uint32_t kPush = PUSH;
     extern __shared__ uint64_t lds[];
     uint64_t* win = lds;                                                         // [4R] window words
     uint4* trec = reinterpret_cast<uint4*>(lds + 4 * (size_t)ta.region);         // [T] tile records
     OutboxLds L;
     L.n_buckets = ta.ob.n_buckets;
+    L.wq_cap = tile_wq_cap(PUSH);   // (a constant of the instance: the launch brings the LDS for it, pgsgd_session.hip: tile_lds_for)
     {
         L.base = (uint32_t)(4 * (size_t)ta.region * sizeof(uint64_t) + (size_t)ta.tile_steps * sizeof(uint4));  // behind the window and the tile records
         for (uint32_t i = threadIdx.x; i < L.n_buckets + kObRings + L.lines(); i += blockDim.x) L.head()[i] = 0;  // heads and line states
     }
     // one lock bit per window word (tile_lock_words(region) 32-bit words behind the queues' bucket bytes)
-    uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b() + kTileWaves * kWqCap);
+    uint32_t* lockw = reinterpret_cast<uint32_t*>(L.wq_b() + kTileWaves * L.wq_cap);
     for (uint32_t i = threadIdx.x; i < tile_lock_words(ta.region); i += blockDim.x) lockw[i] = 0;
     uint32_t n_locked = 0, n_lost = 0;
     // profiling instance 5 (make libpgsgd_x5.so): where a workgroup's time goes, summed by its thread 0 in 100 MHz ticks —
@@ -790,8 +793,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(PGSG
     // this wave's message queue; its fill count is wave-uniform and lives in a scalar register
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveQueue wq;
-    wq.msg = L.wq_msg() + wave * kWqCap;
-    wq.b = L.wq_b() + wave * kWqCap;
+    wq.msg = L.wq_msg() + wave * L.wq_cap;
+    wq.b = L.wq_b() + wave * L.wq_cap;
     uint32_t wq_n = 0;
     L.ring_b0 = 0x7fffffffu;
     __shared__ uint32_t s_item;
