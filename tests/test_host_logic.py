@@ -206,6 +206,25 @@ def test_c_abi_exports_every_declared_symbol(oa):
     assert C.sizeof(_lib.GraphView) == 64 and C.sizeof(_lib.Stats) == 64 and C.sizeof(_lib.Params) == 136
 
 
+def test_shard_flags_rule(oa):
+    """pgsgd_shard_flags — what a multi-GPU driver ORs into its sessions' flags before it creates them: 128-node regions where
+    256-node windows would leave a device fewer than a thousand per launch and 128-node ones leave it at least 240 (the threshold
+    from which pgsgd_session_set_shard(.., -1) shards by region with the exact exchange); nothing for one device, without tiles,
+    with fp32 words or Hogwild stores, when the tile shard is asked for, or when the flag is already there."""
+    from odgi_amd import _lib
+    f, R = _lib.lib.pgsgd_shard_flags, _lib.FLAG_REGION_128
+    assert _lib.lib.pgsgd_abi_version() == 7 and R == 0x40000 and _lib.FLAG_SHARD_TILES == 0x80000
+    # windows per colour: N / 512 with 256-node regions, N / 256 with 128-node ones
+    assert [f(1_000_000, w, 0) for w in (1, 2, 4, 8, 16, 17)] == [0, R, R, R, R, 0]      # 3907 / 16 = 244 >= 240 > 3907 / 17
+    assert [f(10_000_000, w, 0) for w in (2, 8, 19, 20)] == [0, 0, 0, R]                 # 19532 / 19 = 1028 >= 1000 > 19532 / 20
+    assert f(122_880, 2, 0) == R and f(122_879, 2, 0) == R and f(122_624, 2, 0) == 0     # 480 windows of 128-node regions = 240 per device
+    for flags in (_lib.FLAG_NO_TILES, _lib.FLAG_SHARD_TILES, 0x2, 0x4, R):
+        assert f(1_000_000, 8, flags) == 0
+    assert f(1_000_000, 8, _lib.FLAG_SYNC_DRAIN | 0x2000) == R                            # other flags do not matter
+    g = oa.Graph.synthetic(3000, 4, seed=3)
+    assert oa.shard_flags(g, 8) == 0 and oa.shard_flags(g, 1) == 0
+
+
 def test_no_cpu_fallback_without_a_device(oa, graphs):
     """On a machine without a GPU the product must fail loudly, never compute on the CPU."""
     import torch
